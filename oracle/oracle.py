@@ -1,0 +1,307 @@
+"""TEST INFRASTRUCTURE ONLY.
+
+ctypes bindings for
+  * oracle/liboracle.so       -- this repo's plain-C restatement (cwsl_oracle.c, sync_oracle.c)
+  * oracle/_ref/libcwsl_ref.so -- the unmodified reference SSBD.hpp/LowPass.hpp compiled in place
+                                 (present only where `make -C oracle ref` could run)
+
+Nothing in the product path (cwsl_digi_amd/) may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+_i16p = np.ctypeslib.ndpointer(np.int16, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
+
+
+def build(ref=True):
+    """Compile liboracle.so (always) and _ref/libcwsl_ref.so (when the reference is present)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    if ref and os.path.isfile("/root/reference/source/SSBD.hpp"):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
+
+
+class _Demod(C.Structure):
+    _fields_ = [
+        ("fs", C.c_uint64), ("bw", C.c_uint64), ("usb", C.c_int), ("sign", C.c_float),
+        ("block", C.c_uint32), ("ntaps", C.c_uint32),
+        ("taps", C.POINTER(C.c_float)), ("tone_re", C.POINTER(C.c_float)), ("tone_im", C.POINTER(C.c_float)),
+        ("inc_re", C.c_float), ("inc_im", C.c_float), ("ph_re", C.c_float), ("ph_im", C.c_float),
+        ("ws_re", C.c_float * 32), ("ws_im", C.c_float * 32),
+        ("head", C.c_uint32), ("phase_delta", C.c_float),
+    ]
+
+
+class _Channel(C.Structure):
+    _fields_ = [
+        ("mode", C.c_char * 16), ("fs", C.c_uint64), ("iq_len", C.c_uint32), ("demod_hz", C.c_int32),
+        ("scale_ft", C.c_float), ("scale_wspr", C.c_float), ("frame_len", C.c_size_t),
+        ("frame", C.POINTER(C.c_float) * 2), ("fill", C.c_uint64 * 2), ("t0", C.c_uint64 * 2),
+        ("wr", C.c_uint32), ("rd", C.c_uint32), ("demod", _Demod), ("dropped_blocks", C.c_uint64),
+    ]
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.isfile(path):
+            build(ref=False)
+        L = C.CDLL(path)
+        L.orc_lowpass_design.argtypes = [C.c_size_t, C.c_double, _f32p]
+        L.orc_demod_open.argtypes = [C.POINTER(_Demod), C.c_uint64, C.c_uint64, C.c_double, C.c_int]
+        L.orc_demod_close.argtypes = [C.POINTER(_Demod)]
+        L.orc_demod_run.argtypes = [C.POINTER(_Demod), _f32p, C.c_uint64, _f32p, C.c_void_p]
+        L.orc_rx_period.argtypes = [C.c_char_p]; L.orc_rx_period.restype = C.c_double
+        L.orc_frame_len.argtypes = [C.c_char_p]; L.orc_frame_len.restype = C.c_size_t
+        L.orc_prepare_audio.argtypes = [_f32p, C.c_size_t, C.c_char_p, C.c_float, C.c_float, C.POINTER(C.c_float)]
+        L.orc_prepare_audio.restype = C.c_float
+        L.orc_to_int16.argtypes = [_f32p, C.c_size_t, _i16p]
+        L.orc_channel_open.argtypes = [C.POINTER(_Channel), C.c_char_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_float, C.c_float]
+        L.orc_channel_close.argtypes = [C.POINTER(_Channel)]
+        L.orc_channel_push.argtypes = [C.POINTER(_Channel), _f32p]
+        L.orc_channel_boundary.argtypes = [C.POINTER(_Channel), C.c_uint64, _i16p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_float)]
+        L.orc_wav_header.argtypes = [C.c_uint32, C.c_char_p]
+        L.orc_wav_write.argtypes = [C.c_char_p, _i16p, C.c_uint32]
+        L.orc_mix64.argtypes = [C.c_uint64]; L.orc_mix64.restype = C.c_uint64
+        L.orc_synth_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _f32p]
+        L.orc_synth_add_tones.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _f64p, C.c_int, C.c_float, _f32p]
+        L.orc_checksum_f32.argtypes = [_f32p, C.c_size_t]; L.orc_checksum_f32.restype = C.c_double
+        L.orc_crc32.argtypes = [C.c_void_p, C.c_size_t]; L.orc_crc32.restype = C.c_uint32
+        _lib = L
+    return _lib
+
+
+def have_ref():
+    return os.path.isfile(os.path.join(_HERE, "_ref", "libcwsl_ref.so"))
+
+
+def ref():
+    """The compiled reference headers.  Raises if the build container did not produce them."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(_HERE, "_ref", "libcwsl_ref.so")
+        if not os.path.isfile(path):
+            raise RuntimeError("oracle/_ref/libcwsl_ref.so absent (run `make -C oracle ref` where /root/reference exists)")
+        R = C.CDLL(path)
+        R.ref_ssbd_new.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_int, C.c_char_p, C.c_int]
+        R.ref_ssbd_new.restype = C.c_void_p
+        R.ref_ssbd_delete.argtypes = [C.c_void_p]
+        for n in ("in_size", "out_size", "out_rate", "delay", "filt_order", "block_size"):
+            f = getattr(R, "ref_ssbd_" + n); f.argtypes = [C.c_void_p]; f.restype = C.c_uint64
+        R.ref_ssbd_get_taps.argtypes = [C.c_void_p, _f32p]
+        R.ref_ssbd_get_tone.argtypes = [C.c_void_p, _f32p, _f32p, _f32p]
+        R.ref_ssbd_run.argtypes = [C.c_void_p, _f32p, C.c_uint64, _f32p, C.c_void_p]
+        R.ref_ssbd_run.restype = C.c_int
+        R.ref_build_lowpass.argtypes = [C.c_uint64, C.c_double, _f32p]
+        _ref = R
+    return _ref
+
+
+# ----------------------------------------------------------------------------------------------
+# numpy-level helpers
+# ----------------------------------------------------------------------------------------------
+ERRORS = {-1: "Fs/B must be an even integer >= 4", -2: "Signal outside of band (low)",
+          -3: "Signal outside of band (high)", -4: "alloc", -5: "Unhandled mode"}
+
+
+class Demod:
+    """orc_demod_t: the SSBD<float> restatement."""
+
+    def __init__(self, fs, f_hz, bw=6000, usb=True):
+        self.s = _Demod()
+        rc = lib().orc_demod_open(C.byref(self.s), fs, bw, float(f_hz), 1 if usb else 0)
+        if rc != 0:
+            raise ValueError(ERRORS.get(rc, str(rc)))
+        self.block = self.s.block
+        self.ntaps = self.s.ntaps
+
+    def close(self):
+        if self.s is not None:
+            lib().orc_demod_close(C.byref(self.s)); self.s = None
+
+    __del__ = close
+
+    @property
+    def taps(self):
+        return np.ctypeslib.as_array(self.s.taps, (self.ntaps,)).copy()
+
+    @property
+    def tone(self):
+        re = np.ctypeslib.as_array(self.s.tone_re, (self.block,))
+        im = np.ctypeslib.as_array(self.s.tone_im, (self.block,))
+        t = np.empty(self.block, np.complex64)   # no arithmetic: keep -0.0 signs
+        t.real = re; t.imag = im
+        return t
+
+    @property
+    def phase_inc(self):
+        return np.array([self.s.inc_re, self.s.inc_im], np.float32).view(np.complex64)[0]
+
+    @property
+    def phase_delta(self):
+        return np.float32(self.s.phase_delta)
+
+    def run(self, iq, trace=False):
+        """iq: complex64[n] (n multiple of 4*block) -> float32[n/block] (+ complex64 phasor trace)."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        n = iq.shape[0]
+        assert n % (4 * self.block) == 0
+        out = np.empty(n // self.block, np.float32)
+        tr = np.empty(2 * (n // self.block), np.float32) if trace else None
+        lib().orc_demod_run(C.byref(self.s), iq.view(np.float32), n, out,
+                            tr.ctypes.data if trace else None)
+        return (out, tr.view(np.complex64)) if trace else out
+
+
+class RefDemod:
+    """SSBD<float> itself (oracle/_ref)."""
+
+    def __init__(self, fs, f_hz, bw=6000, usb=True):
+        err = C.create_string_buffer(256)
+        self.h = ref().ref_ssbd_new(fs, bw, float(f_hz), 1 if usb else 0, err, 256)
+        if not self.h:
+            raise ValueError(err.value.decode())
+        self.block = int(ref().ref_ssbd_block_size(self.h))
+        self.ntaps = int(ref().ref_ssbd_filt_order(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            ref().ref_ssbd_delete(self.h); self.h = None
+
+    __del__ = close
+
+    @property
+    def taps(self):
+        t = np.empty(self.ntaps, np.float32); ref().ref_ssbd_get_taps(self.h, t); return t
+
+    def _tone(self):
+        t = np.empty(2 * self.block, np.float32); inc = np.empty(2, np.float32); ph = np.empty(2, np.float32)
+        ref().ref_ssbd_get_tone(self.h, t, inc, ph)
+        return t.view(np.complex64), inc.view(np.complex64)[0], ph.view(np.complex64)[0]
+
+    @property
+    def tone(self):
+        return self._tone()[0]
+
+    @property
+    def phase_inc(self):
+        return self._tone()[1]
+
+    def run(self, iq, trace=False):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        n = iq.shape[0]
+        assert n % (4 * self.block) == 0
+        out = np.empty(n // self.block, np.float32)
+        tr = np.empty(2 * (n // self.block), np.float32) if trace else None
+        rc = ref().ref_ssbd_run(self.h, iq.view(np.float32), n, out, tr.ctypes.data if trace else None)
+        assert rc == 0
+        return (out, tr.view(np.complex64)) if trace else out
+
+
+class Channel:
+    """orc_channel_t: Instance::sampleManager restated (one channel, 2-frame ring)."""
+
+    def __init__(self, mode, fs, iq_len, demod_hz, scale_ft=0.90, scale_wspr=0.20):
+        self.c = _Channel()
+        rc = lib().orc_channel_open(C.byref(self.c), mode.encode(), fs, iq_len, int(demod_hz), scale_ft, scale_wspr)
+        if rc != 0:
+            raise ValueError(ERRORS.get(rc, str(rc)))
+        self.frame_len = self.c.frame_len
+        self.iq_len = iq_len
+
+    def close(self):
+        if self.c is not None:
+            lib().orc_channel_close(C.byref(self.c)); self.c = None
+
+    __del__ = close
+
+    def push(self, iq_block):
+        iq_block = np.ascontiguousarray(iq_block, dtype=np.complex64)
+        assert iq_block.shape[0] == self.iq_len
+        return lib().orc_channel_push(C.byref(self.c), iq_block.view(np.float32))
+
+    def push_many(self, iq):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        assert iq.shape[0] % self.iq_len == 0
+        v = iq.view(np.float32)
+        took = 0
+        for k in range(iq.shape[0] // self.iq_len):
+            took += lib().orc_channel_push(C.byref(self.c), v[2 * k * self.iq_len: 2 * (k + 1) * self.iq_len])
+        return took
+
+    def boundary(self, epoch_s, want_f32=False):
+        """-> None (frame discarded) or dict(i16, t_start, factor[, f32])."""
+        i16 = np.empty(self.frame_len, np.int16)
+        t0 = C.c_uint64(0); fac = C.c_float(0)
+        f32 = np.empty(self.frame_len, np.float32) if want_f32 else None
+        got = lib().orc_channel_boundary(C.byref(self.c), epoch_s, i16, C.byref(t0),
+                                         f32.ctypes.data if want_f32 else None, C.byref(fac))
+        if not got:
+            return None
+        r = dict(i16=i16, t_start=t0.value, factor=np.float32(fac.value))
+        if want_f32:
+            r["f32"] = f32
+        return r
+
+    @property
+    def fill(self):
+        return int(self.c.fill[self.c.wr])
+
+    @property
+    def dropped(self):
+        return int(self.c.dropped_blocks)
+
+
+def frame_len(mode):
+    return int(lib().orc_frame_len(mode.encode()))
+
+
+def prepare_audio(buf, mode, scale_ft=0.90, scale_wspr=0.20):
+    """Returns (scaled copy, factor, peak)."""
+    b = np.array(buf, dtype=np.float32, copy=True)
+    pk = C.c_float(0)
+    f = lib().orc_prepare_audio(b, b.shape[0], mode.encode(), scale_ft, scale_wspr, C.byref(pk))
+    return b, np.float32(f), np.float32(pk.value)
+
+
+def to_int16(buf):
+    b = np.ascontiguousarray(buf, dtype=np.float32)
+    o = np.empty(b.shape[0], np.int16)
+    lib().orc_to_int16(b, b.shape[0], o)
+    return o
+
+
+def wav_header(n_samples):
+    h = C.create_string_buffer(46)
+    lib().orc_wav_header(n_samples, h)
+    return h.raw
+
+
+def synth_iq(seed, n, fs=192000, tones_hz=(), amp=2.0e4, first=0):
+    """Portable synthetic IQ: integer noise (sigma~1182) + table-lookup tones.  complex64[n]."""
+    x = np.empty(2 * n, np.float32)
+    lib().orc_synth_noise(seed, first, n, x)
+    if len(tones_hz):
+        f = np.ascontiguousarray(tones_hz, dtype=np.float64)
+        lib().orc_synth_add_tones(fs, first, n, f, len(f), amp, x)
+    return x.view(np.complex64)
+
+
+def checksum(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    return float(lib().orc_checksum_f32(x, x.shape[0]))
+
+
+def crc32(a):
+    a = np.ascontiguousarray(a)
+    return int(lib().orc_crc32(a.ctypes.data, a.nbytes))

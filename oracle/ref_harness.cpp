@@ -1,0 +1,109 @@
+// TEST INFRASTRUCTURE ONLY -- never linked into the product path.
+//
+// Thin extern "C" harness around the *unmodified* reference DSP headers
+// (/root/reference/source/SSBD.hpp + LowPass.hpp), compiled in place by
+// oracle/Makefile into oracle/_ref/libcwsl_ref.so.  No reference source is
+// copied into this repository: the headers are found through -I at build
+// time and only exist in the build container.
+//
+// Build of record: g++ -std=c++17 -O2 -ffp-contract=off,
+// no -march=native, no -ffast-math.
+//
+// The harness exposes the reference's private state (taps, tone, phasor) by
+// compiling the header with `private` remapped; this changes access control
+// only, not a single arithmetic instruction.
+#include <cstddef>
+#include <cstdint>
+#include <complex>
+#include <vector>
+#include <stdexcept>
+#include <cstring>
+#include <cstdlib>
+#include <algorithm>
+#include <cmath>
+
+#define private public
+#include "SSBD.hpp"
+#undef private
+
+extern "C" {
+
+// Opaque handle = SSBD<float>* (the only instantiation the reference uses,
+// Instance.cpp:187).
+void* ref_ssbd_new(uint64_t Fs, uint64_t B, double F, int usb, char* err, int errlen)
+{
+    try {
+        return new SSBD<float>(Fs, B, F, usb != 0);
+    } catch (const std::exception& e) {
+        if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+        return nullptr;
+    }
+}
+
+void ref_ssbd_delete(void* h) { delete static_cast<SSBD<float>*>(h); }
+
+uint64_t ref_ssbd_in_size(void* h)  { return static_cast<SSBD<float>*>(h)->GetInSize(); }
+uint64_t ref_ssbd_out_size(void* h) { return static_cast<SSBD<float>*>(h)->GetOutSize(); }
+uint64_t ref_ssbd_out_rate(void* h) { return static_cast<SSBD<float>*>(h)->GetOutRate(); }
+uint64_t ref_ssbd_delay(void* h)    { return static_cast<SSBD<float>*>(h)->GetDelay(); }
+uint64_t ref_ssbd_filt_order(void* h) { return static_cast<SSBD<float>*>(h)->FiltOrder; }
+uint64_t ref_ssbd_block_size(void* h) { return static_cast<SSBD<float>*>(h)->BlockSize; }
+
+// taps[FiltOrder] (normalised, as the object holds them)
+void ref_ssbd_get_taps(void* h, float* taps)
+{
+    auto* s = static_cast<SSBD<float>*>(h);
+    for (size_t n = 0; n < s->FiltOrder; ++n) taps[n] = s->filter[n];
+}
+
+// tone[BlockSize] interleaved re,im ; phase_inc (2) ; phase (2)
+void ref_ssbd_get_tone(void* h, float* tone_ri, float* phase_inc_ri, float* phase_ri)
+{
+    auto* s = static_cast<SSBD<float>*>(h);
+    for (size_t n = 0; n < s->BlockSize; ++n) {
+        tone_ri[2 * n] = s->tone[n].real();
+        tone_ri[2 * n + 1] = s->tone[n].imag();
+    }
+    phase_inc_ri[0] = s->phase_inc.real(); phase_inc_ri[1] = s->phase_inc.imag();
+    phase_ri[0] = s->phase.real(); phase_ri[1] = s->phase.imag();
+}
+
+// Drive Iterate() exactly as Instance.cpp:273-275 does: n_complex must be a
+// multiple of GetInSize(); out receives n_complex / (GetInSize()/4) floats.
+// If phase_trace != NULL it receives the phasor (re,im) *before* every block,
+// i.e. phase_b for b = 0 .. n_complex/BlockSize-1.
+// Returns 0, or -1 if the traced phasor ever disagreed with the object's own
+// state after Iterate() (it must not: same operator, same flags).
+int ref_ssbd_run(void* h, const float* iq_ri, uint64_t n_complex, float* out, float* phase_trace)
+{
+    int rc = 0;
+    auto* s = static_cast<SSBD<float>*>(h);
+    const std::complex<float>* xc = reinterpret_cast<const std::complex<float>*>(iq_ri);
+    const size_t in_size = s->GetInSize();
+    const size_t dec = in_size / 4;
+    for (size_t n = 0; n < n_complex; n += in_size) {
+        std::complex<float> p = s->phase;
+        if (phase_trace) {
+            // phasor before each of the 4 blocks: replay the recurrence on a copy
+            for (int k = 0; k < 4; ++k) {
+                const size_t b = n / s->BlockSize + k;
+                phase_trace[2 * b] = p.real();
+                phase_trace[2 * b + 1] = p.imag();
+                p *= s->phase_inc;
+            }
+        }
+        s->Iterate(xc + n, out + n / dec);
+        if (phase_trace && std::memcmp(&p, &s->phase, sizeof(p)) != 0) rc = -1;
+    }
+    return rc;
+}
+
+// BuildLowPass<float> alone (LowPass.hpp:16-35), un-normalised.
+void ref_build_lowpass(uint64_t order, double bandwidth, float* taps)
+{
+    float* f = BuildLowPass<float>(order, bandwidth);
+    for (size_t n = 0; n < order; ++n) taps[n] = f[n];
+    delete[] f;
+}
+
+} // extern "C"
