@@ -1,0 +1,10 @@
+"""cwsl_digi_amd -- MI355X-native replacement for CWSL_DIGI's per-Instance DSP chain.
+
+The product is the HIP shared library cwsl_digi_amd/lib/libcwslgpu.so (C ABI: include/cwsl_gpu.h).
+This package is only the loader plus a thin Python mirror of that ABI for tests and bench.py.
+There is no CPU fallback anywhere in this package.
+"""
+from .api import (Context, CwslGpuError, GROUPS, group_of, frame_len, load_library,  # noqa: F401
+                  STATUS_NAMES)
+
+__all__ = ["Context", "CwslGpuError", "GROUPS", "group_of", "frame_len", "load_library", "STATUS_NAMES"]

@@ -1,0 +1,299 @@
+"""ctypes mirror of include/cwsl_gpu.h.
+
+Naming follows the reference's seams (source/Receiver.hpp, source/Instance.cpp, source/SSBD.hpp):
+a Context owns Receivers (IQ rings in HBM) and Channels (one SSBD + frame pair each); slot
+boundaries are signalled per SyncPredicates group.  Every call goes through libcwslgpu.so; if the
+library or a gfx950 device is missing this raises -- nothing here computes DSP on the CPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libcwslgpu.so")
+
+STATUS_NAMES = {
+    0: "OK", -1: "ERR_RATIO", -2: "ERR_BAND_LOW", -3: "ERR_BAND_HIGH", -4: "ERR_NOMEM", -5: "ERR_MODE",
+    -6: "ERR_ARG", -7: "ERR_NO_DEVICE", -8: "ERR_HIP", -9: "ERR_NO_FRAME", -10: "ERR_UNSUPPORTED",
+    -11: "ERR_BLOCK",
+}
+ERR_NO_FRAME = -9
+
+# CWSL_DIGI_Types.hpp:83-143
+GROUPS = {"FT8": 0, "FT4": 1, "Q65_30": 2, "S60": 3, "S120": 4, "S300": 5, "S900": 6, "S1800": 7}
+_MODE_GROUP = {
+    "FT8": 0, "JS8": 0, "FT4": 1, "Q65-30": 2, "JT65": 3, "FST4-60": 3, "WSPR": 4, "FST4-120": 4,
+    "FST4W-120": 4, "FST4-300": 5, "FST4W-300": 5, "FST4-900": 6, "FST4W-900": 6, "FST4-1800": 7,
+    "FST4W-1800": 7,
+}
+_MODE_PERIOD = {
+    "FT8": 15.0, "JS8": 15.0, "FT4": 7.5, "WSPR": 120.0, "Q65-30": 30.0, "JT65": 60.0, "FST4-60": 60.0,
+    "FST4-120": 120.0, "FST4-300": 300.0, "FST4-900": 900.0, "FST4-1800": 1800.0, "FST4W-120": 120.0,
+    "FST4W-300": 300.0, "FST4W-900": 900.0, "FST4W-1800": 1800.0,
+}
+
+
+def group_of(mode):
+    return _MODE_GROUP[mode]
+
+
+def frame_len(mode):
+    """Instance.cpp:149 : 12000 * (period + 5)."""
+    return int(12000.0 * float(np.float32(_MODE_PERIOD[mode]) + np.float32(5)))
+
+
+class CwslGpuError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        name = STATUS_NAMES.get(status, str(status))
+        super().__init__(f"libcwslgpu: {name}" + (f": {detail}" if detail else ""))
+
+
+class Candidate(C.Structure):
+    _fields_ = [("freq_bin", C.c_int32), ("time_step", C.c_int32), ("sync", C.c_float),
+                ("freq_hz", C.c_float), ("dt_s", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("demod_launches", C.c_uint64), ("demod_samples", C.c_uint64),
+                ("finalize_launches", C.c_uint64), ("frames_emitted", C.c_uint64),
+                ("frames_discarded", C.c_uint64), ("blocks_dropped", C.c_uint64),
+                ("h2d_bytes", C.c_uint64), ("demod_ms", C.c_double), ("finalize_ms", C.c_double),
+                ("sync_ms", C.c_double)]
+
+
+_lib = None
+
+# every symbol include/cwsl_gpu.h declares (tests check the library exports exactly these)
+ABI_SYMBOLS = [
+    "cwslg_abi_version", "cwslg_create", "cwslg_destroy", "cwslg_strerror", "cwslg_last_error",
+    "cwslg_set_scale_factors", "cwslg_receiver_open", "cwslg_receiver_close", "cwslg_push_iq",
+    "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_channel_open", "cwslg_channel_close",
+    "cwslg_channel_info", "cwslg_process", "cwslg_slot_boundary", "cwslg_slot_boundary_channel",
+    "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
+    "cwslg_enable_sync", "cwslg_fetch_candidates", "cwslg_get_stats", "cwslg_reset_stats",
+    "cwslg_set_timing", "cwslg_stream", "cwslg_channel_constants", "cwslg_channel_phasor_checkpoints",
+]
+
+
+def load_library(build_if_missing=True):
+    """dlopen libcwslgpu.so.  Raises (never falls back) if it is absent and cannot be built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(_LIB_PATH):
+        if not build_if_missing:
+            raise CwslGpuError(-7, f"{_LIB_PATH} not built")
+        _build.build()
+    try:
+        # If torch is (or will be) in the process, let it load ITS libamdhip64 first: both copies carry
+        # SONAME libamdhip64.so.7 and two HIP runtimes in one process do not share device pointers.
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(_LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, i32, u32, u64, f32 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_float
+    L.cwslg_abi_version.restype = i32
+    L.cwslg_create.argtypes = [C.POINTER(vp), i32]
+    L.cwslg_destroy.argtypes = [vp]; L.cwslg_destroy.restype = None
+    L.cwslg_strerror.argtypes = [i32]; L.cwslg_strerror.restype = C.c_char_p
+    L.cwslg_last_error.argtypes = [vp]; L.cwslg_last_error.restype = C.c_char_p
+    L.cwslg_set_scale_factors.argtypes = [vp, f32, f32]
+    L.cwslg_receiver_open.argtypes = [vp, u32, u32, C.c_int32, u32, C.POINTER(i32)]
+    L.cwslg_receiver_close.argtypes = [vp, i32]
+    L.cwslg_push_iq.argtypes = [vp, i32, vp, u32]
+    L.cwslg_push_iq_device.argtypes = [vp, i32, vp, u32]
+    L.cwslg_push_synth.argtypes = [vp, i32, u64, u32, u32, vp, i32, f32]
+    L.cwslg_ring_commit.argtypes = [vp, i32, u32, u32]
+    L.cwslg_ring_commit_all.argtypes = [vp, u32, u32]
+    L.cwslg_ring_info.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(u32), C.POINTER(u64)]
+    L.cwslg_channel_open.argtypes = [vp, i32, C.c_int32, i32, C.c_char_p, C.POINTER(i32)]
+    L.cwslg_channel_close.argtypes = [vp, i32]
+    L.cwslg_channel_info.argtypes = [vp, i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_size_t)]
+    L.cwslg_process.argtypes = [vp]
+    L.cwslg_slot_boundary.argtypes = [vp, i32, u64]
+    L.cwslg_slot_boundary_channel.argtypes = [vp, i32, u64]
+    L.cwslg_synchronize.argtypes = [vp]
+    L.cwslg_fetch_frame.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(u64), C.POINTER(C.c_size_t), C.POINTER(f32)]
+    L.cwslg_fetch_audio_f32.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.cwslg_frame_device_ptrs.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
+    L.cwslg_enable_sync.argtypes = [vp, i32, f32, i32, i32, i32]
+    L.cwslg_fetch_candidates.argtypes = [vp, i32, C.POINTER(Candidate), i32, C.POINTER(i32)]
+    L.cwslg_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.cwslg_reset_stats.argtypes = [vp]
+    L.cwslg_set_timing.argtypes = [vp, i32]
+    L.cwslg_stream.argtypes = [vp]; L.cwslg_stream.restype = vp
+    L.cwslg_channel_constants.argtypes = [vp, i32, vp, vp, vp]
+    L.cwslg_channel_phasor_checkpoints.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    _lib = L
+    return L
+
+
+class Context:
+    """One GPU's worth of receivers and channels (one process per GPU)."""
+
+    def __init__(self, device=-1):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.cwslg_create(C.byref(h), device)
+        if rc != 0:
+            raise CwslGpuError(rc, self.L.cwslg_strerror(rc).decode())
+        self.h = h
+        self._modes = {}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cwslg_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise CwslGpuError(rc, self.L.cwslg_last_error(self.h).decode() or self.L.cwslg_strerror(rc).decode())
+        return rc
+
+    # ---- Receiver.hpp ----
+    def receiver_open(self, fs=192000, iq_len=2048, lo_hz=0, ring_blocks=0):
+        rid = C.c_int(-1)
+        self._chk(self.L.cwslg_receiver_open(self.h, fs, iq_len, lo_hz, ring_blocks, C.byref(rid)))
+        return rid.value
+
+    def receiver_close(self, rx):
+        self._chk(self.L.cwslg_receiver_close(self.h, rx))
+
+    def push_iq(self, rx, iq):
+        """iq: complex64[n] host array (one or more Receiver blocks)."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        self._chk(self.L.cwslg_push_iq(self.h, rx, iq.ctypes.data, iq.shape[0]))
+
+    def push_iq_device(self, rx, dptr, n_complex):
+        self._chk(self.L.cwslg_push_iq_device(self.h, rx, C.c_void_p(dptr), n_complex))
+
+    def push_synth(self, rx, seed, n_complex, block_len=0, tones_hz=(), amp=2.0e4):
+        t = np.ascontiguousarray(tones_hz, dtype=np.float64)
+        self._chk(self.L.cwslg_push_synth(self.h, rx, seed, n_complex, block_len,
+                                          t.ctypes.data if len(t) else None, len(t), amp))
+
+    def ring_commit(self, rx, n_complex, block_len=0):
+        self._chk(self.L.cwslg_ring_commit(self.h, rx, n_complex, block_len))
+
+    def ring_commit_all(self, n_complex, block_len=0):
+        self._chk(self.L.cwslg_ring_commit_all(self.h, n_complex, block_len))
+
+    def ring_info(self, rx):
+        p, cap, tot = C.c_void_p(), C.c_uint32(), C.c_uint64()
+        self._chk(self.L.cwslg_ring_info(self.h, rx, C.byref(p), C.byref(cap), C.byref(tot)))
+        return p.value, cap.value, tot.value
+
+    # ---- Instance.cpp / SSBD.hpp ----
+    def channel_open(self, rx, demod_hz, mode="FT8", usb=True):
+        cid = C.c_int(-1)
+        self._chk(self.L.cwslg_channel_open(self.h, rx, int(demod_hz), 1 if usb else 0, mode.encode(), C.byref(cid)))
+        self._modes[cid.value] = mode
+        return cid.value
+
+    def channel_close(self, ch):
+        self._chk(self.L.cwslg_channel_close(self.h, ch))
+        self._modes.pop(ch, None)
+
+    def channel_info(self, ch):
+        a, b, c_, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        fl = C.c_size_t()
+        self._chk(self.L.cwslg_channel_info(self.h, ch, C.byref(a), C.byref(b), C.byref(c_), C.byref(d), C.byref(fl)))
+        return dict(in_size=a.value, out_size=b.value, out_rate=c_.value, delay=d.value, frame_len=fl.value)
+
+    def process(self):
+        self._chk(self.L.cwslg_process(self.h))
+
+    def slot_boundary(self, group, epoch_s):
+        g = GROUPS[group] if isinstance(group, str) else int(group)
+        self._chk(self.L.cwslg_slot_boundary(self.h, g, int(epoch_s)))
+
+    def slot_boundary_channel(self, ch, epoch_s):
+        self._chk(self.L.cwslg_slot_boundary_channel(self.h, ch, int(epoch_s)))
+
+    def synchronize(self):
+        self._chk(self.L.cwslg_synchronize(self.h))
+
+    def fetch_frame(self, ch):
+        """-> None until a frame was finalised, else dict(i16, t_start, n_valid, factor)."""
+        n = frame_len(self._modes[ch])
+        out = np.empty(n, np.int16)
+        t0, nv, fac = C.c_uint64(), C.c_size_t(), C.c_float()
+        rc = self.L.cwslg_fetch_frame(self.h, ch, out.ctypes.data, n, C.byref(t0), C.byref(nv), C.byref(fac))
+        if rc == ERR_NO_FRAME:
+            return None
+        self._chk(rc)
+        return dict(i16=out, t_start=t0.value, n_valid=nv.value, factor=np.float32(fac.value))
+
+    def fetch_audio_f32(self, ch):
+        n = frame_len(self._modes[ch])
+        out = np.empty(n, np.float32)
+        nv = C.c_size_t()
+        rc = self.L.cwslg_fetch_audio_f32(self.h, ch, out.ctypes.data, n, C.byref(nv))
+        if rc == ERR_NO_FRAME:
+            return None
+        self._chk(rc)
+        return out, nv.value
+
+    def frame_device_ptrs(self, ch):
+        a, b = C.c_void_p(), C.c_void_p()
+        self._chk(self.L.cwslg_frame_device_ptrs(self.h, ch, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def enable_sync(self, enable=True, syncmin=1.5, max_cand=200, f_lo_hz=200, f_hi_hz=3000):
+        self._chk(self.L.cwslg_enable_sync(self.h, 1 if enable else 0, syncmin, max_cand, f_lo_hz, f_hi_hz))
+
+    def fetch_candidates(self, ch, max_cand=600):
+        buf = (Candidate * max_cand)()
+        n = C.c_int()
+        self._chk(self.L.cwslg_fetch_candidates(self.h, ch, buf, max_cand, C.byref(n)))
+        return [(buf[k].freq_bin, buf[k].time_step, buf[k].sync, buf[k].freq_hz, buf[k].dt_s) for k in range(n.value)]
+
+    def stats(self):
+        s = Stats()
+        self._chk(self.L.cwslg_get_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def reset_stats(self):
+        self._chk(self.L.cwslg_reset_stats(self.h))
+
+    def set_timing(self, on=True):
+        self._chk(self.L.cwslg_set_timing(self.h, 1 if on else 0))
+
+    def set_scale_factors(self, ft=0.90, wspr=0.20):
+        self._chk(self.L.cwslg_set_scale_factors(self.h, ft, wspr))
+
+    def stream(self):
+        return self.L.cwslg_stream(self.h)
+
+    def channel_constants(self, ch):
+        """(taps float32[32D], tone complex64[D], phase_inc complex64) exactly as uploaded."""
+        D = self.channel_info(ch)["in_size"] // 4
+        taps = np.empty(32 * D, np.float32)
+        tone = np.empty(2 * D, np.float32)
+        inc = np.empty(2, np.float32)
+        self._chk(self.L.cwslg_channel_constants(self.h, ch, taps.ctypes.data, tone.ctypes.data, inc.ctypes.data))
+        return taps, tone.view(np.complex64), inc.view(np.complex64)[0]
+
+    def phasor_checkpoints(self, ch, n=None):
+        tot = C.c_size_t()
+        self._chk(self.L.cwslg_channel_phasor_checkpoints(self.h, ch, None, 0, C.byref(tot)))
+        n = tot.value if n is None else min(n, tot.value)
+        out = np.empty(2 * n, np.float32)
+        self._chk(self.L.cwslg_channel_phasor_checkpoints(self.h, ch, out.ctypes.data, n, C.byref(tot)))
+        return out.view(np.complex64)

@@ -1,0 +1,989 @@
+// cwsl_gpu.hip -- host runtime + C ABI of libcwslgpu.so (see include/cwsl_gpu.h).
+//
+// Reference design  : N Instance threads each pull every IQ block and run a scalar recursive filter
+//                     (source/Instance.cpp:178-288).
+// This design       : the Receiver pushes each block ONCE into a ring in HBM; one batched kernel advances
+//                     ALL channels; one batched kernel finalises ALL frames of a slot-clock group.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC (see cwsl_digi_amd/build.py)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/cwsl_gpu.h"
+#include "demod_kernels.hpp"
+#include "host_dsp.hpp"
+#include "sync_kernels.hpp"
+
+namespace cwslg {
+
+// ---------------------------------------------------------------------------------------------
+constexpr int kTile = 256;             // outputs per demod workgroup
+constexpr int kDemodThreads = 256;
+constexpr int kFinThreads = 256;
+constexpr int kCkptStride = 16;        // blocks between phasor checkpoints
+constexpr size_t kStageHalf = 16u << 20;   // pinned staging: two halves of 16 MiB
+constexpr int kWorkBufs = 8;
+
+struct Receiver {
+    bool open = false;
+    uint32_t fs = 0, iq_len = 0, D = 0;
+    int32_t lo_hz = 0;
+    float2 *d_ring = nullptr;
+    uint32_t cap = 0;                  // complex samples
+    uint64_t total = 0;                // samples pushed since open
+    std::vector<int> channels;
+};
+
+struct PhasorTable {
+    float2 *d_ckpt = nullptr;
+    size_t n_ckpt = 0;
+    int refs = 0;
+    bool built = false;
+    float2 inc{};
+};
+
+struct Channel {
+    bool open = false;
+    int rx = -1;
+    int32_t demod_hz = 0;
+    bool usb = true;
+    std::string mode;
+    int group = 0;
+    bool wspr_scale = false;           // mode == "WSPR" exactly (Instance.cpp:320)
+    bool sync_ft8 = false, sync_ft4 = false;
+    size_t frame_len = 0;
+    // device storage (one allocation)
+    char *d_block = nullptr;
+    float *d_frame[2] = {nullptr, nullptr};
+    int16_t *d_i16 = nullptr;
+    unsigned *d_peak = nullptr;        // [2]
+    float *d_factor = nullptr;
+    float2 *d_tone = nullptr;
+    // constants
+    DemodConstants k;
+    std::tuple<uint32_t, int32_t, int, size_t> phasor_key;
+    // Instance state (Instance.cpp:203-276)
+    uint64_t fill[2] = {0, 0};
+    uint64_t t0[2] = {0, 0};
+    int wr = 0, rd = 0;
+    int64_t origin_abs = 0;            // receiver sample index at which the demodulator was created
+    int64_t pend_lo = 0;               // first not-yet-demodulated sample
+    uint32_t pend_n = 0;               // samples accepted but not yet demodulated
+    uint64_t pend_fill0 = 0;           // frame fill at pend_lo
+    bool saturated = false;            // "af buffer full" until the next boundary
+    // last finalised frame
+    bool have_frame = false;
+    int frame_idx = 0;
+    uint64_t frame_t0 = 0;
+    size_t frame_valid = 0;
+    // sync results
+    int n_cand = 0;
+    SyncChannelBuffers syncbuf;
+};
+
+struct WorkBuf {
+    void *h = nullptr;                 // pinned
+    void *d = nullptr;
+    size_t bytes = 0;
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+};
+
+struct TimedSpan {
+    hipEvent_t a, b;
+    int kind;                          // 0 demod, 1 finalize, 2 sync
+};
+
+} // namespace cwslg
+
+using namespace cwslg;
+
+struct cwslg_ctx {
+    std::mutex mu;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    float scale_ft = 0.90f, scale_wspr = 0.20f;    // CWSL_DIGI.cpp:100-101
+    std::vector<Receiver> rxs;
+    std::vector<Channel> chans;
+    std::map<uint32_t, float *> d_taps;            // per sample rate
+    std::map<uint32_t, std::vector<float>> h_taps;
+    std::map<std::tuple<uint32_t, int32_t, int, size_t>, PhasorTable> phasors;
+    std::vector<decltype(phasors)::key_type> phasor_todo;
+    float2 *d_sincos = nullptr;
+    // staging for host pushes
+    char *h_stage = nullptr;
+    size_t stage_pos = 0;
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    bool stage_busy[2] = {false, false};
+    // launch descriptors
+    WorkBuf wb[kWorkBufs];
+    int wb_next = 0;
+    // stats / timing
+    cwslg_stats stats{};
+    bool timing = false;
+    std::vector<TimedSpan> spans;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    // sync stage
+    SyncConfig sync_cfg;
+    SyncShared sync_shared;
+};
+
+namespace {
+
+int fail(cwslg_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->last_error = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(ctx, CWSLG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                     \
+    } while (0)
+
+int sync_launch(cwslg_ctx *c, const std::vector<int> &emitted);
+
+WorkBuf *acquire_workbuf(cwslg_ctx *c, size_t bytes)
+{
+    WorkBuf &w = c->wb[c->wb_next];
+    c->wb_next = (c->wb_next + 1) % kWorkBufs;
+    if (w.in_flight) {
+        hipEventSynchronize(w.done);
+        w.in_flight = false;
+    }
+    if (w.bytes < bytes) {
+        if (w.h) hipHostFree(w.h);
+        if (w.d) hipFree(w.d);
+        size_t nb = std::max<size_t>(bytes, 64 << 10);
+        nb = (nb + 4095) & ~size_t(4095);
+        if (hipHostMalloc(&w.h, nb, hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (hipMalloc(&w.d, nb) != hipSuccess) return nullptr;
+        w.bytes = nb;
+    }
+    if (!w.done) hipEventCreateWithFlags(&w.done, hipEventDisableTiming);
+    return &w;
+}
+
+void span_begin(cwslg_ctx *c, int kind, hipEvent_t *a, hipEvent_t *b)
+{
+    *a = *b = nullptr;
+    if (!c->timing) return;
+    std::pair<hipEvent_t, hipEvent_t> p;
+    if (!c->ev_pool.empty()) {
+        p = c->ev_pool.back();
+        c->ev_pool.pop_back();
+    } else {
+        hipEventCreate(&p.first);
+        hipEventCreate(&p.second);
+    }
+    *a = p.first;
+    *b = p.second;
+    hipEventRecord(*a, c->stream);
+    c->spans.push_back({*a, *b, kind});
+}
+void span_end(cwslg_ctx *c, hipEvent_t b)
+{
+    if (b) hipEventRecord(b, c->stream);
+}
+// Only call with the stream idle (after hipStreamSynchronize).
+void drain_spans(cwslg_ctx *c)
+{
+    for (const TimedSpan &s : c->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            if (s.kind == 0) c->stats.demod_ms += ms;
+            else if (s.kind == 1) c->stats.finalize_ms += ms;
+            else c->stats.sync_ms += ms;
+        }
+        c->ev_pool.push_back({s.a, s.b});
+    }
+    c->spans.clear();
+}
+
+int ensure_taps(cwslg_ctx *c, uint32_t fs)
+{
+    if (c->d_taps.count(fs)) return CWSLG_OK;
+    std::vector<float> h = design_taps(fs, kSsbBw);
+    float *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, h.size() * sizeof(float)));
+    HIPCHK(c, hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->d_taps[fs] = d;
+    c->h_taps[fs] = std::move(h);
+    return CWSLG_OK;
+}
+
+int build_pending_phasors(cwslg_ctx *c)
+{
+    if (c->phasor_todo.empty()) return CWSLG_OK;
+    std::vector<PhasorJob> jobs;
+    for (auto &key : c->phasor_todo) {
+        auto it = c->phasors.find(key);
+        if (it == c->phasors.end() || it->second.built) continue;
+        PhasorJob j{};
+        j.ckpt = it->second.d_ckpt;
+        j.inc = it->second.inc;
+        j.n_ckpt = (unsigned)it->second.n_ckpt;
+        jobs.push_back(j);
+        it->second.built = true;
+    }
+    c->phasor_todo.clear();
+    if (jobs.empty()) return CWSLG_OK;
+    WorkBuf *w = acquire_workbuf(c, jobs.size() * sizeof(PhasorJob));
+    if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
+    std::memcpy(w->h, jobs.data(), jobs.size() * sizeof(PhasorJob));
+    HIPCHK(c, hipMemcpyAsync(w->d, w->h, jobs.size() * sizeof(PhasorJob), hipMemcpyHostToDevice, c->stream));
+    const int n = (int)jobs.size();
+    hipLaunchKernelGGL(phasor_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream,
+                       (const PhasorJob *)w->d, n);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(w->done, c->stream));
+    w->in_flight = true;
+    return CWSLG_OK;
+}
+
+template <int D>
+int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_blocks, uint32_t fs)
+{
+    if (works.empty()) return CWSLG_OK;
+    WorkBuf *w = acquire_workbuf(c, works.size() * sizeof(ChanWork));
+    if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
+    std::memcpy(w->h, works.data(), works.size() * sizeof(ChanWork));
+    HIPCHK(c, hipMemcpyAsync(w->d, w->h, works.size() * sizeof(ChanWork), hipMemcpyHostToDevice, c->stream));
+    const int tiles_x = (int)((max_blocks + kTile - 1) / kTile);
+    const long long total = (long long)tiles_x * (long long)works.size();
+    const long long per_xcd = (total + 7) / 8;
+    hipEvent_t ea, eb;
+    span_begin(c, 0, &ea, &eb);
+    hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
+                       c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
+    span_end(c, eb);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(w->done, c->stream));
+    w->in_flight = true;
+    c->stats.demod_launches++;
+    return CWSLG_OK;
+}
+
+// Demodulate everything pending.  Caller holds the mutex.
+int process_locked(cwslg_ctx *c)
+{
+    int rc = build_pending_phasors(c);
+    if (rc) return rc;
+    // one launch per distinct sample rate
+    std::map<uint32_t, std::vector<ChanWork>> by_fs;
+    std::map<uint32_t, unsigned> max_blocks;
+    for (Channel &ch : c->chans) {
+        if (!ch.open || ch.pend_n == 0) continue;
+        Receiver &rx = c->rxs[ch.rx];
+        ChanWork w{};
+        w.ring = rx.d_ring;
+        w.out = ch.d_frame[ch.wr] + ch.pend_fill0;
+        w.peak = ch.d_peak + ch.wr;
+        w.ckpt = c->phasors[ch.phasor_key].d_ckpt;
+        w.tone = ch.d_tone;
+        w.lo_abs = ch.pend_lo;
+        w.origin_abs = ch.origin_abs;
+        w.ring_cap = rx.cap;
+        w.n_blocks = ch.pend_n / rx.D;
+        w.inc = make_float2(ch.k.inc.real(), ch.k.inc.imag());
+        w.sign = ch.k.sign;
+        by_fs[rx.fs].push_back(w);
+        max_blocks[rx.fs] = std::max(max_blocks[rx.fs], w.n_blocks);
+        c->stats.demod_samples += ch.pend_n;
+        ch.pend_lo += ch.pend_n;
+        ch.pend_fill0 += ch.pend_n / rx.D;
+        ch.pend_n = 0;
+    }
+    for (auto &kv : by_fs) {
+        const uint32_t fs = kv.first;
+        const uint32_t D = fs / kWaveSR;
+        if (D == 16) rc = launch_demod<16>(c, kv.second, max_blocks[fs], fs);
+        else if (D == 8) rc = launch_demod<8>(c, kv.second, max_blocks[fs], fs);
+        else if (D == 4) rc = launch_demod<4>(c, kv.second, max_blocks[fs], fs);
+        else rc = fail(c, CWSLG_ERR_UNSUPPORTED, "sample rate %u unsupported", fs);
+        if (rc) return rc;
+    }
+    return CWSLG_OK;
+}
+
+// Account n new samples (already in the ring) to every channel of the receiver, applying the
+// reference's per-block frame-overflow guard (Instance.cpp:268-271) with granularity block_len.
+void account_push(cwslg_ctx *c, Receiver &rx, uint32_t n, uint32_t block_len)
+{
+    const uint64_t first = rx.total;
+    for (int id : rx.channels) {
+        Channel &ch = c->chans[id];
+        if (!ch.open) continue;
+        uint32_t done = 0;
+        // whole blocks in closed form: block j is accepted iff fill + j*(block_len/D) + block_len <= frame_len-1
+        if (!ch.saturated && n >= block_len) {
+            const uint64_t fill = ch.fill[ch.wr];
+            const uint32_t whole = n / block_len;
+            const uint32_t per = block_len / rx.D;
+            uint32_t take = 0;
+            if (fill + block_len <= ch.frame_len - 1)
+                take = (uint32_t)std::min<uint64_t>(whole, (ch.frame_len - 1 - block_len - fill) / per + 1);
+            if (take) {
+                if (ch.pend_n == 0) {
+                    ch.pend_lo = (int64_t)first;
+                    ch.pend_fill0 = fill;
+                }
+                ch.pend_n += take * block_len;
+                ch.fill[ch.wr] += (uint64_t)take * per;
+                done = take * block_len;
+            }
+            if (take < whole) ch.saturated = true;       // every later block of this slot fails the same test
+        }
+        while (done < n) {                                // trailing partial block (and the saturated case)
+            const uint32_t blk = std::min(block_len, n - done);
+            if (!ch.saturated) {
+                const uint64_t fill = ch.fill[ch.wr];
+                if (fill + blk > ch.frame_len - 1) ch.saturated = true;
+            }
+            if (ch.saturated) {
+                c->stats.blocks_dropped += (n - done + block_len - 1) / block_len;
+                break;
+            }
+            if (ch.pend_n == 0) {
+                ch.pend_lo = (int64_t)(first + done);
+                ch.pend_fill0 = ch.fill[ch.wr];
+            }
+            ch.pend_n += blk;
+            ch.fill[ch.wr] += blk / rx.D;
+            done += blk;
+        }
+    }
+    rx.total += n;
+}
+
+// Make room so that writing n samples cannot overwrite history still needed by pending work.
+int reserve_ring(cwslg_ctx *c, Receiver &rx, uint32_t n)
+{
+    const uint32_t hist = 32 * rx.D;
+    if ((uint64_t)n + hist > rx.cap) return fail(c, CWSLG_ERR_ARG, "push of %u samples exceeds ring capacity %u", n, rx.cap);
+    uint32_t max_pend = 0;
+    for (int id : rx.channels) {
+        const Channel &ch = c->chans[id];
+        if (ch.open) max_pend = std::max(max_pend, ch.pend_n);
+    }
+    if ((uint64_t)max_pend + n + hist > rx.cap) {
+        int rc = process_locked(c);      // the reference logs "I/Q buffer is full!" and stalls (Receiver.hpp:222-229)
+        if (rc) return rc;
+    }
+    return CWSLG_OK;
+}
+
+int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s)
+{
+    if (ids.empty()) return CWSLG_OK;
+    int rc = process_locked(c);          // everything pushed so far belongs to the finishing slot
+    if (rc) return rc;
+    std::vector<FinWork> fin;
+    std::vector<int> emitted;
+    size_t max_len = 0;
+    for (int id : ids) {
+        Channel &ch = c->chans[id];
+        Receiver &rx = c->rxs[ch.rx];
+        const int nxt = ch.wr ^ 1;                      // get_next_write_index, ring of 2
+        ch.fill[nxt] = 0;                               // memset + reset (Instance.cpp:213-214)
+        ch.t0[nxt] = epoch_s;                           // :215
+        ch.wr = nxt;                                    // :217
+        const int cur = ch.rd;                          // :221 pop_ref
+        ch.rd ^= 1;
+        ch.saturated = false;
+        FinWork f{};
+        f.frame = ch.d_frame[cur];
+        f.out = ch.d_i16;
+        f.peak = ch.d_peak + cur;
+        f.peak_next = ch.d_peak + nxt;
+        f.factor_out = ch.d_factor;
+        f.scale = ch.wspr_scale ? c->scale_wspr : c->scale_ft;
+        f.n_valid = (unsigned)ch.fill[cur];
+        f.frame_len = (unsigned)ch.frame_len;
+        f.emit = (ch.t0[cur] != 0) ? 1 : 0;             // :224-227
+        if (f.emit) {
+            ch.have_frame = true;
+            ch.frame_idx = cur;
+            ch.frame_t0 = ch.t0[cur];
+            ch.frame_valid = ch.fill[cur];
+            ch.origin_abs = (int64_t)rx.total;          // :251 new SSBD: history and phasor restart
+            c->stats.frames_emitted++;
+            emitted.push_back(id);
+        } else {
+            c->stats.frames_discarded++;                // NOTE: no demodulator restart on this path (:226 `continue`)
+        }
+        ch.pend_fill0 = 0;
+        fin.push_back(f);
+        max_len = std::max(max_len, ch.frame_len);
+    }
+    WorkBuf *w = acquire_workbuf(c, fin.size() * sizeof(FinWork));
+    if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
+    std::memcpy(w->h, fin.data(), fin.size() * sizeof(FinWork));
+    HIPCHK(c, hipMemcpyAsync(w->d, w->h, fin.size() * sizeof(FinWork), hipMemcpyHostToDevice, c->stream));
+    const unsigned gx = (unsigned)((max_len + kFinThreads * 8 - 1) / (kFinThreads * 8));
+    hipEvent_t ea, eb;
+    span_begin(c, 1, &ea, &eb);
+    hipLaunchKernelGGL((finalize_kernel<kFinThreads>), dim3(gx, (unsigned)fin.size()), dim3(kFinThreads), 0, c->stream,
+                       (const FinWork *)w->d);
+    span_end(c, eb);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(w->done, c->stream));
+    w->in_flight = true;
+    c->stats.finalize_launches++;
+    // optional sync stage on the freshly finalised int16 frames
+    if (c->sync_cfg.enabled && !emitted.empty()) {
+        rc = sync_launch(c, emitted);
+        if (rc) return rc;
+    }
+    return CWSLG_OK;
+}
+
+} // namespace
+
+// sync stage glue (defined in sync_host.inc so this file stays readable)
+#include "sync_host.inc"
+
+// =============================================================================================
+extern "C" {
+
+int cwslg_abi_version(void) { return CWSLG_ABI_VERSION; }
+
+const char *cwslg_strerror(int s)
+{
+    switch (s) {
+    case CWSLG_OK: return "ok";
+    case CWSLG_ERR_RATIO: return "Fs/B must be an even integer >= 4";
+    case CWSLG_ERR_BAND_LOW: return "Signal outside of band (low)";
+    case CWSLG_ERR_BAND_HIGH: return "Signal outside of band (high)";
+    case CWSLG_ERR_NOMEM: return "out of memory";
+    case CWSLG_ERR_MODE: return "Unhandled mode";
+    case CWSLG_ERR_ARG: return "invalid argument";
+    case CWSLG_ERR_NO_DEVICE: return "no usable HIP device (gfx950 required; there is no CPU fallback)";
+    case CWSLG_ERR_HIP: return "HIP runtime error";
+    case CWSLG_ERR_NO_FRAME: return "no finalised frame";
+    case CWSLG_ERR_UNSUPPORTED: return "unsupported sample rate";
+    case CWSLG_ERR_BLOCK: return "block length must be a multiple of SSBD::GetInSize()";
+    default: return "unknown status";
+    }
+}
+
+const char *cwslg_last_error(cwslg_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int cwslg_create(cwslg_ctx **out, int device_ordinal)
+{
+    if (!out) return CWSLG_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return CWSLG_ERR_NO_DEVICE;
+    if (device_ordinal < 0) {
+        const char *lr = std::getenv("LOCAL_RANK");
+        device_ordinal = lr ? std::atoi(lr) % n : 0;
+    }
+    if (device_ordinal >= n) return CWSLG_ERR_NO_DEVICE;
+    if (hipSetDevice(device_ordinal) != hipSuccess) return CWSLG_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return CWSLG_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return CWSLG_ERR_NO_DEVICE;   // code object is gfx950-only
+    std::unique_ptr<cwslg_ctx> c(new cwslg_ctx);
+    c->device = device_ordinal;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
+    if (hipHostMalloc((void **)&c->h_stage, 2 * kStageHalf, hipHostMallocDefault) != hipSuccess) return CWSLG_ERR_NOMEM;
+    hipEventCreateWithFlags(&c->stage_ev[0], hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->stage_ev[1], hipEventDisableTiming);
+    // tone table of the synthetic source (same construction as the oracle's)
+    {
+        std::vector<float2> tab(4096);
+        constexpr double pi = 3.14159265358979323846;
+        for (int j = 0; j < 4096; ++j)
+            tab[j] = make_float2((float)std::cos(2.0 * pi * j / 4096.0), (float)std::sin(2.0 * pi * j / 4096.0));
+        if (hipMalloc(&c->d_sincos, tab.size() * sizeof(float2)) != hipSuccess) return CWSLG_ERR_NOMEM;
+        if (hipMemcpy(c->d_sincos, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) return CWSLG_ERR_HIP;
+    }
+    *out = c.release();
+    return CWSLG_OK;
+}
+
+void cwslg_destroy(cwslg_ctx *c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (Channel &ch : c->chans) {
+        if (ch.d_block) hipFree(ch.d_block);
+        sync_free_channel(ch.syncbuf);
+    }
+    for (Receiver &rx : c->rxs) if (rx.d_ring) hipFree(rx.d_ring);
+    for (auto &kv : c->d_taps) hipFree(kv.second);
+    for (auto &kv : c->phasors) if (kv.second.d_ckpt) hipFree(kv.second.d_ckpt);
+    for (WorkBuf &w : c->wb) {
+        if (w.h) hipHostFree(w.h);
+        if (w.d) hipFree(w.d);
+        if (w.done) hipEventDestroy(w.done);
+    }
+    drain_spans(c);
+    for (auto &p : c->ev_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    sync_free_shared(c->sync_shared);
+    if (c->d_sincos) hipFree(c->d_sincos);
+    if (c->h_stage) hipHostFree(c->h_stage);
+    hipEventDestroy(c->stage_ev[0]);
+    hipEventDestroy(c->stage_ev[1]);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int cwslg_set_scale_factors(cwslg_ctx *c, float ft, float wspr)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->scale_ft = ft;
+    c->scale_wspr = wspr;
+    return CWSLG_OK;
+}
+
+int cwslg_receiver_open(cwslg_ctx *c, uint32_t fs, uint32_t iq_len, int32_t lo_hz, uint32_t ring_blocks, int *rx_id)
+{
+    if (!c || !rx_id || iq_len == 0) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    hipSetDevice(c->device);
+    int rc = check_tuning(fs, kSsbBw, 0.0, true);
+    if (rc == CWSLG_ERR_RATIO) return fail(c, rc, "Fs/B must be an even integer >= 4");
+    const uint32_t D = fs / kWaveSR;
+    if (!(D == 4 || D == 8 || D == 16) || D * kWaveSR != fs) return fail(c, CWSLG_ERR_UNSUPPORTED, "sample rate %u: only 48/96/192 kHz", fs);
+    if (iq_len % (4 * D) != 0) return fail(c, CWSLG_ERR_BLOCK, "iq_len %u is not a multiple of %u", iq_len, 4 * D);
+    rc = ensure_taps(c, fs);
+    if (rc) return rc;
+    Receiver rx;
+    rx.fs = fs; rx.iq_len = iq_len; rx.lo_hz = lo_hz; rx.D = D;
+    const uint64_t blocks = ring_blocks ? ring_blocks : (uint64_t)(fs / iq_len + 1) * 3;   // Receiver.hpp:132
+    uint64_t cap = blocks * iq_len;
+    const uint64_t min_cap = 2ull * (D * (kTile + 31)) + 64;       // the tile loader wraps at most once
+    if (cap < min_cap) cap = (min_cap + iq_len - 1) / iq_len * iq_len;
+    if (cap > 0xFFFFFFF0ull) return fail(c, CWSLG_ERR_ARG, "ring too large");
+    rx.cap = (uint32_t)cap;
+    HIPCHK(c, hipMalloc(&rx.d_ring, (size_t)rx.cap * sizeof(float2)));
+    rx.open = true;
+    int id = -1;
+    for (size_t k = 0; k < c->rxs.size(); ++k) if (!c->rxs[k].open) { id = (int)k; break; }
+    if (id < 0) { c->rxs.push_back(rx); id = (int)c->rxs.size() - 1; } else c->rxs[id] = rx;
+    *rx_id = id;
+    return CWSLG_OK;
+}
+
+int cwslg_receiver_close(cwslg_ctx *c, int rx_id)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (rx_id < 0 || rx_id >= (int)c->rxs.size() || !c->rxs[rx_id].open) return fail(c, CWSLG_ERR_ARG, "bad receiver id");
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    Receiver &rx = c->rxs[rx_id];
+    for (int id : rx.channels) {        // Receiver::finish terminates its instances (Receiver.hpp:194-199)
+        Channel &ch = c->chans[id];
+        if (!ch.open) continue;
+        if (ch.d_block) hipFree(ch.d_block);
+        sync_free_channel(ch.syncbuf);
+        auto it = c->phasors.find(ch.phasor_key);
+        if (it != c->phasors.end() && --it->second.refs == 0) { hipFree(it->second.d_ckpt); c->phasors.erase(it); }
+        ch = Channel();
+    }
+    hipFree(rx.d_ring);
+    rx = Receiver();
+    return CWSLG_OK;
+}
+
+static int push_prologue(cwslg_ctx *c, int rx_id, uint32_t n, Receiver **out)
+{
+    if (rx_id < 0 || rx_id >= (int)c->rxs.size() || !c->rxs[rx_id].open) return fail(c, CWSLG_ERR_ARG, "bad receiver id");
+    Receiver &rx = c->rxs[rx_id];
+    if (n == 0 || n % (4 * rx.D) != 0) return fail(c, CWSLG_ERR_BLOCK, "n_complex %u is not a multiple of %u", n, 4 * rx.D);
+    hipSetDevice(c->device);
+    int rc = reserve_ring(c, rx, n);
+    if (rc) return rc;
+    *out = &rx;
+    return CWSLG_OK;
+}
+
+int cwslg_push_iq(cwslg_ctx *c, int rx_id, const float *iq, uint32_t n)
+{
+    if (!c || !iq) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    Receiver *rx = nullptr;
+    int rc = push_prologue(c, rx_id, n, &rx);
+    if (rc) return rc;
+    // host block -> pinned staging -> ring (the caller's block is only valid during this call)
+    uint32_t done = 0;
+    while (done < n) {
+        const size_t half_samples = kStageHalf / sizeof(float2);
+        const int half = (int)(c->stage_pos / kStageHalf);
+        const size_t off_in_half = c->stage_pos % kStageHalf;
+        size_t room = (kStageHalf - off_in_half) / sizeof(float2);
+        if (off_in_half == 0 && c->stage_busy[half]) {
+            HIPCHK(c, hipEventSynchronize(c->stage_ev[half]));
+            c->stage_busy[half] = false;
+        }
+        uint32_t m = (uint32_t)std::min<size_t>({(size_t)(n - done), room, half_samples});
+        const uint32_t ring_pos = (uint32_t)((rx->total + done) % rx->cap);
+        m = std::min(m, rx->cap - ring_pos);           // split at the ring wrap
+        char *stg = c->h_stage + c->stage_pos;
+        std::memcpy(stg, iq + 2 * (size_t)done, (size_t)m * sizeof(float2));
+        HIPCHK(c, hipMemcpyAsync(rx->d_ring + ring_pos, stg, (size_t)m * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+        c->stage_pos += (size_t)m * sizeof(float2);
+        if (c->stage_pos % kStageHalf == 0) {           // leaving a half: fence it
+            HIPCHK(c, hipEventRecord(c->stage_ev[half], c->stream));
+            c->stage_busy[half] = true;
+            if (c->stage_pos == 2 * kStageHalf) c->stage_pos = 0;
+        }
+        done += m;
+    }
+    c->stats.h2d_bytes += (uint64_t)n * sizeof(float2);
+    account_push(c, *rx, n, rx->iq_len);
+    return CWSLG_OK;
+}
+
+int cwslg_push_iq_device(cwslg_ctx *c, int rx_id, const void *d_iq, uint32_t n)
+{
+    if (!c || !d_iq) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    Receiver *rx = nullptr;
+    int rc = push_prologue(c, rx_id, n, &rx);
+    if (rc) return rc;
+    uint32_t done = 0;
+    while (done < n) {
+        const uint32_t ring_pos = (uint32_t)((rx->total + done) % rx->cap);
+        const uint32_t m = std::min(n - done, rx->cap - ring_pos);
+        HIPCHK(c, hipMemcpyAsync(rx->d_ring + ring_pos, (const float2 *)d_iq + done, (size_t)m * sizeof(float2),
+                                 hipMemcpyDeviceToDevice, c->stream));
+        done += m;
+    }
+    account_push(c, *rx, n, rx->iq_len);
+    return CWSLG_OK;
+}
+
+int cwslg_push_synth(cwslg_ctx *c, int rx_id, uint64_t seed, uint32_t n, uint32_t block_len,
+                     const double *tones_hz, int n_tones, float amp)
+{
+    if (!c || n_tones < 0 || n_tones > 8 || (n_tones && !tones_hz)) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    Receiver *rx = nullptr;
+    int rc = push_prologue(c, rx_id, n, &rx);
+    if (rc) return rc;
+    if (block_len == 0) block_len = rx->iq_len;
+    if (block_len % (4 * rx->D) != 0) return fail(c, CWSLG_ERR_BLOCK, "block_len %u", block_len);
+    SynthArgs a{};
+    a.ring = rx->d_ring;
+    a.ring_cap = rx->cap;
+    a.ring_pos = rx->total % rx->cap;
+    a.first_sample = rx->total;
+    a.seed = seed;
+    a.n = n;
+    a.n_tones = n_tones;
+    a.amp = amp;
+    for (int t = 0; t < n_tones; ++t) {
+        const double cyc = tones_hz[t] / (double)rx->fs;
+        a.step[t] = (uint32_t)(int64_t)std::llround(cyc * 4294967296.0);
+    }
+    hipLaunchKernelGGL(synth_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, a, (const float2 *)c->d_sincos);
+    HIPCHK(c, hipGetLastError());
+    account_push(c, *rx, n, block_len);
+    return CWSLG_OK;
+}
+
+int cwslg_ring_commit(cwslg_ctx *c, int rx_id, uint32_t n, uint32_t block_len)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    Receiver *rx = nullptr;
+    int rc = push_prologue(c, rx_id, n, &rx);
+    if (rc) return rc;
+    if (block_len == 0) block_len = rx->iq_len;
+    if (block_len % (4 * rx->D) != 0) return fail(c, CWSLG_ERR_BLOCK, "block_len %u", block_len);
+    account_push(c, *rx, n, block_len);
+    return CWSLG_OK;
+}
+
+int cwslg_ring_commit_all(cwslg_ctx *c, uint32_t n, uint32_t block_len)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    for (size_t id = 0; id < c->rxs.size(); ++id) {
+        if (!c->rxs[id].open) continue;
+        Receiver *rx = nullptr;
+        int rc = push_prologue(c, (int)id, n, &rx);
+        if (rc) return rc;
+        const uint32_t bl = block_len ? block_len : rx->iq_len;
+        if (bl % (4 * rx->D) != 0) return fail(c, CWSLG_ERR_BLOCK, "block_len %u", bl);
+        account_push(c, *rx, n, bl);
+    }
+    return CWSLG_OK;
+}
+
+int cwslg_ring_info(cwslg_ctx *c, int rx_id, void **d_ring, uint32_t *capacity, uint64_t *total_pushed)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (rx_id < 0 || rx_id >= (int)c->rxs.size() || !c->rxs[rx_id].open) return fail(c, CWSLG_ERR_ARG, "bad receiver id");
+    const Receiver &rx = c->rxs[rx_id];
+    if (d_ring) *d_ring = rx.d_ring;
+    if (capacity) *capacity = rx.cap;
+    if (total_pushed) *total_pushed = rx.total;
+    return CWSLG_OK;
+}
+
+int cwslg_channel_open(cwslg_ctx *c, int rx_id, int32_t demod_hz, int usb, const char *mode, int *ch_id)
+{
+    if (!c || !ch_id) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (rx_id < 0 || rx_id >= (int)c->rxs.size() || !c->rxs[rx_id].open) return fail(c, CWSLG_ERR_ARG, "bad receiver id");
+    hipSetDevice(c->device);
+    Receiver &rx = c->rxs[rx_id];
+    const ModeInfo *mi = find_mode(mode);
+    if (!mi) return fail(c, CWSLG_ERR_MODE, "Unhandled mode: %s", mode ? mode : "(null)");
+    // Instance.cpp:187 : F = static_cast<float>(demodFreq) widened to double
+    const double f_hz = (double)(float)demod_hz;
+    int rc = check_tuning(rx.fs, kSsbBw, f_hz, usb != 0);
+    if (rc) return fail(c, rc, "%s", cwslg_strerror(rc));
+    Channel ch;
+    ch.rx = rx_id; ch.demod_hz = demod_hz; ch.usb = usb != 0; ch.mode = mode;
+    ch.group = mi->group;
+    ch.wspr_scale = (ch.mode == "WSPR");
+    ch.sync_ft8 = (ch.mode == "FT8");
+    ch.sync_ft4 = (ch.mode == "FT4");
+    ch.frame_len = frame_length(*mi);
+    ch.k = make_constants(rx.fs, kSsbBw, f_hz, usb != 0);
+    // one device allocation: 2 float frames | int16 frame | peaks | factor | tone
+    const size_t fbytes = (ch.frame_len * sizeof(float) + 255) & ~size_t(255);
+    const size_t ibytes = (ch.frame_len * sizeof(int16_t) + 255) & ~size_t(255);
+    const size_t total = 2 * fbytes + ibytes + 256 + 256;
+    HIPCHK(c, hipMalloc((void **)&ch.d_block, total));
+    ch.d_frame[0] = (float *)ch.d_block;
+    ch.d_frame[1] = (float *)(ch.d_block + fbytes);
+    ch.d_i16 = (int16_t *)(ch.d_block + 2 * fbytes);
+    ch.d_peak = (unsigned *)(ch.d_block + 2 * fbytes + ibytes);
+    ch.d_factor = (float *)(ch.d_block + 2 * fbytes + ibytes + 16);
+    ch.d_tone = (float2 *)(ch.d_block + 2 * fbytes + ibytes + 256);
+    HIPCHK(c, hipMemsetAsync(ch.d_block + 2 * fbytes + ibytes, 0, 256, c->stream));
+    HIPCHK(c, hipMemcpyAsync(ch.d_tone, ch.k.tone.data(), ch.k.block * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));     // k.tone is a temporary host vector: finish the copy now
+    // phasor checkpoints: cover the first frame, which continues across the discarded partial slot
+    // (up to 2 frames of blocks since creation), plus one tile of slack
+    const size_t n_ckpt = (2 * ch.frame_len + kTile + 64) / kCkptStride + 2;
+    ch.phasor_key = std::make_tuple(rx.fs, demod_hz, usb ? 1 : 0, n_ckpt);
+    PhasorTable &pt = c->phasors[ch.phasor_key];
+    if (pt.refs == 0) {
+        HIPCHK(c, hipMalloc(&pt.d_ckpt, n_ckpt * sizeof(float2)));
+        pt.n_ckpt = n_ckpt;
+        pt.inc = make_float2(ch.k.inc.real(), ch.k.inc.imag());
+        pt.built = false;
+        c->phasor_todo.push_back(ch.phasor_key);
+    }
+    pt.refs++;
+    ch.origin_abs = (int64_t)rx.total;
+    ch.pend_lo = ch.origin_abs;
+    ch.open = true;
+    int id = -1;
+    for (size_t k = 0; k < c->chans.size(); ++k) if (!c->chans[k].open) { id = (int)k; break; }
+    if (id < 0) { c->chans.push_back(ch); id = (int)c->chans.size() - 1; } else c->chans[id] = ch;
+    rx.channels.push_back(id);
+    *ch_id = id;
+    return CWSLG_OK;
+}
+
+int cwslg_channel_close(cwslg_ctx *c, int ch_id)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    Channel &ch = c->chans[ch_id];
+    Receiver &rx = c->rxs[ch.rx];
+    rx.channels.erase(std::remove(rx.channels.begin(), rx.channels.end(), ch_id), rx.channels.end());
+    hipFree(ch.d_block);
+    sync_free_channel(ch.syncbuf);
+    auto it = c->phasors.find(ch.phasor_key);
+    if (it != c->phasors.end() && --it->second.refs == 0) { hipFree(it->second.d_ckpt); c->phasors.erase(it); }
+    ch = Channel();
+    return CWSLG_OK;
+}
+
+int cwslg_channel_info(cwslg_ctx *c, int ch_id, uint32_t *in_size, uint32_t *out_size, uint32_t *out_rate,
+                       uint32_t *delay, size_t *frame_len)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
+    const Channel &ch = c->chans[ch_id];
+    if (in_size) *in_size = 4 * ch.k.block;     // GetInSize = 2*Fs/B
+    if (out_size) *out_size = 4;                // GetOutSize
+    if (out_rate) *out_rate = 2 * kSsbBw;       // GetOutRate
+    if (delay) *delay = 8;                      // GetDelay = latency
+    if (frame_len) *frame_len = ch.frame_len;
+    return CWSLG_OK;
+}
+
+int cwslg_process(cwslg_ctx *c)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    hipSetDevice(c->device);
+    return process_locked(c);
+}
+
+int cwslg_slot_boundary(cwslg_ctx *c, int group, uint64_t epoch_s)
+{
+    if (!c || group < 0 || group >= CWSLG_NUM_GROUPS) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    hipSetDevice(c->device);
+    std::vector<int> ids;
+    for (size_t k = 0; k < c->chans.size(); ++k)
+        if (c->chans[k].open && c->chans[k].group == group) ids.push_back((int)k);
+    return boundary_locked(c, ids, epoch_s);
+}
+
+int cwslg_slot_boundary_channel(cwslg_ctx *c, int ch_id, uint64_t epoch_s)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
+    hipSetDevice(c->device);
+    return boundary_locked(c, std::vector<int>{ch_id}, epoch_s);
+}
+
+int cwslg_synchronize(cwslg_ctx *c)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    hipSetDevice(c->device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drain_spans(c);
+    return CWSLG_OK;
+}
+
+int cwslg_fetch_frame(cwslg_ctx *c, int ch_id, int16_t *dst, size_t cap, uint64_t *start_epoch, size_t *n_valid, float *factor)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
+    Channel &ch = c->chans[ch_id];
+    if (!ch.have_frame) return CWSLG_ERR_NO_FRAME;
+    hipSetDevice(c->device);
+    if (dst) {
+        if (cap < ch.frame_len) return fail(c, CWSLG_ERR_ARG, "destination holds %zu samples, frame has %zu", cap, ch.frame_len);
+        HIPCHK(c, hipMemcpyAsync(dst, ch.d_i16, ch.frame_len * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (factor) HIPCHK(c, hipMemcpyAsync(factor, ch.d_factor, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drain_spans(c);
+    if (start_epoch) *start_epoch = ch.frame_t0;
+    if (n_valid) *n_valid = ch.frame_valid;
+    return CWSLG_OK;
+}
+
+int cwslg_fetch_audio_f32(cwslg_ctx *c, int ch_id, float *dst, size_t cap, size_t *n_valid)
+{
+    if (!c || !dst) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
+    Channel &ch = c->chans[ch_id];
+    if (!ch.have_frame) return CWSLG_ERR_NO_FRAME;
+    if (cap < ch.frame_len) return fail(c, CWSLG_ERR_ARG, "destination holds %zu samples, frame has %zu", cap, ch.frame_len);
+    hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpyAsync(dst, ch.d_frame[ch.frame_idx], ch.frame_valid * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drain_spans(c);
+    std::memset(dst + ch.frame_valid, 0, (ch.frame_len - ch.frame_valid) * sizeof(float));   // the reference's zero tail
+    if (n_valid) *n_valid = ch.frame_valid;
+    return CWSLG_OK;
+}
+
+int cwslg_frame_device_ptrs(cwslg_ctx *c, int ch_id, const int16_t **d_i16, const float **d_f32)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
+    Channel &ch = c->chans[ch_id];
+    if (!ch.have_frame) return CWSLG_ERR_NO_FRAME;
+    if (d_i16) *d_i16 = ch.d_i16;
+    if (d_f32) *d_f32 = ch.d_frame[ch.frame_idx];
+    return CWSLG_OK;
+}
+
+int cwslg_get_stats(cwslg_ctx *c, cwslg_stats *out)
+{
+    if (!c || !out) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    *out = c->stats;
+    return CWSLG_OK;
+}
+
+int cwslg_reset_stats(cwslg_ctx *c)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->stats = cwslg_stats{};
+    return CWSLG_OK;
+}
+
+int cwslg_set_timing(cwslg_ctx *c, int enable)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->timing = enable != 0;
+    return CWSLG_OK;
+}
+
+void *cwslg_stream(cwslg_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int cwslg_channel_constants(cwslg_ctx *c, int ch_id, float *taps, float *tone_ri, float *phase_inc_ri)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
+    const Channel &ch = c->chans[ch_id];
+    const Receiver &rx = c->rxs[ch.rx];
+    if (taps) std::memcpy(taps, c->h_taps[rx.fs].data(), c->h_taps[rx.fs].size() * sizeof(float));
+    if (tone_ri) std::memcpy(tone_ri, ch.k.tone.data(), ch.k.block * 2 * sizeof(float));
+    if (phase_inc_ri) { phase_inc_ri[0] = ch.k.inc.real(); phase_inc_ri[1] = ch.k.inc.imag(); }
+    return (int)ch.k.block;
+}
+
+int cwslg_channel_phasor_checkpoints(cwslg_ctx *c, int ch_id, float *dst_ri, size_t n, size_t *n_total)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
+    hipSetDevice(c->device);
+    Channel &ch = c->chans[ch_id];
+    int rc = build_pending_phasors(c);
+    if (rc) return rc;
+    PhasorTable &pt = c->phasors[ch.phasor_key];
+    if (n_total) *n_total = pt.n_ckpt;
+    if (dst_ri && n) {
+        const size_t m = std::min(n, pt.n_ckpt);
+        HIPCHK(c, hipMemcpyAsync(dst_ri, pt.d_ckpt, m * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return CWSLG_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,411 @@
+// demod_kernels.hpp -- hand-written gfx950 kernels for the CWSL_DIGI per-channel DSP chain.
+//
+// What is computed (reference: source/SSBD.hpp:127-183, closed form in SURVEY.md 8a-note):
+//
+//   z_b      = sum_{t=0}^{32D-1} x[D(b-31)+t] * nco[D(b-31)+t] * h[t]       D = Fs/12000, x[i<0] = 0
+//   nco[i]   = tone[i mod D] * phase_{i div D},  phase_{q+1} = fl(phase_q * phase_inc)   (float32, UNfused)
+//   audio[b] = Re( z_b * j^(b mod 4) )                                       (USB; LSB flips the Im terms)
+//
+// The reference evaluates this as a recursive overlap-add over 32 workspace slots, one scalar
+// thread per channel.  Here it is inverted into a stride-2D polyphase FIR:
+//
+//   outputs of equal parity p = b mod 2 are 2D input samples apart and need only ONE real
+//   component of y = x*nco (Re for even b, Im for odd b).  With t = 2D*v + u  (u < 2D, v < 16):
+//
+//       audio[qs + 2w + p] = s(w,p) * sum_u sum_v  P_p[u][w+v] * H[u][v],   H[u][v] = h[2D*v+u]
+//       P_p[u][w] = component_p( y[ D*(qs-31+p) + 2D*w + u ] )
+//
+//   i.e. 2D independent 16-tap FIRs ("branches") along w, summed over the branches.
+//
+// Kernel layout (one workgroup = one tile of T outputs of one channel):
+//   phase 0  threads 0..NCK-1 rebuild the bit-exact float32 phasor for the tile's T+31 blocks from
+//            per-channel checkpoints (every 16 blocks) into LDS -- <=16 serial UNfused complex
+//            multiplies each, the same rounding sequence as SSBD.hpp:174.
+//   phase 1  coalesced 16-B loads of the IQ ring (HBM), complex mix, scatter of Re/Im into the two
+//            branch-major LDS planes P_0/P_1.
+//   phase 2  lane = branch u: each lane runs its 16-tap FIR over 16 consecutive w (31 LDS floats,
+//            256 FMAs, taps in registers), then a halving butterfly over the 2D lanes of a group
+//            sums the branches.  Results are staged in LDS and stored as whole rows.
+//   epilogue wave shuffle max|audio| -> one atomicMax per wave into the frame's peak word
+//            (feeds prepareAudio's normalisation, Instance.cpp:294-316, without a second pass).
+//
+// MFMA is deliberately not used: per-channel phasors make the contraction channel-specific, the
+// f32 MFMA rate equals the VALU rate on gfx950, and the path is HBM-bound (8 B in per sample).
+//
+// This translation unit is compiled with -ffp-contract=off; every fused multiply-add below is an
+// explicit __builtin_fmaf, every bit-exact sequence is plain * and +/-.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cwslg {
+
+// One entry per active channel per demod launch.
+struct alignas(16) ChanWork {
+    const float2 *ring;       // receiver IQ ring in HBM (interleaved re,im)
+    float        *out;        // &frame[fill] : where the first pending output goes
+    unsigned     *peak;       // max|audio| of the frame, as float bits (atomicMax)
+    const float2 *ckpt;       // phasor checkpoints: ckpt[c] = phase_{16c}
+    const float2 *tone;       // tone[D]
+    long long     lo_abs;     // absolute sample index of the first pending sample
+    long long     origin_abs; // absolute sample index at which the demodulator was (re)created
+    unsigned      ring_cap;   // ring capacity in complex samples
+    unsigned      n_blocks;   // pending outputs (= pending samples / D)
+    float2        inc;        // phase_inc
+    float         sign;       // +1 USB, -1 LSB
+    unsigned      pad_;
+};
+
+// One entry per channel per finalize launch.
+struct alignas(16) FinWork {
+    const float *frame;       // finished float frame
+    int16_t     *out;         // int16 frame (frame_len samples)
+    unsigned    *peak;        // peak word of the finished frame
+    unsigned    *peak_next;   // peak word of the frame that becomes the write frame (reset to 0)
+    float       *factor_out;  // where the scale factor is published
+    float        scale;       // ftaudioscalefactor or wspraudioscalefactor
+    unsigned     n_valid;     // samples demodulated into the frame
+    unsigned     frame_len;   // 12000*(period+5)
+    int          emit;        // 0: discarded frame (startEpochTime == 0) -> only the reset
+};
+
+struct alignas(16) PhasorJob {
+    float2  *ckpt;
+    float2   inc;
+    unsigned n_ckpt;
+    unsigned pad_;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Exact float32 complex product, unfused: the sequence g++ emits for std::complex<float>
+// operator* (SSBD.hpp:174 `phase *= phase_inc`).  The TU is built with -ffp-contract=off.
+__device__ __forceinline__ float2 cmul_exact(float2 a, float2 b)
+{
+    const float ac = a.x * b.x;
+    const float bd = a.y * b.y;
+    const float ad = a.x * b.y;
+    const float bc = a.y * b.x;
+    return make_float2(ac - bd, ad + bc);
+}
+
+// Phasor checkpoint table: one thread walks the whole recurrence of one channel once, at open time.
+__global__ void phasor_kernel(const PhasorJob *__restrict__ jobs, int n_jobs)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_jobs) return;
+    const PhasorJob job = jobs[j];
+    float2 p = make_float2(1.0f, 0.0f);                 // SSBD.hpp:121
+    for (unsigned c = 0; c < job.n_ckpt; ++c) {
+        job.ckpt[c] = p;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) p = cmul_exact(p, job.inc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int D, int T>
+struct DemodGeom {
+    static constexpr int G      = 2 * D;              // polyphase branches = lanes per group
+    static constexpr int NBLK   = T + 31;             // input blocks per tile
+    static constexpr int NSAMP  = D * NBLK;           // input samples per tile
+    static constexpr int NW     = T / 2 + 16;         // columns per plane (T/2+15 used, +1 read slack)
+    static constexpr int PITCH0 = (NW + 3) / 4 * 4;
+    // PITCH/4 odd: the 16 lanes of a ds_read_b128 group land in 16 distinct 16-B slots of a bank row
+    static constexpr int PITCH  = ((PITCH0 / 4) % 2 == 1) ? PITCH0 : PITCH0 + 4;
+    static constexpr int NCK    = (NBLK + 15) / 16 + 1;   // checkpoints touched by a tile
+    static constexpr int PLANE_FLOATS = G * PITCH;
+    static constexpr int AUX_FLOATS   = (2 * (NBLK + 1) > T) ? 2 * (NBLK + 1) : T;  // phases, later the output row
+    static constexpr int LDS_BYTES    = (2 * PLANE_FLOATS + AUX_FLOATS) * 4;
+};
+
+template <int D, int T, int NT>
+__global__ __launch_bounds__(NT) void demod_kernel(const ChanWork *__restrict__ works,
+                                                    const float *__restrict__ taps,
+                                                    int tiles_x, int n_ch)
+{
+    using Geo = DemodGeom<D, T>;
+    constexpr int G = Geo::G;
+    constexpr int PITCH = Geo::PITCH;
+    constexpr int NWAVE = NT / 64;
+    constexpr int NG = 64 / G;                 // lane groups per wave
+    constexpr int CPW = (NG >= 2) ? NG / 2 : 1; // 16-output chunks (x2 planes) per wave iteration
+    static_assert(G <= 32, "one group must hold both planes in a wave");
+    static_assert(T % (32 * CPW) == 0, "tile must be a whole number of wave iterations");
+    static_assert((2 * NT) % D == 0, "per-thread tone index must be loop invariant");
+
+    __shared__ __attribute__((aligned(16))) float s_plane[2 * Geo::PLANE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float s_aux[Geo::AUX_FLOATS];
+    float2 *s_phase = reinterpret_cast<float2 *>(s_aux);
+
+    // ---- XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs, so give each
+    // XCD one contiguous run of (channel, tile) pairs: neighbouring tiles re-read 31 blocks of halo,
+    // which then hits that XCD's own L2.
+    const int total = tiles_x * n_ch;
+    const int per_xcd = (total + 7) >> 3;
+    const int wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (wid >= total) return;
+    const int ch = wid / tiles_x;
+    const int tile = wid - ch * tiles_x;
+
+    const ChanWork *cw = works + ch;
+    const unsigned n_blocks = cw->n_blocks;
+    if ((unsigned)tile * T >= n_blocks) return;
+    const int n_out = min((unsigned)T, n_blocks - (unsigned)tile * T);
+
+    const long long origin = cw->origin_abs;
+    const long long q_first = (cw->lo_abs - origin) / D;          // block index of first pending output
+    const long long qs = q_first + (long long)tile * T;           // first output block of this tile
+    const long long qlo = qs - 31;                                // first input block of this tile (may be < 0)
+    const int tid = threadIdx.x;
+
+    // ---- phase 0: bit-exact phasor for blocks qlo .. qlo+NBLK-1
+    if (tid < Geo::NCK) {
+        const float2 inc = cw->inc;
+        const long long c0 = (qlo >= 0) ? (qlo >> 4) : -((15 - qlo) >> 4);   // floor(qlo/16)
+        const long long c = c0 + tid;
+        if (c >= 0) {
+            float2 p = cw->ckpt[c];
+            const long long qb = c << 4;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const long long pb = qb + s - qlo;
+                if (pb >= 0 && pb < Geo::NBLK) s_phase[pb] = p;
+                p = cmul_exact(p, inc);
+            }
+        }
+    }
+    // per-thread constants of the mix
+    const int m0 = (2 * tid) % D;
+    const float2 tn0 = cw->tone[m0];
+    const float2 tn1 = cw->tone[m0 + 1];
+    // polyphase taps of this lane's branch: H[u][v] = h[G*v + u]
+    const int lane = tid & 63;
+    const int u = lane % G;
+    float tap[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) tap[v] = taps[G * v + u];
+
+    __syncthreads();
+
+    // ---- phase 1: load + mix + scatter into the branch-major planes
+    {
+        const unsigned cap = cw->ring_cap;
+        const long long tile_abs0 = origin + qlo * D;              // absolute index of tile sample r = 0
+        long long base = tile_abs0 % (long long)cap;
+        if (base < 0) base += cap;
+        const float4 *ring4 = reinterpret_cast<const float4 *>(cw->ring);
+        const long long first_valid = -qlo * D;                    // r >= first_valid  <=>  sample at/after origin
+        float *plane0 = s_plane;
+        float *plane1 = s_plane + Geo::PLANE_FLOATS;
+        for (int r = 2 * tid; r < Geo::NSAMP; r += 2 * NT) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool live = (long long)r >= first_valid;
+            if (live) {
+                unsigned idx = (unsigned)base + (unsigned)r;
+                if (idx >= cap) idx -= cap;
+                x = ring4[idx >> 1];
+            }
+            float y0r = 0.f, y0i = 0.f, y1r = 0.f, y1i = 0.f;
+            if (live) {
+                const float2 ph = s_phase[r / D];
+                // (x * tone) * phase : same association as the reference's sum*phase (SSBD.hpp:167-170)
+                float ar = __builtin_fmaf(x.x, tn0.x, -(x.y * tn0.y));
+                float ai = __builtin_fmaf(x.x, tn0.y, x.y * tn0.x);
+                y0r = __builtin_fmaf(ar, ph.x, -(ai * ph.y));
+                y0i = __builtin_fmaf(ar, ph.y, ai * ph.x);
+                ar = __builtin_fmaf(x.z, tn1.x, -(x.w * tn1.y));
+                ai = __builtin_fmaf(x.z, tn1.y, x.w * tn1.x);
+                y1r = __builtin_fmaf(ar, ph.x, -(ai * ph.y));
+                y1i = __builtin_fmaf(ar, ph.y, ai * ph.x);
+            }
+            // plane 0 (even outputs, Re): rel = r
+            {
+                const int w = r / G, uu = r % G;
+                if (w < T / 2 + 15) {
+                    plane0[uu * PITCH + w] = y0r;
+                    plane0[(uu + 1) * PITCH + w] = y1r;
+                }
+            }
+            // plane 1 (odd outputs, Im): rel = r - D
+            {
+                const int rel = r - D;
+                if (rel >= 0) {
+                    const int w = rel / G, uu = rel % G;
+                    plane1[uu * PITCH + w] = y0i;
+                    plane1[(uu + 1) * PITCH + w] = y1i;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: branch FIRs + cross-branch reduction.  s_aux is now the output row.
+    {
+        const int wv = tid >> 6;
+        const int g = lane / G;
+        const int pl = g & 1;                       // plane = output parity
+        const float sgn_plane = pl ? -cw->sign : 1.0f;
+        for (int it = wv; it < T / (32 * CPW); it += NWAVE) {
+            const int chunk = it * CPW + (g >> 1);   // 16 outputs of one parity
+            const float4 *src = reinterpret_cast<const float4 *>(
+                s_plane + pl * Geo::PLANE_FLOATS + u * PITCH + 16 * chunk);
+            float x[32];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 t4 = src[k];
+                x[4 * k] = t4.x; x[4 * k + 1] = t4.y; x[4 * k + 2] = t4.z; x[4 * k + 3] = t4.w;
+            }
+            float acc[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = x[r] * tap[0];
+#pragma unroll
+            for (int v = 1; v < 16; ++v)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(x[r + v], tap[v], acc[r]);
+
+            // halving butterfly over the G lanes of the group
+            int nv = 16, rbase = 0;
+#pragma unroll
+            for (int m = G / 2; m >= 1; m >>= 1) {
+                const bool hi = (u & m) != 0;
+                if (nv > 1) {
+                    const int h = nv / 2;
+#pragma unroll
+                    for (int r = 0; r < h; ++r) {
+                        const float keep = hi ? acc[r + h] : acc[r];
+                        const float send = hi ? acc[r] : acc[r + h];
+                        acc[r] = keep + __shfl_xor(send, m, 64);
+                    }
+                    if (hi) rbase += h;
+                    nv = h;
+                } else {
+                    acc[0] += __shfl_xor(acc[0], m, 64);
+                }
+            }
+            // lanes whose low (log2(G) - 4) bits are zero publish (G=32: even lanes; G<=16: all lanes)
+            const bool writer = (G <= 16) ? true : ((u & ((G / 16) - 1)) == 0);
+            if (writer) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    if (r < nv) {
+                        const int wq = 16 * chunk + rbase + r;     // w' within the plane
+                        const float s = (wq & 1) ? -sgn_plane : sgn_plane;
+                        s_aux[2 * wq + pl] = s * acc[r];
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue: whole-row store + frame peak
+    {
+        float *out = cw->out + (size_t)tile * T;
+        float mx = 0.0f;
+        for (int o = tid; o < n_out; o += NT) {
+            const float v = s_aux[o];
+            out[o] = v;
+            mx = fmaxf(mx, fabsf(v));
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        if (lane == 0 && mx > 0.0f) atomicMax(cw->peak, __float_as_uint(mx));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Slot finalise: prepareAudio + float->int16 (Instance.cpp:294-338, 238-241), bit-exact:
+//   factor = 32767.0f / (peak + 1.0f); factor *= scale;  buf[k] *= factor;  (int16)(buf[k] + 0.5f)
+// The peak is max|audio| (max(maxVal, |minVal|) == max|x| for every frame).
+// Samples at and beyond n_valid are the reference's zero tail.
+template <int NT>
+__global__ __launch_bounds__(NT) void finalize_kernel(const FinWork *__restrict__ works)
+{
+    const FinWork *fw = works + blockIdx.y;
+    const unsigned i0 = (blockIdx.x * NT + threadIdx.x) * 8u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (fw->peak_next) *fw->peak_next = 0u;
+    }
+    if (!fw->emit || i0 >= fw->frame_len) return;
+    const float peak = __uint_as_float(*fw->peak);
+    float factor = 32767.0f / (peak + 1.0f);
+    factor = factor * fw->scale;
+    if (i0 == 0 && fw->factor_out) *fw->factor_out = factor;
+    const unsigned nv = fw->n_valid;
+    float v[8];
+    if (i0 + 8 <= nv) {
+        const float4 a = *reinterpret_cast<const float4 *>(fw->frame + i0);
+        const float4 b = *reinterpret_cast<const float4 *>(fw->frame + i0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (i0 + k < nv) ? fw->frame[i0 + k] : 0.0f;
+    }
+    int q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float scaled = v[k] * factor;                 // buf[k] *= factor
+        const float biased = scaled + 0.5f;                 // + 0.5f
+        q[k] = (int)biased;                                 // C truncation toward zero, then narrowed to int16
+    }
+    uint4 pk;
+    pk.x = ((unsigned)q[0] & 0xFFFFu) | ((unsigned)q[1] << 16);
+    pk.y = ((unsigned)q[2] & 0xFFFFu) | ((unsigned)q[3] << 16);
+    pk.z = ((unsigned)q[4] & 0xFFFFu) | ((unsigned)q[5] << 16);
+    pk.w = ((unsigned)q[6] & 0xFFFFu) | ((unsigned)q[7] << 16);
+    const unsigned rem = fw->frame_len - i0;
+    if (rem >= 8) {
+        *reinterpret_cast<uint4 *>(fw->out + i0) = pk;
+    } else {
+        for (unsigned k = 0; k < rem; ++k) fw->out[i0 + k] = (int16_t)q[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Portable synthetic IQ, bit-identical to oracle/cwsl_oracle.c:orc_synth_* (integer Irwin-Hall
+// noise, exact in float; tones by uint32 phase accumulator into a host-made 4096-entry table).
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float noise_from_bits(unsigned long long r)
+{
+    const int s = (int)(r & 0xFFFF) + (int)((r >> 16) & 0xFFFF) + (int)((r >> 32) & 0xFFFF) +
+                  (int)((r >> 48) & 0xFFFF) - 131070;
+    return (float)s * 0.03125f;
+}
+
+struct SynthArgs {
+    float2 *ring;
+    unsigned ring_cap;
+    unsigned long long ring_pos;      // ring index of the first generated sample
+    unsigned long long first_sample;  // stream index of the first generated sample
+    unsigned long long seed;
+    unsigned n;
+    int n_tones;
+    float amp;
+    unsigned step[8];                 // cycles/sample * 2^32
+};
+
+__global__ void synth_kernel(SynthArgs a, const float2 *__restrict__ sincos_tab)
+{
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.n) return;
+    const unsigned long long i = a.first_sample + k;
+    float re = noise_from_bits(mix64(a.seed ^ (2ull * i) * 0xD1342543DE82EF95ull));
+    float im = noise_from_bits(mix64(a.seed ^ (2ull * i + 1ull) * 0xD1342543DE82EF95ull));
+    for (int t = 0; t < a.n_tones; ++t) {
+        const unsigned ph = (unsigned)(i * (unsigned long long)a.step[t]);
+        const float2 cs = sincos_tab[ph >> 20];
+        re = re + a.amp * cs.x;       // unfused, like the oracle
+        im = im + a.amp * cs.y;
+    }
+    unsigned long long p = a.ring_pos + k;
+    if (p >= a.ring_cap) p -= a.ring_cap;
+    a.ring[p] = make_float2(re, im);
+}
+
+} // namespace cwslg

@@ -1,0 +1,170 @@
+/*
+ * cwsl_gpu.h -- C ABI of libcwslgpu.so, the MI355X (gfx950) replacement for the
+ * per-Instance CPU DSP chain of CWSL_DIGI.
+ *
+ * The reference has no plugin/FFI layer: the seam is a handful of C++ call sites.
+ * Every entry point below names the reference interface it replaces (paths are
+ * relative to the reference's source/ directory).  include/cwsl_gpu_shim.hpp
+ * wraps this ABI back into SSBD- and Instance-shaped C++ classes so those call
+ * sites compile unchanged; INTEGRATION.md shows the binding.
+ *
+ * Conventions: plain pointers and sizes only; every function returns a CWSLG_*
+ * status (0 = OK, <0 = error); the library never falls back to a CPU path --
+ * without a usable HIP device cwslg_create() fails with CWSLG_ERR_NO_DEVICE.
+ * All entry points are thread-safe with respect to one context (one internal
+ * mutex; device work is serialised on the context's HIP stream), mirroring the
+ * reference's {Receiver thread} || {slot-clock thread} || {consumer} concurrency.
+ */
+#ifndef CWSL_GPU_H
+#define CWSL_GPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CWSLG_ABI_VERSION 1
+
+/* ---- status codes ---- */
+#define CWSLG_OK                  0
+#define CWSLG_ERR_RATIO          -1  /* SSBD.hpp:54-55   "Fs/B must be an even integer >= 4"      */
+#define CWSLG_ERR_BAND_LOW       -2  /* SSBD.hpp:100-101 "Signal outside of band (low)"           */
+#define CWSLG_ERR_BAND_HIGH      -3  /* SSBD.hpp:102-103 "Signal outside of band (high)"          */
+#define CWSLG_ERR_NOMEM          -4
+#define CWSLG_ERR_MODE           -5  /* CWSL_DIGI.hpp:110-112 "Unhandled mode: ..."               */
+#define CWSLG_ERR_ARG            -6
+#define CWSLG_ERR_NO_DEVICE      -7  /* no HIP device / wrong arch: the product never runs on CPU */
+#define CWSLG_ERR_HIP            -8
+#define CWSLG_ERR_NO_FRAME       -9  /* nothing to fetch (e.g. first partial slot, Instance.cpp:224-227) */
+#define CWSLG_ERR_UNSUPPORTED   -10  /* sample rate other than CWSL's 48/96/192 kHz               */
+#define CWSLG_ERR_BLOCK         -11  /* n_complex not a multiple of SSBD::GetInSize() (= 2*Fs/B)  */
+
+/* ---- slot-clock groups: CWSL_DIGI_Types.hpp:83-143 (SyncPredicates vectors) ---- */
+#define CWSLG_GROUP_FT8     0   /* FT8, JS8                       (ft8Preds)    */
+#define CWSLG_GROUP_FT4     1   /* FT4                            (ft4Preds)    */
+#define CWSLG_GROUP_Q65_30  2   /* Q65-30                         (q65_30Preds) */
+#define CWSLG_GROUP_S60     3   /* JT65, FST4-60                  (s60sPreds)   */
+#define CWSLG_GROUP_S120    4   /* WSPR, FST4-120, FST4W-120      (s120sPreds)  */
+#define CWSLG_GROUP_S300    5   /* FST4-300, FST4W-300            (s300sPreds)  */
+#define CWSLG_GROUP_S900    6   /* FST4-900, FST4W-900            (s900sPreds)  */
+#define CWSLG_GROUP_S1800   7   /* FST4-1800, FST4W-1800          (s1800sPreds) */
+#define CWSLG_NUM_GROUPS    8
+
+typedef struct cwslg_ctx cwslg_ctx;
+
+/* One sync candidate (row a13 of SURVEY.md 8a: no reference counterpart; the layout is
+ * builder-defined and the ordering is deterministic: descending sync, ties by ascending
+ * freq_bin then ascending time_step). */
+typedef struct {
+    int32_t freq_bin;     /* FT8: 3.125 Hz bins of the 3840-point symbol spectrum               */
+    int32_t time_step;    /* FT8: lag in quarter-symbol steps (40 ms), -62..+62                 */
+    float   sync;         /* normalised Costas sync metric                                      */
+    float   freq_hz;      /* freq_bin * df                                                      */
+    float   dt_s;         /* (time_step - 0.5 s offset convention of the upstream decoder)      */
+} cwslg_candidate;
+
+/* ---- context ---- */
+int  cwslg_abi_version(void);
+/* device_ordinal < 0: use LOCAL_RANK from the environment if set, else 0. */
+int  cwslg_create(cwslg_ctx **out, int device_ordinal);
+void cwslg_destroy(cwslg_ctx *ctx);
+const char *cwslg_strerror(int status);
+/* Text of the last failure on this context (HIP error string included). */
+const char *cwslg_last_error(cwslg_ctx *ctx);
+/* wsjtx.ftaudioscalefactor / wsjtx.wspraudioscalefactor (CWSL_DIGI.cpp:100-101; defaults 0.90 / 0.20) */
+int  cwslg_set_scale_factors(cwslg_ctx *ctx, float scale_ft, float scale_wspr);
+
+/* ---- receivers: replaces Receiver::init + the SPMC ring (Receiver.hpp:115-163, ring_buffer_spmc.h) ----
+ * fs, iq_len, lo_hz are SM_HDR.SampleRate / BlockInSamples / L0 (SharedMemory.h:10-21, Receiver.hpp:86-88).
+ * ring_blocks = 0 selects the reference depth 3*(fs/iq_len+1) blocks (Receiver.hpp:132).  The ring lives in HBM. */
+int cwslg_receiver_open(cwslg_ctx *ctx, uint32_t fs, uint32_t iq_len, int32_t lo_hz,
+                        uint32_t ring_blocks, int *rx_id);
+int cwslg_receiver_close(cwslg_ctx *ctx, int rx_id);
+/* Replaces the memcpy into the ring slot + inc_write_index (Receiver.hpp:247-249) AND the N per-Instance
+ * pop_no_wait()/Iterate() loops (Instance.cpp:265-276): called ONCE per block per receiver.  The host block
+ * is only read during the call.  n_complex must be a multiple of 2*fs/6000 (SSBD::GetInSize). */
+int cwslg_push_iq(cwslg_ctx *ctx, int rx_id, const float *iq_interleaved, uint32_t n_complex);
+/* Same, source already in device memory (tests, device-side producers). */
+int cwslg_push_iq_device(cwslg_ctx *ctx, int rx_id, const void *d_iq_interleaved, uint32_t n_complex);
+/* Synthetic IQ source standing in for CW Skimmer's shared memory (SharedMemory.cpp is Win32-only):
+ * appends n_complex samples generated on the device.  The generator is the portable one specified in
+ * DESIGN.md (integer Irwin-Hall noise + table-lookup tones) and is bit-identical to the oracle's.
+ * tones_hz are relative to the LO; block_len = the push granularity used for the frame-overflow guard. */
+int cwslg_push_synth(cwslg_ctx *ctx, int rx_id, uint64_t seed, uint32_t n_complex, uint32_t block_len,
+                     const double *tones_hz, int n_tones, float amp);
+
+/* Zero-copy producer: declare that the next n_complex samples ALREADY in the ring (written by a device-side
+ * producer, or left there by an earlier lap) are new input.  Host bookkeeping only; nothing is copied.
+ * block_len = granularity of the frame-overflow guard (0 = the receiver's iq_len). */
+int cwslg_ring_commit(cwslg_ctx *ctx, int rx_id, uint32_t n_complex, uint32_t block_len);
+/* cwslg_ring_commit on every open receiver of the context (one call per tick for thousands of streams). */
+int cwslg_ring_commit_all(cwslg_ctx *ctx, uint32_t n_complex, uint32_t block_len);
+/* Device address and capacity (complex samples) of the ring; *write_pos = ring index of the next sample. */
+int cwslg_ring_info(cwslg_ctx *ctx, int rx_id, void **d_ring, uint32_t *capacity, uint64_t *total_pushed);
+
+/* ---- channels: replaces SSBD<float>(Fs, SSB_BW, (float)demodFreq, USB) + Instance::init
+ *      (Instance.cpp:121-176,183-187).  demod_hz = calibratedSSBFreq - LO (Instance.cpp:183).
+ *      mode is the decoder= line's mode string ("FT8", "FT4", "WSPR", "FST4W-120", ...). ---- */
+int cwslg_channel_open(cwslg_ctx *ctx, int rx_id, int32_t demod_hz, int usb, const char *mode, int *ch_id);
+int cwslg_channel_close(cwslg_ctx *ctx, int ch_id);
+/* SSBD getters (SSBD.hpp:140-154) for the shim */
+int cwslg_channel_info(cwslg_ctx *ctx, int ch_id, uint32_t *in_size, uint32_t *out_size,
+                       uint32_t *out_rate, uint32_t *delay, size_t *frame_len);
+
+/* ---- processing ----
+ * Demodulate everything pushed so far for every channel (enqueued on the context stream; returns
+ * without waiting).  push/slot_boundary/fetch call it implicitly when they have to. */
+int cwslg_process(cwslg_ctx *ctx);
+/* Replaces SyncPredicate::store(true) for every predicate of one group (CWSL_DIGI.cpp:247-251) and the
+ * per-Instance reaction to it (Instance.cpp:203-253): swap frames, stamp the new frame with epoch_s,
+ * finalise (peak-normalise + int16) the finished one unless its start time is 0, restart the demodulator. */
+int cwslg_slot_boundary(cwslg_ctx *ctx, int group, uint64_t epoch_s);
+/* Same for a single channel (one SyncPredicate). */
+int cwslg_slot_boundary_channel(cwslg_ctx *ctx, int ch_id, uint64_t epoch_s);
+int cwslg_synchronize(cwslg_ctx *ctx);
+
+/* ---- results: replaces decoderPool->push(ItemToDecode(audio_i16, ...)) (Instance.cpp:244-245) ----
+ * Copies the last finalised frame of the channel: frame_len = 12000*(period+5) int16 samples with the
+ * reference's zero tail; *n_valid = samples actually demodulated in the slot; *start_epoch = the frame's
+ * startEpochTime.  Returns CWSLG_ERR_NO_FRAME until a frame has been finalised. */
+int cwslg_fetch_frame(cwslg_ctx *ctx, int ch_id, int16_t *dst, size_t cap,
+                      uint64_t *start_epoch, size_t *n_valid, float *factor);
+/* The same frame as 12 kHz float audio BEFORE prepareAudio's scaling (for the 1e-5 check). */
+int cwslg_fetch_audio_f32(cwslg_ctx *ctx, int ch_id, float *dst, size_t cap, size_t *n_valid);
+/* Device pointers of the last finalised frame (valid until the next boundary of that channel). */
+int cwslg_frame_device_ptrs(cwslg_ctx *ctx, int ch_id, const int16_t **d_i16, const float **d_f32);
+/* Sync candidates of the last finalised frame (FT8/FT4 channels with sync enabled). */
+int cwslg_enable_sync(cwslg_ctx *ctx, int enable, float syncmin, int max_cand, int f_lo_hz, int f_hi_hz);
+int cwslg_fetch_candidates(cwslg_ctx *ctx, int ch_id, cwslg_candidate *dst, int max, int *n);
+
+/* ---- introspection for bench / tests ---- */
+typedef struct {
+    uint64_t demod_launches;       /* demod kernel launches                                   */
+    uint64_t demod_samples;        /* complex input samples consumed, summed over channels    */
+    uint64_t finalize_launches;
+    uint64_t frames_emitted;
+    uint64_t frames_discarded;     /* startEpochTime == 0                                      */
+    uint64_t blocks_dropped;       /* "af buffer full" events (Instance.cpp:268-271)           */
+    uint64_t h2d_bytes;
+    double   demod_ms;             /* HIP-event time of demod kernels on the context stream   */
+    double   finalize_ms;
+    double   sync_ms;
+} cwslg_stats;
+int cwslg_get_stats(cwslg_ctx *ctx, cwslg_stats *out);
+int cwslg_reset_stats(cwslg_ctx *ctx);
+/* Enable HIP-event timing of every kernel launch (bench.py's roofline leg).  Off by default. */
+int cwslg_set_timing(cwslg_ctx *ctx, int enable);
+/* Raw stream handle (hipStream_t) so callers can order their own work (torch, RCCL) against it. */
+void *cwslg_stream(cwslg_ctx *ctx);
+/* Host-side DSP constants exactly as uploaded (tests pin them against the oracle):
+ * taps[32*D], tone[2*D] (re,im), phase_inc[2]; returns D (= Fs/12000) or <0. */
+int cwslg_channel_constants(cwslg_ctx *ctx, int ch_id, float *taps, float *tone_ri, float *phase_inc_ri);
+/* Phasor checkpoints (every 16 blocks) as computed on the device: copies up to n complex values. */
+int cwslg_channel_phasor_checkpoints(cwslg_ctx *ctx, int ch_id, float *dst_ri, size_t n, size_t *n_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CWSL_GPU_H */

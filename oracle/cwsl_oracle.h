@@ -116,6 +116,10 @@ void orc_synth_noise(uint64_t seed, uint64_t first_sample, uint64_t n_complex, f
 void orc_synth_add_tones(uint64_t fs, uint64_t first_sample, uint64_t n_complex,
                          const double *f_hz, int k_tones, float amp, float *iq_ri);
 
+/* CPU baseline ("port"): `threads` channels in parallel (one pthread each, the reference's
+ * thread-per-Instance shape), `slots` FT8 slots of n_per_slot samples each; returns wall seconds. */
+double orc_bench_cpu(int threads, int slots, uint64_t fs, uint32_t iq_len, uint64_t n_per_slot);
+
 /* position-weighted checksum used by fixtures: sum_k (1+(k%251)) * x[k] in double */
 double orc_checksum_f32(const float *x, size_t n);
 uint32_t orc_crc32(const void *data, size_t nbytes);

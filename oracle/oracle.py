@@ -76,6 +76,8 @@ def lib():
         L.orc_synth_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _f32p]
         L.orc_synth_add_tones.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _f64p, C.c_int, C.c_float, _f32p]
         L.orc_checksum_f32.argtypes = [_f32p, C.c_size_t]; L.orc_checksum_f32.restype = C.c_double
+        L.orc_bench_cpu.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint64]
+        L.orc_bench_cpu.restype = C.c_double
         L.orc_crc32.argtypes = [C.c_void_p, C.c_size_t]; L.orc_crc32.restype = C.c_uint32
         _lib = L
     return _lib
@@ -239,6 +241,19 @@ class Channel:
             took += lib().orc_channel_push(C.byref(self.c), v[2 * k * self.iq_len: 2 * (k + 1) * self.iq_len])
         return took
 
+    def push_stream(self, iq):
+        """Whole iq_len blocks, then one trailing shorter block (a multiple of 4*D samples) pushed with
+        iq_len temporarily set to its length -- how the GPU path accounts a non-multiple commit."""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        whole = iq.shape[0] // self.iq_len * self.iq_len
+        took = self.push_many(iq[:whole]) if whole else 0
+        rest = iq.shape[0] - whole
+        if rest:
+            self.c.iq_len = rest
+            took += lib().orc_channel_push(C.byref(self.c), np.ascontiguousarray(iq[whole:]).view(np.float32))
+            self.c.iq_len = self.iq_len
+        return took
+
     def boundary(self, epoch_s, want_f32=False):
         """-> None (frame discarded) or dict(i16, t_start, factor[, f32])."""
         i16 = np.empty(self.frame_len, np.int16)
@@ -305,3 +320,8 @@ def checksum(x):
 def crc32(a):
     a = np.ascontiguousarray(a)
     return int(lib().orc_crc32(a.ctypes.data, a.nbytes))
+
+
+def bench_cpu(threads, slots, fs=192000, iq_len=2048, n_per_slot=2880000):
+    """Wall seconds for `threads` channels x `slots` FT8 slots on the host cores (reference shape)."""
+    return float(lib().orc_bench_cpu(threads, slots, fs, iq_len, n_per_slot))

@@ -1,0 +1,53 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure).  Built on demand; liboracle.so is plain C."""
+    from oracle import oracle as O
+    O.build(ref=True)
+    return O
+
+
+@pytest.fixture()
+def ctx():
+    """A fresh libcwslgpu context on cuda:0.  No fallback: raises without a gfx950 device."""
+    import cwsl_digi_amd as P
+    c = P.Context(0)
+    yield c
+    c.close()
+
+
+def assert_frames_match(gpu_f32, ref_f32, tol=1e-5):
+    """north_star tolerance: max|gpu-ref| <= 1e-5 * max|ref| per frame (hard part 2)."""
+    peak = float(np.abs(ref_f32).max())
+    err = float(np.abs(gpu_f32.astype(np.float64) - ref_f32.astype(np.float64)).max())
+    assert err <= tol * max(peak, 1e-30), f"max err {err:.3e} vs peak {peak:.3e} (rel {err / max(peak, 1e-30):.3e})"
+    return err / max(peak, 1e-30)
+
+
+def assert_int16_match(gpu_i16, ref_i16, ref_scaled_f32, peak_rel_tol=1e-5):
+    """int16 frames must be identical except where the pre-rounding value lies within
+    1e-5*peak of a rounding boundary (documented +-1 LSB ties)."""
+    diff = gpu_i16.astype(np.int32) - ref_i16.astype(np.int32)
+    bad = np.nonzero(diff)[0]
+    if bad.size == 0:
+        return 0
+    assert np.abs(diff[bad]).max() <= 1, "int16 differs by more than 1 LSB"
+    peak = float(np.abs(ref_scaled_f32).max())
+    x = ref_scaled_f32[bad].astype(np.float64) + 0.5
+    dist = np.abs(x - np.round(x))        # distance of (x+0.5) to the nearest integer = truncation boundary
+    assert (dist <= peak_rel_tol * peak).all(), "int16 mismatch away from a rounding tie"
+    return int(bad.size)
