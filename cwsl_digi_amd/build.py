@@ -15,7 +15,10 @@ LIB = os.path.join(LIBDIR, "libcwslgpu.so")
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit __builtin_fmaf and every
 # bit-exact sequence (the float32 phasor recurrence, prepareAudio, the synthetic source) is plain * and +.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC",
-               "-Wno-unused-value", "-Wno-unused-result"]
+               "-Wno-unused-value", "-Wno-unused-result",
+               # gfx950 issues v_pk_fma_f32 no faster than two v_fma_f32, and SLP-packing the FIR makes hipcc
+               # re-read odd-aligned operand pairs from LDS: keep the FMAs scalar
+               "-fno-slp-vectorize"]
 
 
 def sources():

@@ -40,6 +40,23 @@
 
 namespace cwslg {
 
+// Pointers fetched from a descriptor in memory are generic to the compiler (flat_load); these are
+// known to be HBM addresses, so say so and get global_load / global_store.
+#define CWSLG_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const CWSLG_GLOBAL T *as_global(const T *p)
+{
+    return (const CWSLG_GLOBAL T *)(uintptr_t)p;
+}
+template <typename T>
+__device__ __forceinline__ CWSLG_GLOBAL T *as_global_rw(T *p)
+{
+    return (CWSLG_GLOBAL T *)(uintptr_t)p;
+}
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 // One entry per active channel per demod launch.
 struct alignas(16) ChanWork {
     const float2 *ring;       // receiver IQ ring in HBM (interleaved re,im)
@@ -103,6 +120,82 @@ __global__ void phasor_kernel(const PhasorJob *__restrict__ jobs, int n_jobs)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Cross-lane primitives of the branch reduction: no LDS traffic, VALU only.
+//   DPP_ROR8        lane i <- lane i^8   (rotate the 16-lane row by 8)
+//   DPP_HALF_MIRROR lane i <- lane i^7   (reverse each 8-lane half row: pairs bit2 = 0 with bit2 = 1)
+//   DPP_XOR2/XOR1   quad permutes [2,3,0,1] / [1,0,3,2]
+constexpr int DPP_ROR8 = 0x128, DPP_HALF_MIRROR = 0x141, DPP_XOR2 = 0x4E, DPP_XOR1 = 0xB1;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+
+// One halving step over the lane bit BIT (pairing CTRL): lanes with the bit clear keep lo and get the
+// partner's lo, lanes with it set keep hi and get the partner's hi.
+template <int CTRL>
+__device__ __forceinline__ float halve_dpp(float lo, float hi, bool bit_set)
+{
+    const float keep = bit_set ? hi : lo;
+    const float send = bit_set ? lo : hi;
+    return keep + dpp_get<CTRL>(send);
+}
+
+// Same across the two 16-lane rows of a 32-lane group (lane bit 4) with v_permlane16_swap:
+// afterwards even rows hold lo(row r)+lo(row r+1) and odd rows hold hi(row r-1)+hi(row r).
+__device__ __forceinline__ float halve_rows(float lo, float hi)
+{
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+
+// Sum acc[0..15] over the G lanes of a group.  On return lane u holds NV results acc[0..NV-1] for
+// output indices rbase .. rbase+NV-1 (NV = 1 for G >= 16, 2 for G = 8); for G = 32 lanes u and u^1
+// hold the same result.
+template <int G>
+__device__ __forceinline__ int reduce_branches(float (&acc)[16], int u)
+{
+    int rbase = 0;
+    if constexpr (G == 32) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc[r] = halve_rows(acc[r], acc[r + 8]);
+        if (u & 16) rbase += 8;
+    }
+    if constexpr (G >= 16) {
+        const bool b = (u & 8) != 0;
+        constexpr int N = (G == 32) ? 8 : 16;
+#pragma unroll
+        for (int r = 0; r < N / 2; ++r) acc[r] = halve_dpp<DPP_ROR8>(acc[r], acc[r + N / 2], b);
+        if (b) rbase += N / 2;
+    }
+    {
+        const bool b = (u & 4) != 0;
+        constexpr int N = (G == 32) ? 4 : (G == 16 ? 8 : 16);
+#pragma unroll
+        for (int r = 0; r < N / 2; ++r) acc[r] = halve_dpp<DPP_HALF_MIRROR>(acc[r], acc[r + N / 2], b);
+        if (b) rbase += N / 2;
+    }
+    {
+        const bool b = (u & 2) != 0;
+        constexpr int N = (G == 32) ? 2 : (G == 16 ? 4 : 8);
+#pragma unroll
+        for (int r = 0; r < N / 2; ++r) acc[r] = halve_dpp<DPP_XOR2>(acc[r], acc[r + N / 2], b);
+        if (b) rbase += N / 2;
+    }
+    if constexpr (G == 32) {
+        acc[0] = acc[0] + dpp_get<DPP_XOR1>(acc[0]);
+    } else {
+        const bool b = (u & 1) != 0;
+        constexpr int N = (G == 16) ? 2 : 4;
+#pragma unroll
+        for (int r = 0; r < N / 2; ++r) acc[r] = halve_dpp<DPP_XOR1>(acc[r], acc[r + N / 2], b);
+        if (b) rbase += N / 2;
+    }
+    return rbase;
+}
+
+// ---------------------------------------------------------------------------------------------
 template <int D, int T>
 struct DemodGeom {
     static constexpr int G      = 2 * D;              // polyphase branches = lanes per group
@@ -158,26 +251,37 @@ __global__ __launch_bounds__(NT) void demod_kernel(const ChanWork *__restrict__ 
     const long long qlo = qs - 31;                                // first input block of this tile (may be < 0)
     const int tid = threadIdx.x;
 
-    // ---- phase 0: bit-exact phasor for blocks qlo .. qlo+NBLK-1
-    if (tid < Geo::NCK) {
-        const float2 inc = cw->inc;
-        const long long c0 = (qlo >= 0) ? (qlo >> 4) : -((15 - qlo) >> 4);   // floor(qlo/16)
-        const long long c = c0 + tid;
-        if (c >= 0) {
-            float2 p = cw->ckpt[c];
-            const long long qb = c << 4;
+    // ---- issue every HBM load of the tile up front (IQ, checkpoint, tone, taps) so that ONE memory
+    // latency is paid per tile, overlapped with the serial phasor rebuild below.
+    constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
+    const unsigned cap = cw->ring_cap;
+    const long long tile_abs0 = origin + qlo * D;              // absolute index of tile sample r = 0
+    long long base = tile_abs0 % (long long)cap;
+    if (base < 0) base += cap;
+    // r >= first_valid  <=>  sample at/after the demodulator's origin (x[i<0] = 0)
+    const int first_valid = (qlo >= 0) ? 0 : ((-qlo * D > (long long)Geo::NSAMP) ? Geo::NSAMP : (int)(-qlo * D));
+    const CWSLG_GLOBAL v4f *ring4 = as_global(reinterpret_cast<const v4f *>(cw->ring));
+    v4f xs[NIT];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const long long pb = qb + s - qlo;
-                if (pb >= 0 && pb < Geo::NBLK) s_phase[pb] = p;
-                p = cmul_exact(p, inc);
-            }
-        }
+    for (int it = 0; it < NIT; ++it) {
+        int r = 2 * tid + it * 2 * NT;
+        if (r > Geo::NSAMP - 2) r = Geo::NSAMP - 2;            // clamp: the load is unconditional
+        unsigned idx = (unsigned)base + (unsigned)r;
+        if (idx >= cap) idx -= cap;
+        xs[it] = ring4[idx >> 1];
+    }
+    float2 ck = make_float2(1.0f, 0.0f);
+    const long long c0 = (qlo >= 0) ? (qlo >> 4) : -((15 - qlo) >> 4);   // floor(qlo/16)
+    const long long cidx = c0 + tid;
+    if (tid < Geo::NCK && cidx >= 0) {
+        const v2f t = as_global(reinterpret_cast<const v2f *>(cw->ckpt))[cidx];
+        ck = make_float2(t.x, t.y);
     }
     // per-thread constants of the mix
     const int m0 = (2 * tid) % D;
-    const float2 tn0 = cw->tone[m0];
-    const float2 tn1 = cw->tone[m0 + 1];
+    const v4f tn01 = as_global(reinterpret_cast<const v4f *>(cw->tone))[m0 >> 1];   // tone[m0], tone[m0+1]
+    const float2 tn0 = make_float2(tn01.x, tn01.y);
+    const float2 tn1 = make_float2(tn01.z, tn01.w);
     // polyphase taps of this lane's branch: H[u][v] = h[G*v + u]
     const int lane = tid & 63;
     const int u = lane % G;
@@ -185,54 +289,57 @@ __global__ __launch_bounds__(NT) void demod_kernel(const ChanWork *__restrict__ 
 #pragma unroll
     for (int v = 0; v < 16; ++v) tap[v] = taps[G * v + u];
 
+    // ---- phase 0: bit-exact phasor for blocks qlo .. qlo+NBLK-1
+    if (tid < Geo::NCK && cidx >= 0) {
+        const float2 inc = cw->inc;
+        float2 p = ck;
+        const long long qb = cidx << 4;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const long long pb = qb + s - qlo;
+            if (pb >= 0 && pb < Geo::NBLK) s_phase[pb] = p;
+            p = cmul_exact(p, inc);
+        }
+    }
     __syncthreads();
 
-    // ---- phase 1: load + mix + scatter into the branch-major planes
+    // ---- phase 1: mix + scatter into the branch-major planes
     {
-        const unsigned cap = cw->ring_cap;
-        const long long tile_abs0 = origin + qlo * D;              // absolute index of tile sample r = 0
-        long long base = tile_abs0 % (long long)cap;
-        if (base < 0) base += cap;
-        const float4 *ring4 = reinterpret_cast<const float4 *>(cw->ring);
-        const long long first_valid = -qlo * D;                    // r >= first_valid  <=>  sample at/after origin
         float *plane0 = s_plane;
         float *plane1 = s_plane + Geo::PLANE_FLOATS;
-        for (int r = 2 * tid; r < Geo::NSAMP; r += 2 * NT) {
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            const bool live = (long long)r >= first_valid;
-            if (live) {
-                unsigned idx = (unsigned)base + (unsigned)r;
-                if (idx >= cap) idx -= cap;
-                x = ring4[idx >> 1];
-            }
-            float y0r = 0.f, y0i = 0.f, y1r = 0.f, y1i = 0.f;
-            if (live) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = 2 * tid + it * 2 * NT;
+            if (r < Geo::NSAMP) {
+                const bool live = r >= first_valid;
+                const v4f x = xs[it];
                 const float2 ph = s_phase[r / D];
                 // (x * tone) * phase : same association as the reference's sum*phase (SSBD.hpp:167-170)
                 float ar = __builtin_fmaf(x.x, tn0.x, -(x.y * tn0.y));
                 float ai = __builtin_fmaf(x.x, tn0.y, x.y * tn0.x);
-                y0r = __builtin_fmaf(ar, ph.x, -(ai * ph.y));
-                y0i = __builtin_fmaf(ar, ph.y, ai * ph.x);
+                float y0r = __builtin_fmaf(ar, ph.x, -(ai * ph.y));
+                float y0i = __builtin_fmaf(ar, ph.y, ai * ph.x);
                 ar = __builtin_fmaf(x.z, tn1.x, -(x.w * tn1.y));
                 ai = __builtin_fmaf(x.z, tn1.y, x.w * tn1.x);
-                y1r = __builtin_fmaf(ar, ph.x, -(ai * ph.y));
-                y1i = __builtin_fmaf(ar, ph.y, ai * ph.x);
-            }
-            // plane 0 (even outputs, Re): rel = r
-            {
-                const int w = r / G, uu = r % G;
-                if (w < T / 2 + 15) {
-                    plane0[uu * PITCH + w] = y0r;
-                    plane0[(uu + 1) * PITCH + w] = y1r;
+                float y1r = __builtin_fmaf(ar, ph.x, -(ai * ph.y));
+                float y1i = __builtin_fmaf(ar, ph.y, ai * ph.x);
+                if (!live) { y0r = 0.f; y0i = 0.f; y1r = 0.f; y1i = 0.f; }   // x[i<0] = 0 (fresh demodulator)
+                // plane 0 (even outputs, Re): rel = r
+                {
+                    const int w = r / G, uu = r % G;
+                    if (w < T / 2 + 15) {
+                        plane0[uu * PITCH + w] = y0r;
+                        plane0[(uu + 1) * PITCH + w] = y1r;
+                    }
                 }
-            }
-            // plane 1 (odd outputs, Im): rel = r - D
-            {
-                const int rel = r - D;
-                if (rel >= 0) {
-                    const int w = rel / G, uu = rel % G;
-                    plane1[uu * PITCH + w] = y0i;
-                    plane1[(uu + 1) * PITCH + w] = y1i;
+                // plane 1 (odd outputs, Im): rel = r - D
+                {
+                    const int rel = r - D;
+                    if (rel >= 0) {
+                        const int w = rel / G, uu = rel % G;
+                        plane1[uu * PITCH + w] = y0i;
+                        plane1[(uu + 1) * PITCH + w] = y1i;
+                    }
                 }
             }
         }
@@ -263,35 +370,16 @@ __global__ __launch_bounds__(NT) void demod_kernel(const ChanWork *__restrict__ 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(x[r + v], tap[v], acc[r]);
 
-            // halving butterfly over the G lanes of the group
-            int nv = 16, rbase = 0;
-#pragma unroll
-            for (int m = G / 2; m >= 1; m >>= 1) {
-                const bool hi = (u & m) != 0;
-                if (nv > 1) {
-                    const int h = nv / 2;
-#pragma unroll
-                    for (int r = 0; r < h; ++r) {
-                        const float keep = hi ? acc[r + h] : acc[r];
-                        const float send = hi ? acc[r] : acc[r + h];
-                        acc[r] = keep + __shfl_xor(send, m, 64);
-                    }
-                    if (hi) rbase += h;
-                    nv = h;
-                } else {
-                    acc[0] += __shfl_xor(acc[0], m, 64);
-                }
-            }
-            // lanes whose low (log2(G) - 4) bits are zero publish (G=32: even lanes; G<=16: all lanes)
-            const bool writer = (G <= 16) ? true : ((u & ((G / 16) - 1)) == 0);
+            // sum the branches: halving butterfly over the G lanes of the group (DPP / permlane, no LDS)
+            const int rbase = reduce_branches<G>(acc, u);
+            constexpr int NV = (G == 8) ? 2 : 1;
+            const bool writer = (G == 32) ? ((u & 1) == 0) : true;
             if (writer) {
 #pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    if (r < nv) {
-                        const int wq = 16 * chunk + rbase + r;     // w' within the plane
-                        const float s = (wq & 1) ? -sgn_plane : sgn_plane;
-                        s_aux[2 * wq + pl] = s * acc[r];
-                    }
+                for (int r = 0; r < NV; ++r) {
+                    const int wq = 16 * chunk + rbase + r;         // w' within the plane
+                    const float s = (wq & 1) ? -sgn_plane : sgn_plane;
+                    s_aux[2 * wq + pl] = s * acc[r];
                 }
             }
         }
@@ -300,7 +388,7 @@ __global__ __launch_bounds__(NT) void demod_kernel(const ChanWork *__restrict__ 
 
     // ---- epilogue: whole-row store + frame peak
     {
-        float *out = cw->out + (size_t)tile * T;
+        CWSLG_GLOBAL float *out = as_global_rw(cw->out) + (size_t)tile * T;
         float mx = 0.0f;
         for (int o = tid; o < n_out; o += NT) {
             const float v = s_aux[o];
