@@ -1,0 +1,119 @@
+// cwsl_gpu_shim.hpp -- header-only C++17 shim that turns the C ABI of libcwslgpu.so back into the shapes
+// the reference's call sites use, so Receiver / Instance / DecoderPool code compiles against the GPU path
+// with one-line changes.
+//
+//   cwslgpu::Context          process-wide handle (one per GPU)
+//   cwslgpu::ReceiverPort     what Receiver::readIQ writes into instead of ring_buffer_spmc_t
+//                             (source/Receiver.hpp:247-249)
+//   cwslgpu::SsbChannel       SSBD<float>-shaped object: same constructor arguments, same getters, same
+//                             std::invalid_argument messages (source/SSBD.hpp:48-59,97-103,140-154)
+//   cwslgpu::FrameSink        what Instance::sampleManager does at a slot boundary, as a callback that
+//                             receives the ItemToDecode ingredients (source/Instance.cpp:238-245)
+//
+// Nothing here computes DSP: every call forwards to the C ABI.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <complex>
+
+#include "cwsl_gpu.h"
+
+namespace cwslgpu {
+
+inline void check(cwslg_ctx *c, int rc)
+{
+    if (rc >= 0) return;
+    const char *detail = c ? cwslg_last_error(c) : "";
+    std::string msg = (detail && *detail) ? detail : cwslg_strerror(rc);
+    // the reference throws std::invalid_argument for the three tuning errors (SSBD.hpp:54-59,100-103)
+    if (rc == CWSLG_ERR_RATIO || rc == CWSLG_ERR_BAND_LOW || rc == CWSLG_ERR_BAND_HIGH)
+        throw std::invalid_argument(cwslg_strerror(rc));
+    if (rc == CWSLG_ERR_MODE) throw std::runtime_error(msg);          // CWSL_DIGI.hpp:111
+    throw std::runtime_error("libcwslgpu: " + msg);
+}
+
+class Context {
+public:
+    explicit Context(int device = -1) { check(nullptr, cwslg_create(&c_, device)); }
+    ~Context() { cwslg_destroy(c_); }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    cwslg_ctx *raw() const { return c_; }
+    void setScaleFactors(float ft, float wspr) { check(c_, cwslg_set_scale_factors(c_, ft, wspr)); }
+    // SyncPredicate::store(true) for a whole group (CWSL_DIGI.cpp:247-251)
+    void slotBoundary(int group, std::uint64_t epoch_s) { check(c_, cwslg_slot_boundary(c_, group, epoch_s)); }
+    void process() { check(c_, cwslg_process(c_)); }
+    void synchronize() { check(c_, cwslg_synchronize(c_)); }
+private:
+    cwslg_ctx *c_ = nullptr;
+};
+
+// Receiver side: `memcpy(iq_buffer.recs[write_index], rawiq.data(), readSize); iq_buffer.inc_write_index();`
+// becomes `port.push(rawiq.data(), iq_len);`
+class ReceiverPort {
+public:
+    ReceiverPort(Context &ctx, std::uint32_t sampleRate, std::uint32_t blockInSamples, std::int32_t lo_hz,
+                 std::uint32_t ringBlocks = 0) : ctx_(ctx)
+    {
+        check(ctx_.raw(), cwslg_receiver_open(ctx_.raw(), sampleRate, blockInSamples, lo_hz, ringBlocks, &id_));
+    }
+    ~ReceiverPort() { cwslg_receiver_close(ctx_.raw(), id_); }
+    void push(const std::complex<float> *block, std::uint32_t n_complex)
+    {
+        check(ctx_.raw(), cwslg_push_iq(ctx_.raw(), id_, reinterpret_cast<const float *>(block), n_complex));
+    }
+    int id() const { return id_; }
+    Context &context() const { return ctx_; }
+private:
+    Context &ctx_;
+    int id_ = -1;
+};
+
+// SSBD<float>(Fs, B, F, isUSB) -> SsbChannel(port, F, isUSB, mode).  Fs comes from the port; B is SSB_BW.
+class SsbChannel {
+public:
+    SsbChannel(ReceiverPort &port, double F, bool isUSB, const std::string &mode) : ctx_(port.context())
+    {
+        check(ctx_.raw(), cwslg_channel_open(ctx_.raw(), port.id(), static_cast<std::int32_t>(F), isUSB ? 1 : 0,
+                                             mode.c_str(), &id_));
+        check(ctx_.raw(), cwslg_channel_info(ctx_.raw(), id_, &in_, &out_, &rate_, &delay_, &frame_));
+    }
+    ~SsbChannel() { cwslg_channel_close(ctx_.raw(), id_); }
+    std::size_t GetInSize() const { return in_; }       // SSBD.hpp:144
+    std::size_t GetOutSize() const { return out_; }     // :146
+    std::size_t GetOutRate() const { return rate_; }    // :142
+    std::size_t GetDelay() const { return delay_; }     // :154
+    std::size_t frameLength() const { return frame_; }  // Instance.cpp:149
+    int id() const { return id_; }
+
+    // What Instance.cpp:238-245 hands to DecoderPool::push: returns false while no frame is ready
+    // (first partial slot).  audio is resized to frameLength().
+    bool fetch(std::vector<std::int16_t> &audio, std::uint64_t &startEpoch)
+    {
+        audio.resize(frame_);
+        std::size_t nv = 0;
+        const int rc = cwslg_fetch_frame(ctx_.raw(), id_, audio.data(), audio.size(), &startEpoch, &nv, nullptr);
+        if (rc == CWSLG_ERR_NO_FRAME) return false;
+        check(ctx_.raw(), rc);
+        return true;
+    }
+    int candidates(std::vector<cwslg_candidate> &out, int max = 600)
+    {
+        out.resize(max);
+        int n = 0;
+        check(ctx_.raw(), cwslg_fetch_candidates(ctx_.raw(), id_, out.data(), max, &n));
+        out.resize(n);
+        return n;
+    }
+private:
+    Context &ctx_;
+    int id_ = -1;
+    std::uint32_t in_ = 0, out_ = 0, rate_ = 0, delay_ = 0;
+    std::size_t frame_ = 0;
+};
+
+} // namespace cwslgpu

@@ -1,0 +1,56 @@
+"""CPU, world_size 2, gloo: the N>1 path of bench.py -- slot sharding with no data-path collective and the
+slot-boundary rendezvous (4-byte all-reduce).  On GPUs the same code runs on the "nccl" (= RCCL) backend."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cwsl_digi_amd import shard
+    mine = list(shard.slots_of_rank(total, rank, world))
+    assert all(shard.rank_of_slot(s, total, world) == rank for s in mine)
+    got = []
+    for epoch in range(3):
+        frames = len(mine) if epoch else 0          # first boundary: every frame discarded
+        got.append(shard.slot_boundary_rendezvous(frames))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    q.put((rank, mine, got, gathered))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [4096, 1001, 1])
+def test_sharding_and_boundary_rendezvous(total):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    allslots = sorted(s for _, mine, _, _ in res for s in mine)
+    assert allslots == list(range(total))                      # every slot owned exactly once
+    for _, _, got, gathered in res:
+        assert got == [0, total, total]                        # rendezvous carries the frame count
+        assert sorted(s for part in gathered for s in part) == list(range(total))
+
+
+def test_single_process_rendezvous_is_identity():
+    from cwsl_digi_amd import shard
+    assert shard.slot_boundary_rendezvous(7) == 7
+    assert list(shard.slots_of_rank(10, 0, 1)) == list(range(10))
