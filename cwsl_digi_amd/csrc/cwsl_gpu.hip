@@ -460,7 +460,7 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s)
 
 } // namespace
 
-// sync stage glue (defined in sync_host.inc so this file stays readable)
+// sync stage glue (kept in its own file so this one stays readable)
 #include "sync_host.inc"
 
 // =============================================================================================

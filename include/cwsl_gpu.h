@@ -139,11 +139,16 @@ int cwslg_frame_device_ptrs(cwslg_ctx *ctx, int ch_id, const int16_t **d_i16, co
 int cwslg_enable_sync(cwslg_ctx *ctx, int enable, float syncmin, int max_cand, int f_lo_hz, int f_hi_hz);
 int cwslg_fetch_candidates(cwslg_ctx *ctx, int ch_id, cwslg_candidate *dst, int max, int *n);
 
+/* Intermediate products of the sync stage for parity tests: what = 0 symbol spectra [372][nbins] float,
+ * 1 red, 2 red2 (float[1921], before normalisation), 3 jpeak, 4 jpeak2 (int32[1921]).  *n_items = items available. */
+int cwslg_sync_debug_fetch(cwslg_ctx *ctx, int ch_id, int what, void *dst, size_t cap_bytes, size_t *n_items, int *row_len);
+
 /* ---- introspection for bench / tests ---- */
 typedef struct {
     uint64_t demod_launches;       /* demod kernel launches                                   */
     uint64_t demod_samples;        /* complex input samples consumed, summed over channels    */
     uint64_t finalize_launches;
+    uint64_t sync_launches;
     uint64_t frames_emitted;
     uint64_t frames_discarded;     /* startEpochTime == 0                                      */
     uint64_t blocks_dropped;       /* "af buffer full" events (Instance.cpp:268-271)           */

@@ -76,6 +76,9 @@ def lib():
         L.orc_synth_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _f32p]
         L.orc_synth_add_tones.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _f64p, C.c_int, C.c_float, _f32p]
         L.orc_checksum_f32.argtypes = [_f32p, C.c_size_t]; L.orc_checksum_f32.restype = C.c_double
+        L.orc_ft8_spectra.argtypes = [_i16p, _f32p, C.c_int]
+        L.orc_ft8_sync.argtypes = [_i16p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_bench_cpu.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint64]
         L.orc_bench_cpu.restype = C.c_double
         L.orc_crc32.argtypes = [C.c_void_p, C.c_size_t]; L.orc_crc32.restype = C.c_uint32
@@ -325,3 +328,33 @@ def crc32(a):
 def bench_cpu(threads, slots, fs=192000, iq_len=2048, n_per_slot=2880000):
     """Wall seconds for `threads` channels x `slots` FT8 slots on the host cores (reference shape)."""
     return float(lib().orc_bench_cpu(threads, slots, fs, iq_len, n_per_slot))
+
+
+class _Cand(C.Structure):
+    _fields_ = [("freq_bin", C.c_int32), ("time_step", C.c_int32), ("sync", C.c_float),
+                ("freq_hz", C.c_float), ("dt_s", C.c_float)]
+
+
+def ft8_spectra(frame_i16, nbins):
+    """PARITY UNPINNED (sync_oracle.h).  float32[372, nbins] symbol power spectra of an int16 frame."""
+    fr = np.ascontiguousarray(frame_i16, dtype=np.int16)
+    assert fr.shape[0] >= 180000
+    out = np.empty(372 * nbins, np.float32)
+    assert lib().orc_ft8_spectra(fr, out, nbins) == 0
+    return out.reshape(372, nbins)
+
+
+def ft8_sync(frame_i16, f_lo_hz=200, f_hi_hz=3000, syncmin=1.5, maxcand=200, want_arrays=False):
+    """PARITY UNPINNED.  -> list of (freq_bin, time_step, sync, freq_hz, dt_s) [, dict of red/jpeak arrays]."""
+    fr = np.ascontiguousarray(frame_i16, dtype=np.int16)
+    assert fr.shape[0] >= 180000
+    buf = (_Cand * maxcand)()
+    red = np.zeros(1921, np.float32); red2 = np.zeros(1921, np.float32)
+    jp = np.zeros(1921, np.int32); jp2 = np.zeros(1921, np.int32)
+    n = lib().orc_ft8_sync(fr, f_lo_hz, f_hi_hz, syncmin, maxcand, C.addressof(buf), maxcand,
+                           red.ctypes.data, jp.ctypes.data, red2.ctypes.data, jp2.ctypes.data)
+    assert n >= 0
+    cands = [(buf[k].freq_bin, buf[k].time_step, buf[k].sync, buf[k].freq_hz, buf[k].dt_s) for k in range(n)]
+    if want_arrays:
+        return cands, dict(red=red, red2=red2, jpeak=jp, jpeak2=jp2)
+    return cands

@@ -1,1 +1,241 @@
+/* sync_oracle.c -- TEST INFRASTRUCTURE ONLY; *** PARITY UNPINNED *** (see sync_oracle.h). */
 #include "sync_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NZ   1920              /* complex FFT length after real packing */
+#define NA   15
+#define NB   128
+
+static float w15r[NA], w15i[NA];           /* exp(-2 pi i k/15)   */
+static float w1920r[NZ], w1920i[NZ];       /* exp(-2 pi i k/1920) */
+static float w128r[NB / 2], w128i[NB / 2]; /* exp(-2 pi i k/128)  */
+static float w3840r[NZ + 1], w3840i[NZ + 1]; /* exp(-2 pi i k/3840), k = 0..1920 */
+static unsigned char rev7[NB];
+static int tables_ready = 0;
+
+static void make_tables(void)
+{
+    const double pi = 3.14159265358979323846;
+    for (int k = 0; k < NA; ++k) { w15r[k] = (float)cos(2.0 * pi * k / 15.0); w15i[k] = (float)(-sin(2.0 * pi * k / 15.0)); }
+    for (int k = 0; k < NZ; ++k) { w1920r[k] = (float)cos(2.0 * pi * k / 1920.0); w1920i[k] = (float)(-sin(2.0 * pi * k / 1920.0)); }
+    for (int k = 0; k < NB / 2; ++k) { w128r[k] = (float)cos(2.0 * pi * k / 128.0); w128i[k] = (float)(-sin(2.0 * pi * k / 128.0)); }
+    for (int k = 0; k <= NZ; ++k) { w3840r[k] = (float)cos(2.0 * pi * k / 3840.0); w3840i[k] = (float)(-sin(2.0 * pi * k / 3840.0)); }
+    for (int b = 0; b < NB; ++b) {
+        int r = 0;
+        for (int t = 0; t < 7; ++t) if (b & (1 << t)) r |= 1 << (6 - t);
+        rev7[b] = (unsigned char)r;
+    }
+    tables_ready = 1;
+}
+
+/* One symbol spectrum: x[0..1920) real, zero padded to 3840; pw[k] = |X[k]|^2 for k in [0,nbins). */
+static void spectrum_3840(const float *x, float *pw, int nbins)
+{
+    static float yr[NA][NB], yi[NA][NB];
+    /* pack: z[m] = x[2m] + i x[2m+1], m < 960 (zero above); m = 128 a + b */
+    /* stage 1: 15-point DFT over a (only a <= 7 can be non-zero), then twiddle W1920^(b*c), stored bit-reversed in b */
+    for (int b = 0; b < NB; ++b) {
+        for (int c = 0; c < NA; ++c) {
+            float ar = x[2 * b], ai = x[2 * b + 1];                    /* a = 0 term, W^0 */
+            for (int a = 1; a < 8; ++a) {
+                const int m = NB * a + b;
+                if (m >= 960) break;
+                const float zr = x[2 * m], zi = x[2 * m + 1];
+                const float wr = w15r[(a * c) % NA], wi = w15i[(a * c) % NA];
+                const float pr = zr * wr - zi * wi;
+                const float pi_ = zr * wi + zi * wr;
+                ar = ar + pr;
+                ai = ai + pi_;
+            }
+            const float tr = w1920r[b * c], ti = w1920i[b * c];
+            const float qr = ar * tr - ai * ti;
+            const float qi = ar * ti + ai * tr;
+            yr[c][rev7[b]] = qr;
+            yi[c][rev7[b]] = qi;
+        }
+    }
+    /* stage 2: 15 radix-2 DIT FFTs of 128 points (input bit-reversed, output natural): Z[c + 15 d] = y[c][d] */
+    for (int c = 0; c < NA; ++c) {
+        for (int len = 2; len <= NB; len <<= 1) {
+            const int half = len >> 1, step = NB / len;
+            for (int base = 0; base < NB; base += len) {
+                for (int k = 0; k < half; ++k) {
+                    const float wr = w128r[k * step], wi = w128i[k * step];
+                    const float ur = yr[c][base + k], ui = yi[c][base + k];
+                    const float vr = yr[c][base + k + half], vi = yi[c][base + k + half];
+                    const float tr = vr * wr - vi * wi;
+                    const float ti = vr * wi + vi * wr;
+                    yr[c][base + k] = ur + tr;        yi[c][base + k] = ui + ti;
+                    yr[c][base + k + half] = ur - tr; yi[c][base + k + half] = ui - ti;
+                }
+            }
+        }
+    }
+    /* stage 3: unpack the real-input transform: X[k], k = 0..1920 */
+    for (int k = 0; k < nbins; ++k) {
+        const int k2 = (NZ - k) % NZ;
+        const int kk = k % NZ;
+        const float ar = yr[kk % NA][kk / NA], ai = yi[kk % NA][kk / NA];
+        const float br = yr[k2 % NA][k2 / NA], bi = -yi[k2 % NA][k2 / NA];   /* conj(Z[N-k]) */
+        const float er = (ar + br) * 0.5f, ei = (ai + bi) * 0.5f;
+        const float orr = (ar - br) * 0.5f, oi = (ai - bi) * 0.5f;
+        const float wr = w3840r[k], wi = w3840i[k];
+        const float tr = orr * wr - oi * wi;
+        const float ti = orr * wi + oi * wr;
+        const float xr = er + ti;            /* E + (-i) T */
+        const float xi = ei - tr;
+        pw[k] = xr * xr + xi * xi;
+    }
+}
+
+int orc_ft8_spectra(const int16_t *frame, float *s_out, int nbins)
+{
+    if (!tables_ready) make_tables();
+    if (nbins < 1 || nbins > FT8_NH1 + 1) return -1;
+    float x[FT8_NSPS];
+    const float fac = 1.0f / 300.0f;
+    for (int j = 0; j < FT8_NHSYM; ++j) {
+        const int16_t *d = frame + (size_t)FT8_NSTEP * j;
+        for (int n = 0; n < FT8_NSPS; ++n) x[n] = fac * (float)d[n];
+        spectrum_3840(x, s_out + (size_t)j * nbins, nbins);
+    }
+    return 0;
+}
+
+typedef struct { float v; int idx; } keyed_t;
+static int cmp_keyed(const void *a, const void *b)
+{
+    const keyed_t *x = (const keyed_t *)a, *y = (const keyed_t *)b;
+    if (x->v < y->v) return -1;
+    if (x->v > y->v) return 1;
+    return (x->idx > y->idx) - (x->idx < y->idx);         /* ties: ascending index (total order) */
+}
+
+static const int icos7[7] = {3, 1, 4, 0, 6, 5, 2};
+
+int orc_ft8_sync(const int16_t *frame, int nfa_hz, int nfb_hz, float syncmin, int maxcand,
+                 orc_candidate_t *out, int max_out,
+                 float *red_o, int32_t *jpeak_o, float *red2_o, int32_t *jpeak2_o)
+{
+    const float df = 12000.0f / FT8_NFFT1;              /* 3.125 */
+    const float tstep = FT8_NSTEP / 12000.0f;           /* 0.04  */
+    int ia = (int)lroundf((float)nfa_hz / df); if (ia < 1) ia = 1;
+    int ib = (int)lroundf((float)nfb_hz / df);
+    if (ib + 12 > FT8_NH1) ib = FT8_NH1 - 12;
+    if (ib < ia) return 0;
+    const int nbins = ib + 13;                           /* bins 0 .. ib+12 */
+    float *s = (float *)malloc(sizeof(float) * (size_t)nbins * FT8_NHSYM);
+    if (!s || orc_ft8_spectra(frame, s, nbins)) { free(s); return -1; }
+#define S(i, m) s[(size_t)((m) - 1) * nbins + (i)]       /* 1-based symbol-step index m, bin i */
+    const int nssy = 4, nfos = 2, jstrt = 12;            /* NSPS/NSTEP, NFFT1/NSPS, 0.5/tstep */
+    const int iz = ib - ia + 1;
+    float *red = (float *)calloc(FT8_NH1 + 1, sizeof(float));
+    float *red2 = (float *)calloc(FT8_NH1 + 1, sizeof(float));
+    int *jpeak = (int *)calloc(FT8_NH1 + 1, sizeof(int));
+    int *jpeak2 = (int *)calloc(FT8_NH1 + 1, sizeof(int));
+    for (int i = ia; i <= ib; ++i) {
+        float best = 0, best2 = 0; int jb = 0, jb2 = 0; int first = 1, first2 = 1;
+        for (int j = -FT8_JZ; j <= FT8_JZ; ++j) {
+            float ta = 0, tb = 0, tc = 0, t0a = 0, t0b = 0, t0c = 0;
+            for (int n = 0; n < 7; ++n) {
+                const int m = j + jstrt + nssy * n;
+                if (m >= 1 && m <= FT8_NHSYM) {
+                    ta = ta + S(i + nfos * icos7[n], m);
+                    float c0 = 0; for (int k = 0; k < 7; ++k) c0 = c0 + S(i + nfos * k, m);
+                    t0a = t0a + c0;
+                }
+                {
+                    const int mb = m + nssy * 36;
+                    tb = tb + S(i + nfos * icos7[n], mb);
+                    float c0 = 0; for (int k = 0; k < 7; ++k) c0 = c0 + S(i + nfos * k, mb);
+                    t0b = t0b + c0;
+                }
+                if (m + nssy * 72 <= FT8_NHSYM) {
+                    const int mc = m + nssy * 72;
+                    tc = tc + S(i + nfos * icos7[n], mc);
+                    float c0 = 0; for (int k = 0; k < 7; ++k) c0 = c0 + S(i + nfos * k, mc);
+                    t0c = t0c + c0;
+                }
+            }
+            float t = ta + tb + tc;
+            float t0 = t0a + t0b + t0c;
+            t0 = (t0 - t) / 6.0f;
+            const float sync_abc = t / t0;
+            t = tb + tc;
+            t0 = t0b + t0c;
+            t0 = (t0 - t) / 6.0f;
+            const float sync_bc = t / t0;
+            float sy = (sync_abc > sync_bc) ? sync_abc : sync_bc;           /* max() */
+            if (!(sy == sy)) sy = 0.0f;                                     /* 0/0 on all-zero windows: defined as 0 here */
+            if (j >= -10 && j <= 10 && (first || sy > best)) { best = sy; jb = j; first = 0; }   /* maxloc: first maximum */
+            if (first2 || sy > best2) { best2 = sy; jb2 = j; first2 = 0; }
+        }
+        red[i] = best; jpeak[i] = jb; red2[i] = best2; jpeak2[i] = jb2;
+    }
+#undef S
+    free(s);
+    if (red_o) memcpy(red_o, red, sizeof(float) * (FT8_NH1 + 1));
+    if (red2_o) memcpy(red2_o, red2, sizeof(float) * (FT8_NH1 + 1));
+    if (jpeak_o) for (int i = 0; i <= FT8_NH1; ++i) jpeak_o[i] = jpeak[i];
+    if (jpeak2_o) for (int i = 0; i <= FT8_NH1; ++i) jpeak2_o[i] = jpeak2[i];
+
+    /* 40th-percentile normalisation (indexx -> ascending order; ties by bin) */
+    keyed_t *ord = (keyed_t *)malloc(sizeof(keyed_t) * (size_t)iz);
+    keyed_t *ord2 = (keyed_t *)malloc(sizeof(keyed_t) * (size_t)iz);
+    for (int k = 0; k < iz; ++k) { ord[k].v = red[ia + k]; ord[k].idx = ia + k; ord2[k].v = red2[ia + k]; ord2[k].idx = ia + k; }
+    qsort(ord, (size_t)iz, sizeof(keyed_t), cmp_keyed);
+    qsort(ord2, (size_t)iz, sizeof(keyed_t), cmp_keyed);
+    int npct = (int)lroundf(0.40f * (float)iz);
+    int ncand = 0;
+    orc_candidate_t *c0 = (orc_candidate_t *)calloc((size_t)(2 * maxcand + 2), sizeof(orc_candidate_t));
+    if (npct >= 1) {
+        const float base = red[ord[npct - 1].idx];
+        const float base2 = red2[ord2[npct - 1].idx];
+        for (int i = ia; i <= ib; ++i) { red[i] = red[i] / base; red2[i] = red2[i] / base2; }
+        const int lim = (maxcand < iz) ? maxcand : iz;
+        for (int r = 1; r <= lim; ++r) {
+            const int n = ord[iz - r].idx;                /* descending red (order fixed before normalisation) */
+            if (ncand >= maxcand) break;
+            if (red[n] >= syncmin && !isnan(red[n])) {
+                c0[ncand].freq_bin = n; c0[ncand].time_step = jpeak[n]; c0[ncand].sync = red[n]; ncand++;
+            }
+            if (jpeak2[n] == jpeak[n]) continue;
+            if (ncand >= maxcand) break;
+            if (red2[n] >= syncmin && !isnan(red2[n])) {
+                c0[ncand].freq_bin = n; c0[ncand].time_step = jpeak2[n]; c0[ncand].sync = red2[n]; ncand++;
+            }
+        }
+    }
+    /* near-dupe suppression: |df| < 4 Hz and |dt| < 0.04 s -> keep the stronger (sequential, in place) */
+    for (int i = 0; i < ncand; ++i) { c0[i].freq_hz = (float)c0[i].freq_bin * df; c0[i].dt_s = ((float)c0[i].time_step - 0.5f) * tstep; }
+    for (int i = 1; i < ncand; ++i) {
+        for (int j = 0; j < i; ++j) {
+            const float fdiff = fabsf(c0[i].freq_hz) - fabsf(c0[j].freq_hz);
+            const float tdiff = fabsf(c0[i].dt_s - c0[j].dt_s);
+            if (fabsf(fdiff) < 4.0f && tdiff < 0.04f) {
+                if (c0[i].sync >= c0[j].sync) c0[j].sync = 0.0f;
+                if (c0[i].sync < c0[j].sync) c0[i].sync = 0.0f;
+            }
+        }
+    }
+    /* final list: descending sync, ties by ascending bin then lag; survivors only */
+    int nout = 0;
+    for (int pass = 0; pass < ncand && nout < max_out && nout < maxcand; ++pass) {
+        int bi = -1;
+        for (int i = 0; i < ncand; ++i) {
+            if (!(c0[i].sync >= syncmin)) continue;
+            if (bi < 0) { bi = i; continue; }
+            const orc_candidate_t *a = &c0[i], *b = &c0[bi];
+            if (a->sync > b->sync || (a->sync == b->sync && (a->freq_bin < b->freq_bin ||
+                (a->freq_bin == b->freq_bin && a->time_step < b->time_step)))) bi = i;
+        }
+        if (bi < 0) break;
+        out[nout++] = c0[bi];
+        c0[bi].sync = -1.0f;
+    }
+    free(ord); free(ord2); free(c0); free(red); free(red2); free(jpeak); free(jpeak2);
+    return nout;
+}

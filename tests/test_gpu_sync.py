@@ -1,0 +1,97 @@
+"""GPU: FT8 sync stage through the C ABI vs the repository's CPU restatement (oracle/sync_oracle.c).
+PARITY UNPINNED by the reference (it has no sync code); against the restatement everything is BIT-EXACT:
+symbol spectra, per-bin peaks and lags, and the final candidate list."""
+import numpy as np
+import pytest
+
+from ft8_signal import ft8_iq
+
+pytestmark = pytest.mark.gpu
+FS, BLK = 192000, 2048
+
+
+def _run(ctx, oracle, f, specs, seed, maxcand=200, syncmin=1.5, lo=200, hi=3000, n_iq=None):
+    n = n_iq or (2880000 // BLK * BLK)
+    rng = np.random.default_rng(seed)
+    iq = oracle.synth_iq(seed, n, FS)
+    for audio_hz, t0, amp in specs:
+        iq = iq + ft8_iq(FS, n, f, audio_hz, t0, amp, rng)
+    iq = iq.astype(np.complex64)
+    ctx.enable_sync(True, syncmin, maxcand, lo, hi)
+    rx = ctx.receiver_open(FS, BLK, 0)
+    ch = ctx.channel_open(rx, f, "FT8")
+    ctx.slot_boundary("FT8", 1)
+    for k in range(0, n, 128 * BLK):
+        ctx.push_iq(rx, iq[k:k + 128 * BLK])
+    ctx.slot_boundary("FT8", 16)
+    fr = ctx.fetch_frame(ch)["i16"]
+    return ch, fr
+
+
+def test_sync_bit_exact_vs_restatement(ctx, oracle):
+    specs = [(700.0, 0.5, 3000.0), (1531.25, 1.3, 2000.0), (2400.0, 0.1, 1500.0), (2403.0, 0.12, 900.0)]
+    ch, fr = _run(ctx, oracle, 10000, specs, 5)
+    # the stage runs on the GPU's own int16 frame; feed the SAME frame to the restatement
+    cands_ref, arr = oracle.ft8_sync(fr, 200, 3000, 1.5, 200, want_arrays=True)
+    s_gpu = ctx.sync_debug(ch, "spectra")
+    s_ref = oracle.ft8_spectra(fr, s_gpu.shape[1])
+    assert np.array_equal(s_gpu.view(np.uint32), s_ref.view(np.uint32))
+    ia, ib = 64, 960
+    for name in ("red", "red2"):
+        g = ctx.sync_debug(ch, name)
+        assert np.array_equal(g[ia:ib + 1].view(np.uint32), arr[name][ia:ib + 1].view(np.uint32)), name
+    for name in ("jpeak", "jpeak2"):
+        assert np.array_equal(ctx.sync_debug(ch, name)[ia:ib + 1], arr[name][ia:ib + 1]), name
+    cands = ctx.fetch_candidates(ch, 200)
+    assert len(cands) == len(cands_ref) >= 3
+    for a, b in zip(cands, cands_ref):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert np.float32(a[2]).view(np.uint32) == np.float32(b[2]).view(np.uint32)
+        assert np.float32(a[3]) == np.float32(b[3]) and np.float32(a[4]) == np.float32(b[4])
+
+
+@pytest.mark.parametrize("maxcand,syncmin,lo,hi", [(600, 1.2, 100, 4000), (10, 1.5, 200, 3000), (50, 2.0, 500, 2500)])
+def test_sync_parameter_sweep(ctx, oracle, maxcand, syncmin, lo, hi):
+    specs = [(800.0 + 37 * k, 0.2 + 0.11 * k, 2500.0 - 150 * k) for k in range(9)]
+    ch, fr = _run(ctx, oracle, -30000, specs, 11, maxcand, syncmin, lo, hi)
+    ref = oracle.ft8_sync(fr, lo, hi, syncmin, maxcand)
+    got = ctx.fetch_candidates(ch, 600)
+    assert [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in got] == \
+           [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in ref]
+    assert len(got) <= maxcand
+
+
+def test_sync_short_frame_zero_tail(ctx, oracle):
+    """A slot that ended early: the zero tail gives all-zero symbol windows (0/0 defined as 0 in both)."""
+    specs = [(1200.0, 0.5, 3000.0)]
+    ch, fr = _run(ctx, oracle, 5000, specs, 3, n_iq=900 * BLK)
+    ref = oracle.ft8_sync(fr, 200, 3000, 1.5, 200)
+    got = ctx.fetch_candidates(ch, 200)
+    assert [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in got] == \
+           [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in ref]
+
+
+def test_sync_many_channels_one_launch(ctx, oracle):
+    """16 FT8 channels + 2 FT4 channels (no FT8 sync for those) finalised by one boundary."""
+    n = 2880000 // BLK * BLK
+    rng = np.random.default_rng(2)
+    freqs = [-80000 + 9000 * k for k in range(16)]
+    iq = oracle.synth_iq(99, n, FS)
+    for k, f in enumerate(freqs):
+        iq = iq + ft8_iq(FS, n, f, 500.0 + 140 * k, 0.3 + 0.05 * k, 2500.0, rng)
+    iq = iq.astype(np.complex64)
+    ctx.enable_sync(True, 1.5, 100, 200, 3000)
+    rx = ctx.receiver_open(FS, BLK, 0)
+    chans = [ctx.channel_open(rx, f, "FT8") for f in freqs]
+    ctx.slot_boundary("FT8", 1)
+    for k in range(0, n, 128 * BLK):
+        ctx.push_iq(rx, iq[k:k + 128 * BLK])
+    ctx.slot_boundary("FT8", 16)
+    for k, ch in enumerate(chans):
+        fr = ctx.fetch_frame(ch)["i16"]
+        ref = oracle.ft8_sync(fr, 200, 3000, 1.5, 100)
+        got = ctx.fetch_candidates(ch, 100)
+        assert [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in got] == \
+               [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in ref]
+        want_bin = int(round((500.0 + 140 * k) / 3.125))
+        assert any(abs(c[0] - want_bin) <= 1 for c in got)
