@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--slots", type=int, default=512, help="FT8 slots per GPU")
+    ap.add_argument("--sync", type=int, default=1, help="run the FT8 sync stage (symbol spectra + Costas search) at every boundary")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
     ap.add_argument("--verify", type=int, default=1, help="slots checked against the oracle after the timed region")
@@ -82,6 +83,8 @@ def main():
 
     S = args.slots
     ctx = P.Context(local_rank)
+    if args.sync:
+        ctx.enable_sync(True, 1.5, 200, 200, 3000)    # jt9 -8 defaults used by the reference: syncmin 1.5, 200..3000 Hz (-H highestdecodefreq)
     ring_blocks = SLOT_SAMPLES // IQ_LEN + 2 + (SLOT_SAMPLES % IQ_LEN != 0)
     cap = ring_blocks * IQ_LEN
     chans, rxs, freqs = [], [], []
@@ -202,7 +205,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{S} FT8 slots/GPU x 15 s (2.88 M IQ samples) at 192 kHz, private IQ stream per slot "
                                    f"(BASELINE configs[3] share 4096/8=512 per GPU; same kernel as configs[1]'s 64 slots)",
-                       "slots_per_gpu": S, "fs_hz": FS, "iq_block": IQ_LEN, "stages": "nco-mix+polyphase-decimate, peak-normalise+int16",
+                       "slots_per_gpu": S, "fs_hz": FS, "iq_block": IQ_LEN, "stages": "nco-mix+polyphase-decimate, peak-normalise+int16" + (", ft8 symbol-spectra+costas-sync+candidates" if args.sync else ""),
                        "sharding": f"slots x{world}, RCCL 4-byte all-reduce per slot boundary" if world > 1 else "single GPU"},
             "realtime_ft8_slots": msps / 0.192,
             "roofline": {"bound": "hbm", "kernel": "demod_kernel<16,256,256>", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -210,6 +213,7 @@ def main():
                          "bytes_per_sample": BYTES_PER_SAMPLE_DEMOD, "samples_per_launch": samples_per_launch,
                          "avg_launch_ms": avg_ms, "launches": st["demod_launches"],
                          "finalize_avg_ms": st["finalize_ms"] / max(1, st["finalize_launches"]),
+                         "sync_avg_ms": st["sync_ms"] / max(1, st["sync_launches"]),
                          "whole_path_frac": BYTES_PER_SAMPLE_PATH * samples_per_launch * args.steps / dt / 1e9 / HBM_PEAK_GBS},
             "cpu_baseline": cpu,
             "verify": verify,

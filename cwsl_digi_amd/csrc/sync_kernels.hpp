@@ -28,6 +28,7 @@ namespace cwslg {
 constexpr int FT8_NSPS = 1920, FT8_NSTEP = 480, FT8_NHSYM = 372, FT8_NH1 = 1920, FT8_JZ = 62, FT8_NMAX = 180000;
 constexpr int SYNC_BAND = 32;           // bins per sync2d workgroup
 constexpr int SYNC_MAXCAND_CAP = 600;   // MAXCAND of the upstream decoder
+constexpr int SYNC_MAXPRE = 1000;       // MAXPRECAND of sync8.f90: pre-candidates before de-duplication
 
 struct SyncConfig {
     bool enabled = false;
@@ -83,61 +84,145 @@ __device__ __forceinline__ float2 cmul_u(float2 a, float2 b)          // un-fuse
 }
 
 // ---------------------------------------------------------------------------------------------
-// grid (NHSYM, n_channels), 256 threads.
+// Symbol spectra.  grid (NHSYM, n_channels), 256 threads.
+//
+// The transform is DEFINED as: pack z[m] = x[2m] + i x[2m+1] (m < 960, zero above), 1920 = 15 x 128:
+// 15-point DFTs over a (m = 128a + b) -> twiddle W1920^(bc) -> 15 radix-2 DIT FFTs of 128 points (bit-reversed
+// input) -> real-input unpack with W3840^k.  Any schedule that evaluates the same butterflies gives the same
+// bits; here each lane does 8-point groups (three radix-2 stages) in registers per LDS pass.
+template <int CH>
+__device__ __forceinline__ void spectra_stage1(const float *s_x, float2 (*s_y)[128], const float2 *s_w15,
+                                               const float2 *__restrict__ w1920, int b)
+{
+    float2 z[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const int m = 128 * a + b;
+        z[a] = (m < 960) ? make_float2(s_x[2 * m], s_x[2 * m + 1]) : make_float2(0.f, 0.f);
+    }
+    const bool a7 = (128 * 7 + b) < 960;
+    const int rb = (int)(__brev((unsigned)b) >> 25);
+    float2 tw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = CH + 2 * i;
+        tw[i] = (c < 15) ? w1920[b * c] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = CH + 2 * i;
+        if (c < 15) {
+            float2 acc = z[0];
+#pragma unroll
+            for (int a = 1; a < 7; ++a) {
+                const float2 p = cmul_u(z[a], s_w15[(a * c) % 15]);
+                acc.x = acc.x + p.x;
+                acc.y = acc.y + p.y;
+            }
+            if (a7) {
+                const float2 p = cmul_u(z[7], s_w15[(7 * c) % 15]);
+                acc.x = acc.x + p.x;
+                acc.y = acc.y + p.y;
+            }
+            s_y[c][rb] = cmul_u(acc, tw[i]);
+        }
+    }
+}
+
+// radix-2 DIT butterfly on two registers: (u, v) -> (u + w v, u - w v), un-fused
+__device__ __forceinline__ void bfly(float2 &u, float2 &v, float2 w)
+{
+    const float2 t = cmul_u(v, w);
+    const float2 a = make_float2(u.x + t.x, u.y + t.y);
+    const float2 d = make_float2(u.x - t.x, u.y - t.y);
+    u = a;
+    v = d;
+}
+
 __global__ __launch_bounds__(256) void ft8_spectra_kernel(const SyncWork *__restrict__ works, SyncTables tb, int nbins)
 {
     __shared__ float s_x[FT8_NSPS];
     __shared__ float2 s_y[15][128];
+    __shared__ float2 s_w15[16];
+    __shared__ float2 s_w128[64];
     const SyncWork *w = works + blockIdx.y;
     const int j = blockIdx.x;
     const int tid = threadIdx.x;
     const int16_t *d = w->frame + (size_t)FT8_NSTEP * j;
     const float fac = 1.0f / 300.0f;
-    for (int n = tid; n < FT8_NSPS; n += 256) s_x[n] = fac * (float)d[n];
-    __syncthreads();
-
-    // stage 1: 15-point DFT over a (z[128a+b], a<=7 non-zero), twiddle W1920^(bc), store bit-reversed in b
-    {
-        const int b = tid & 127;
-        const int chalf = __builtin_amdgcn_readfirstlane(tid >> 7);     // wave-uniform: waves 0,1 -> 0 ; 2,3 -> 1
-        float2 z[8];
+    {   // 1920 int16 = 240 x 16 B
+        if (tid < 240) {
+            const uint4 q = reinterpret_cast<const uint4 *>(d)[tid];
+            const unsigned v[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-        for (int a = 0; a < 8; ++a) {
-            const int m = 128 * a + b;
-            z[a] = (m < 960) ? make_float2(s_x[2 * m], s_x[2 * m + 1]) : make_float2(0.f, 0.f);
-        }
-        const int rb = (int)(__brev((unsigned)b) >> 25);
-        for (int c = chalf; c < 15; c += 2) {
-            float2 acc = z[0];
-#pragma unroll
-            for (int a = 1; a < 8; ++a) {
-                const int m = 128 * a + b;
-                if (m < 960) {
-                    const float2 p = cmul_u(z[a], tb.w15[(a * c) % 15]);
-                    acc.x = acc.x + p.x;
-                    acc.y = acc.y + p.y;
-                }
+            for (int k = 0; k < 4; ++k) {
+                s_x[8 * tid + 2 * k] = fac * (float)(short)(v[k] & 0xFFFFu);
+                s_x[8 * tid + 2 * k + 1] = fac * (float)(short)(v[k] >> 16);
             }
-            s_y[c][rb] = cmul_u(acc, tb.w1920[b * c]);
         }
+        if (tid < 15) s_w15[tid] = tb.w15[tid];
+        if (tid >= 64 && tid < 128) s_w128[tid - 64] = tb.w128[tid - 64];
     }
     __syncthreads();
 
-    // stage 2: 15 radix-2 DIT FFTs of 128 points, 960 butterflies per stage
-#pragma unroll 1
-    for (int len = 2; len <= 128; len <<= 1) {
-        const int half = len >> 1, step = 128 / len;
-        for (int idx = tid; idx < 960; idx += 256) {
-            const int c = idx >> 6, q = idx & 63;
-            const int k = q & (half - 1);
-            const int i0 = ((q / half) * len) + k, i1 = i0 + half;
-            const float2 u = s_y[c][i0], v = s_y[c][i1];
-            const float2 t = cmul_u(v, tb.w128[k * step]);
-            s_y[c][i0] = make_float2(u.x + t.x, u.y + t.y);
-            s_y[c][i1] = make_float2(u.x - t.x, u.y - t.y);
-        }
-        __syncthreads();
+    // stage 1 (wave-uniform split of the 15 outputs c: even c on waves 0-1, odd c on waves 2-3)
+    if (tid < 128) spectra_stage1<0>(s_x, s_y, s_w15, tb.w1920, tid & 127);
+    else spectra_stage1<1>(s_x, s_y, s_w15, tb.w1920, tid & 127);
+    __syncthreads();
+
+    // stage 2, pass A: DIT stages len = 2,4,8 on 8 consecutive points; 15 x 16 = 240 groups
+    if (tid < 240) {
+        const int c = tid >> 4, g = tid & 15;
+        float2 *row = &s_y[c][8 * g];
+        float2 e[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = row[k];
+        // len 2: pairs (0,1)(2,3)(4,5)(6,7), twiddle W128^0
+        bfly(e[0], e[1], s_w128[0]); bfly(e[2], e[3], s_w128[0]); bfly(e[4], e[5], s_w128[0]); bfly(e[6], e[7], s_w128[0]);
+        // len 4: pairs (0,2)(1,3)(4,6)(5,7), twiddles W128^(k*32)
+        bfly(e[0], e[2], s_w128[0]); bfly(e[1], e[3], s_w128[32]); bfly(e[4], e[6], s_w128[0]); bfly(e[5], e[7], s_w128[32]);
+        // len 8: pairs (k, k+4), twiddles W128^(k*16)
+        bfly(e[0], e[4], s_w128[0]); bfly(e[1], e[5], s_w128[16]); bfly(e[2], e[6], s_w128[32]); bfly(e[3], e[7], s_w128[48]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) row[k] = e[k];
     }
+    __syncthreads();
+    // pass B: stages len = 16,32,64 on points {r + 8 q : q<8} within each 64-block; groups: 15 x 2 blocks x 8 r
+    if (tid < 240) {
+        const int c = tid >> 4, g = tid & 15;
+        const int blk = g >> 3, r = g & 7;
+        float2 *row = &s_y[c][64 * blk + r];
+        float2 e[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) e[q] = row[8 * q];
+        // len 16: index i = r + 8q, pairs differ in q bit0: k = i mod 8 = r, twiddle W128^(r*8)
+        {
+            const float2 w0 = s_w128[r * 8];
+            bfly(e[0], e[1], w0); bfly(e[2], e[3], w0); bfly(e[4], e[5], w0); bfly(e[6], e[7], w0);
+        }
+        // len 32: pairs differ in q bit1: k = i mod 16 = r + 8*(q&1), twiddle W128^(k*4)
+        {
+            const float2 w0 = s_w128[r * 4], w1 = s_w128[(r + 8) * 4];
+            bfly(e[0], e[2], w0); bfly(e[1], e[3], w1); bfly(e[4], e[6], w0); bfly(e[5], e[7], w1);
+        }
+        // len 64: pairs differ in q bit2: k = i mod 32 = r + 8*(q&3), twiddle W128^(k*2)
+        {
+            bfly(e[0], e[4], s_w128[r * 2]); bfly(e[1], e[5], s_w128[(r + 8) * 2]);
+            bfly(e[2], e[6], s_w128[(r + 16) * 2]); bfly(e[3], e[7], s_w128[(r + 24) * 2]);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) row[8 * q] = e[q];
+    }
+    __syncthreads();
+    // pass C: stage len = 128: pairs (k, k+64), twiddle W128^k ; 960 butterflies
+    for (int idx = tid; idx < 960; idx += 256) {
+        const int c = idx >> 6, k = idx & 63;
+        float2 u = s_y[c][k], v = s_y[c][k + 64];
+        bfly(u, v, s_w128[k]);
+        s_y[c][k] = u;
+        s_y[c][k + 64] = v;
+    }
+    __syncthreads();
 
     // stage 3: unpack the real-input transform, power spectrum
     float *out = w->spectra + (size_t)j * nbins;
@@ -159,94 +244,140 @@ __global__ __launch_bounds__(256) void ft8_spectra_kernel(const SyncWork *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// grid (ceil((ib-ia+1)/32), n_channels), 256 threads.  LDS: band rows [44][376] + 7-tone sums [32][376].
+// Costas correlation + lag peak search.  grid (ceil((ib-ia+1)/32), n_channels), 256 threads.
+// LDS: the band's 44 spectrum rows [44][376] (66 KB) + per-bin 7-tone sums for the 2 bins in flight => 2 WG/CU.
+// Per bin: a wave pair, lane = lag (125 lags), 42 conflict-free LDS reads per lane; the +-10 and +-62 peak
+// searches are wavefront arg-max reductions on an order-preserving 64-bit key (value, -lag).
+__device__ __forceinline__ unsigned long long sync_key(float v, int l)
+{
+    unsigned u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);              // total order of floats as unsigned
+    return ((unsigned long long)u << 32) | (unsigned)(255 - l);  // ties: the smaller lag wins (maxloc: first maximum)
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long k)
+{
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)k, (int)(unsigned)k, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(k >> 32), (int)(unsigned)(k >> 32), CTRL, 0xf, 0xf, false);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+// wavefront max of a 64-bit key; every lane ends with the maximum.  DPP inside the 16-lane rows
+// (quad xor 1, quad xor 2, half-row mirror, row mirror), ds_bpermute across rows.
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
+{
+    unsigned long long o;
+    o = dpp_u64<0xB1>(k); k = (o > k) ? o : k;      // quad_perm [1,0,3,2]
+    o = dpp_u64<0x4E>(k); k = (o > k) ? o : k;      // quad_perm [2,3,0,1]
+    o = dpp_u64<0x141>(k); k = (o > k) ? o : k;     // row_half_mirror
+    o = dpp_u64<0x140>(k); k = (o > k) ? o : k;     // row_mirror
+#pragma unroll
+    for (int msk = 16; msk <= 32; msk <<= 1) {
+        const unsigned lo = __shfl_xor((unsigned)k, msk, 64);
+        const unsigned hi = __shfl_xor((unsigned)(k >> 32), msk, 64);
+        o = ((unsigned long long)hi << 32) | lo;
+        k = (o > k) ? o : k;
+    }
+    return k;
+}
+__device__ __forceinline__ float key_value(unsigned long long k)
+{
+    unsigned u = (unsigned)(k >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+    return __uint_as_float(u);
+}
+
+// sync2d(i, j) for one bin (band row rr) and one lag; s_c0 holds the bin's 7-tone sums.
+__device__ __forceinline__ float costas_sync(const float (*s_s)[376], const float *s_c0, int rr, int j)
+{
+    const int icos[7] = {3, 1, 4, 0, 6, 5, 2};
+    float ta = 0, tbv = 0, tc = 0, t0a = 0, t0b = 0, t0c = 0;
+#pragma unroll
+    for (int n = 0; n < 7; ++n) {
+        const int m = j + 12 + 4 * n;                  // 1-based symbol-step index
+        const int row = rr + 2 * icos[n];
+        if (m >= 1 && m <= FT8_NHSYM) { ta = ta + s_s[row][m - 1]; t0a = t0a + s_c0[m - 1]; }
+        { const int mb = m + 144; tbv = tbv + s_s[row][mb - 1]; t0b = t0b + s_c0[mb - 1]; }
+        if (m + 288 <= FT8_NHSYM) { const int mc = m + 288; tc = tc + s_s[row][mc - 1]; t0c = t0c + s_c0[mc - 1]; }
+    }
+    float t = ta + tbv + tc;
+    float t0 = t0a + t0b + t0c;
+    t0 = (t0 - t) / 6.0f;
+    const float sync_abc = t / t0;
+    t = tbv + tc;
+    t0 = t0b + t0c;
+    t0 = (t0 - t) / 6.0f;
+    const float sync_bc = t / t0;
+    float sy = (sync_abc > sync_bc) ? sync_abc : sync_bc;
+    if (!(sy == sy)) sy = 0.0f;                        // 0/0 on all-zero windows: defined as 0 (as the oracle)
+    return sy;
+}
+
 __global__ __launch_bounds__(256) void ft8_sync2d_kernel(const SyncWork *__restrict__ works, int ia, int ib, int nbins)
 {
     constexpr int ROWS = SYNC_BAND + 12, PITCH = 376;
     __shared__ float s_s[ROWS][PITCH];
-    __shared__ float s_c0[SYNC_BAND][PITCH];
-    __shared__ float s_rv[4][2];
-    __shared__ int s_rj[4][2];
+    __shared__ float s_c0[4][PITCH];
     const SyncWork *w = works + blockIdx.y;
     const int i0 = ia + blockIdx.x * SYNC_BAND;
     const int tid = threadIdx.x;
-    // stage the band: s_s[r][m-1] = s(i0+r, m)
-    for (int e = tid; e < ROWS * FT8_NHSYM; e += 256) {
-        const int m = e / ROWS, r = e - m * ROWS;
-        const int bin = i0 + r;
-        s_s[r][m] = (bin < nbins) ? w->spectra[(size_t)m * nbins + bin] : 0.0f;
-    }
-    __syncthreads();
-    for (int e = tid; e < SYNC_BAND * FT8_NHSYM; e += 256) {
-        const int r = e / FT8_NHSYM, m = e - r * FT8_NHSYM;
-        float c0 = 0.0f;
+    // stage the band: s_s[r][m-1] = s(i0+r, m); loads batched 16 deep so their latencies overlap
+    {
+        const float *sp = w->spectra;
+        constexpr int TOTAL = ROWS * FT8_NHSYM;            // 16368
+        for (int e0 = 0; e0 < TOTAL; e0 += 256 * 16) {
+            float v[16];
 #pragma unroll
-        for (int k = 0; k < 7; ++k) c0 = c0 + s_s[r + 2 * k][m];
-        s_c0[r][m] = c0;
+            for (int q = 0; q < 16; ++q) {
+                const int e = e0 + q * 256 + tid;
+                const int m = e / ROWS, r = e - m * ROWS;
+                const int bin = i0 + r;
+                v[q] = (e < TOTAL && bin < nbins) ? sp[(size_t)m * nbins + bin] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int e = e0 + q * 256 + tid;
+                const int m = e / ROWS, r = e - m * ROWS;
+                if (e < TOTAL) s_s[r][m] = v[q];
+            }
+        }
     }
     __syncthreads();
 
+    // one wave per bin from here on: no workgroup barriers, each wave owns s_c0[wv]
     const int lane = tid & 63, wv = tid >> 6;
-    const int l = (wv & 1) * 64 + lane;             // lag index 0..127 ; j = l - 62
-    const int j = l - FT8_JZ;
-    const bool lag_ok = l <= 2 * FT8_JZ;
-    const int icos[7] = {3, 1, 4, 0, 6, 5, 2};
-    for (int rr = wv >> 1; rr < SYNC_BAND; rr += 2) {          // two bins per iteration (wave pairs)
+    float *c0 = s_c0[wv];
+    for (int rr = wv; rr < SYNC_BAND; rr += 4) {
         const int bin = i0 + rr;
-        float sy = 0.0f;
-        if (lag_ok && bin <= ib) {
-            float ta = 0, tbv = 0, tc = 0, t0a = 0, t0b = 0, t0c = 0;
+        if (bin > ib) break;                            // wave-uniform
+        // 7-tone sums of this bin for every symbol step (sequential k, as the restatement)
+        for (int m = lane; m < FT8_NHSYM; m += 64) {
+            float acc = 0.0f;
 #pragma unroll
-            for (int n = 0; n < 7; ++n) {
-                const int m = j + 12 + 4 * n;                  // 1-based symbol-step index
-                const int row = rr + 2 * icos[n];
-                if (m >= 1 && m <= FT8_NHSYM) { ta = ta + s_s[row][m - 1]; t0a = t0a + s_c0[rr][m - 1]; }
-                { const int mb = m + 144; tbv = tbv + s_s[row][mb - 1]; t0b = t0b + s_c0[rr][mb - 1]; }
-                if (m + 288 <= FT8_NHSYM) { const int mc = m + 288; tc = tc + s_s[row][mc - 1]; t0c = t0c + s_c0[rr][mc - 1]; }
-            }
-            float t = ta + tbv + tc;
-            float t0 = t0a + t0b + t0c;
-            t0 = (t0 - t) / 6.0f;
-            const float sync_abc = t / t0;
-            t = tbv + tc;
-            t0 = t0b + t0c;
-            t0 = (t0 - t) / 6.0f;
-            const float sync_bc = t / t0;
-            sy = (sync_abc > sync_bc) ? sync_abc : sync_bc;
-            if (!(sy == sy)) sy = 0.0f;                        // 0/0 on all-zero windows: defined as 0 (as the oracle)
+            for (int k = 0; k < 7; ++k) acc = acc + s_s[rr + 2 * k][m];
+            c0[m] = acc;
         }
-        // wavefront arg-max (first maximum wins, like maxloc) for the two searches
-        float v2 = sy; int j2 = j; bool h2 = lag_ok;
-        float v1 = sy; int j1 = j; bool h1 = lag_ok && j >= -10 && j <= 10;
-#pragma unroll
-        for (int msk = 32; msk >= 1; msk >>= 1) {
-            {
-                const float ov = __shfl_xor(v2, msk, 64); const int oj = __shfl_xor(j2, msk, 64); const int oh = __shfl_xor((int)h2, msk, 64);
-                if (oh && (!h2 || ov > v2 || (ov == v2 && oj < j2))) { v2 = ov; j2 = oj; h2 = true; }
-            }
-            {
-                const float ov = __shfl_xor(v1, msk, 64); const int oj = __shfl_xor(j1, msk, 64); const int oh = __shfl_xor((int)h1, msk, 64);
-                if (oh && (!h1 || ov > v1 || (ov == v1 && oj < j1))) { v1 = ov; j1 = oj; h1 = true; }
-            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // lags: lane -> j = lane - 62 (lags -62..1) and j = lane + 2 (lags 2..62, lanes 0..60)
+        const int ja = lane - FT8_JZ, jb = lane + 2;
+        const float sa = costas_sync(s_s, c0, rr, ja);
+        const bool okb = jb <= FT8_JZ;
+        const float sb = okb ? costas_sync(s_s, c0, rr, jb) : 0.0f;
+        const unsigned long long ka = sync_key(sa, ja + FT8_JZ);
+        const unsigned long long kb = okb ? sync_key(sb, jb + FT8_JZ) : 0ull;
+        unsigned long long k2 = (kb > ka) ? kb : ka;
+        unsigned long long k1 = 0ull;
+        if (ja >= -10 && ja <= 10) k1 = ka;
+        if (okb && jb <= 10 && kb > k1) k1 = kb;
+        k2 = wave_max_u64(k2);
+        k1 = wave_max_u64(k1);
+        if (lane == 0) {
+            w->red[bin] = key_value(k1);  w->jpeak[bin] = (255 - (int)(k1 & 0xFFu)) - FT8_JZ;
+            w->red2[bin] = key_value(k2); w->jpeak2[bin] = (255 - (int)(k2 & 0xFFu)) - FT8_JZ;
         }
-        if (lane == 0) { s_rv[wv][0] = v1; s_rj[wv][0] = h1 ? j1 : 9999; s_rv[wv][1] = v2; s_rj[wv][1] = h2 ? j2 : 9999; }
-        __syncthreads();
-        if (lane == 0 && (wv & 1) == 0 && bin <= ib) {
-            // combine the two waves of this bin (lags -62..1 | 2..62); sequential first-maximum rule
-#pragma unroll
-            for (int which = 0; which < 2; ++which) {
-                float va = s_rv[wv][which], vb = s_rv[wv + 1][which];
-                int ja = s_rj[wv][which], jb = s_rj[wv + 1][which];
-                float best; int bj;
-                if (ja == 9999) { best = vb; bj = jb; }
-                else if (jb == 9999) { best = va; bj = ja; }
-                else if (vb > va) { best = vb; bj = jb; }
-                else { best = va; bj = ja; }
-                if (which == 0) { w->red[bin] = best; w->jpeak[bin] = bj; }
-                else { w->red2[bin] = best; w->jpeak2[bin] = bj; }
-            }
-        }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();               // c0 is rewritten by the next bin
     }
 }
 
@@ -285,10 +416,12 @@ __global__ __launch_bounds__(256) void ft8_candidates_kernel(const SyncWork *__r
     __shared__ int s_ki[2048];
     __shared__ float s_red[FT8_NH1 + 1], s_red2[FT8_NH1 + 1];
     __shared__ short s_jp[FT8_NH1 + 1], s_jp2[FT8_NH1 + 1];
-    __shared__ int s_desc[SYNC_MAXCAND_CAP];            // bins in descending red order
-    __shared__ int s_cnt[2];
-    __shared__ int s_cbin[SYNC_MAXCAND_CAP], s_clag[SYNC_MAXCAND_CAP];
-    __shared__ float s_csync[SYNC_MAXCAND_CAP], s_cf[SYNC_MAXCAND_CAP], s_ct[SYNC_MAXCAND_CAP];
+    __shared__ short s_first[FT8_NH1 + 2], s_second[FT8_NH1 + 2];   // bin -> pre-candidate index (or -1)
+    __shared__ int s_desc[SYNC_MAXPRE];                 // bins in descending red order
+    __shared__ int s_scan[256];
+    __shared__ unsigned s_scan_lo[1024];
+    __shared__ int s_cbin[SYNC_MAXPRE], s_clag[SYNC_MAXPRE];
+    __shared__ float s_csync[SYNC_MAXPRE], s_cf[SYNC_MAXPRE], s_ct[SYNC_MAXPRE];
     __shared__ float s_base[2];
     __shared__ int s_n;
     const SyncWork *w = works + blockIdx.x;
@@ -298,8 +431,9 @@ __global__ __launch_bounds__(256) void ft8_candidates_kernel(const SyncWork *__r
     for (int i = ia + tid; i <= ib; i += 256) {
         s_red[i] = w->red[i]; s_red2[i] = w->red2[i]; s_jp[i] = (short)w->jpeak[i]; s_jp2[i] = (short)w->jpeak2[i];
     }
+    for (int i = tid; i < FT8_NH1 + 2; i += 256) { s_first[i] = -1; s_second[i] = -1; }
     const int npct = (int)lroundf(0.40f * (float)iz);
-    const int lim = min(min(maxcand, iz), SYNC_MAXCAND_CAP);
+    const int lim = min(SYNC_MAXPRE, iz);
     __syncthreads();
     // --- percentile of red2
     for (int k = tid; k < 2048; k += 256) { s_kv[k] = (k < iz) ? s_red2[ia + k] : __builtin_huge_valf(); s_ki[k] = (k < iz) ? ia + k : 0x7fffffff; }
@@ -318,67 +452,162 @@ __global__ __launch_bounds__(256) void ft8_candidates_kernel(const SyncWork *__r
     const float base = s_base[0], base2 = s_base[1];
     for (int i = ia + tid; i <= ib; i += 256) { s_red[i] = s_red[i] / base; s_red2[i] = s_red2[i] / base2; }
     __syncthreads();
-    // --- walk the bins in descending red; each may append its +-10 peak and its +-62 peak (<= 600 ranks: serial)
-    if (tid == 0) {
-        int k = 0;
-        for (int r = 0; r < lim; ++r) {
+    // --- walk the bins in descending red; each appends its +-10 peak and, if at another lag, its +-62 peak,
+    // until MAXPRECAND entries exist.  Parallel form: per-rank counts -> exclusive scan -> positions < MAXPRECAND.
+    constexpr int PER = (SYNC_MAXPRE + 255) / 256;      // ranks per thread (4)
+    int cnt[PER], flags[PER];
+    int local = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int r = tid * PER + q;
+        int f = 0;
+        if (r < lim) {
             const int n = s_desc[r];
-            if (k >= maxcand) break;
-            if (s_red[n] >= syncmin) { s_cbin[k] = n; s_clag[k] = s_jp[n]; s_csync[k] = s_red[n]; ++k; }
-            if (s_jp2[n] == s_jp[n]) continue;
-            if (k >= maxcand) break;
-            if (s_red2[n] >= syncmin) { s_cbin[k] = n; s_clag[k] = s_jp2[n]; s_csync[k] = s_red2[n]; ++k; }
+            if (s_red[n] >= syncmin) f |= 1;
+            if (s_jp2[n] != s_jp[n] && s_red2[n] >= syncmin) f |= 2;
         }
-        s_n = k;
+        flags[q] = f;
+        cnt[q] = (f & 1) + ((f >> 1) & 1);
+        local += cnt[q];
     }
+    s_scan[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {           // Hillis-Steele inclusive scan
+        const int v = (tid >= off) ? s_scan[tid - off] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    int pos = s_scan[tid] - local;                      // exclusive prefix of this thread's first rank
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int r = tid * PER + q;
+        if (r < lim) {
+            const int n = s_desc[r];
+            if ((flags[q] & 1) && pos < SYNC_MAXPRE) { s_cbin[pos] = n; s_clag[pos] = s_jp[n]; s_csync[pos] = s_red[n]; s_first[n] = (short)pos; }
+            if (flags[q] & 1) ++pos;
+            if ((flags[q] & 2) && pos < SYNC_MAXPRE) { s_cbin[pos] = n; s_clag[pos] = s_jp2[n]; s_csync[pos] = s_red2[n]; s_second[n] = (short)pos; }
+            if (flags[q] & 2) ++pos;
+        }
+    }
+    if (tid == 255) s_n = min(s_scan[255], SYNC_MAXPRE);
     __syncthreads();
     const int ncand = s_n;
     for (int i = tid; i < ncand; i += 256) { s_cf[i] = (float)s_cbin[i] * df; s_ct[i] = ((float)s_clag[i] - 0.5f) * tstep; }
     __syncthreads();
-    // --- near-duplicate suppression: sequential in i (as upstream), parallel in j.  j* = first earlier candidate
-    // that beats i; everything before j* that i beats is zeroed, then i itself; nothing after j* can change.
-    for (int i = 1; i < ncand; ++i) {
-        if (tid == 0) s_cnt[0] = 0x7fffffff;
-        __syncthreads();
-        const float fi = fabsf(s_cf[i]), ti = s_ct[i], si = s_csync[i];
-        for (int j = tid; j < i; j += 256) {
-            const float fdiff = fi - fabsf(s_cf[j]);
-            const float tdiff = fabsf(ti - s_ct[j]);
-            if (fabsf(fdiff) < 4.0f && tdiff < 0.04f && si < s_csync[j]) atomicMin(&s_cnt[0], j);
+    // --- near-duplicate suppression.  Upstream's sequential double loop
+    //       for i: for j<i: if ||f_i|-|f_j|| < 4 Hz and |t_i-t_j| < 0.04 s: zero the weaker of the two (in place)
+    // has short-range dependencies only: |df| < 4 Hz <=> bins differ by at most 1 (f = bin*3.125 exactly) and a bin
+    // owns at most two pre-candidates, so candidate i meets at most six earlier partners, and its outcome depends
+    // only on earlier candidates within +-2 bins.  Evaluate in dependency order: each round, every candidate whose
+    // earlier +-2-bin neighbours are all finished runs its inner loop (partners in ascending j, as the original);
+    // candidates finished in one round are >= 3 bins apart, so they touch disjoint partners.  Rounds = depth of the
+    // dependency chains (a handful for real spectra, ncand in the worst case = the serial loop).
+    short *s_done = reinterpret_cast<short *>(s_ki);          // the sort buffers are free now
+    short *s_ready = s_done + SYNC_MAXPRE;
+    for (int i = tid; i < ncand; i += 256) s_done[i] = 0;
+    __syncthreads();
+    for (int round = 0; round <= ncand; ++round) {
+        int pending = 0;
+        for (int i = tid; i < ncand; i += 256) {
+            if (s_done[i]) { s_ready[i] = 0; continue; }
+            const int n = s_cbin[i];
+            bool ok = true;
+#pragma unroll
+            for (int dn = -2; dn <= 2; ++dn) {
+                const int nb = n + dn;
+                if (nb < 0 || nb > FT8_NH1) continue;
+                const int a = s_first[nb], b = s_second[nb];
+                if (a >= 0 && a < i && !s_done[a]) ok = false;
+                if (b >= 0 && b < i && !s_done[b]) ok = false;
+            }
+            s_ready[i] = ok ? 1 : 0;
+            pending = 1;
         }
-        __syncthreads();
-        const int jstar = s_cnt[0];
-        for (int j = tid; j < i; j += 256) {
-            if (j < jstar) {
+        if (!__syncthreads_or(pending)) break;
+        for (int i = tid; i < ncand; i += 256) {
+            if (!s_ready[i]) continue;
+            const int n = s_cbin[i];
+            int part[6];
+            int np = 0;
+#pragma unroll
+            for (int dn = -1; dn <= 1; ++dn) {
+                const int nb = n + dn;
+                if (nb < 0 || nb > FT8_NH1) continue;
+                const int a = s_first[nb], b = s_second[nb];
+                if (a >= 0 && a < i) part[np++] = a;
+                if (b >= 0 && b < i) part[np++] = b;
+            }
+#pragma unroll
+            for (int x = 1; x < 6; ++x) {                    // insertion sort, ascending j
+                if (x < np) {
+                    const int v = part[x];
+                    int y = x - 1;
+                    while (y >= 0 && part[y] > v) { part[y + 1] = part[y]; --y; }
+                    part[y + 1] = v;
+                }
+            }
+            const float fi = fabsf(s_cf[i]), ti = s_ct[i];
+            float si = s_csync[i];
+            for (int x = 0; x < np; ++x) {
+                const int j = part[x];
                 const float fdiff = fi - fabsf(s_cf[j]);
                 const float tdiff = fabsf(ti - s_ct[j]);
-                if (fabsf(fdiff) < 4.0f && tdiff < 0.04f && si >= s_csync[j]) s_csync[j] = 0.0f;
+                if (fabsf(fdiff) < 4.0f && tdiff < 0.04f) {
+                    const float sj = s_csync[j];
+                    if (si >= sj) s_csync[j] = 0.0f;
+                    if (si < sj) si = 0.0f;
+                }
             }
+            s_csync[i] = si;
+            s_done[i] = 1;
         }
-        if (tid == 0 && jstar != 0x7fffffff) s_csync[i] = 0.0f;
         __syncthreads();
     }
-    // --- final order by rank counting: descending sync, ties ascending bin, then lag
-    int nout_local = 0;
-    for (int i = tid; i < ncand; i += 256) {
-        const float si = s_csync[i];
-        if (!(si >= syncmin)) continue;
-        int rank = 0;
-        for (int j = 0; j < ncand; ++j) {
-            const float sj = s_csync[j];
-            if (!(sj >= syncmin) || j == i) continue;
-            if (sj > si || (sj == si && (s_cbin[j] < s_cbin[i] || (s_cbin[j] == s_cbin[i] && s_clag[j] < s_clag[i])))) ++rank;
+    __syncthreads();
+    // --- final order: descending sync, ties ascending bin, then lag; first maxcand kept.
+    // Bitonic sort of 64-bit keys (inverted order-preserving sync bits | bin | lag | index) in the two sort buffers.
+    unsigned *s_hi = reinterpret_cast<unsigned *>(s_kv);
+    unsigned *s_lo = reinterpret_cast<unsigned *>(s_scan_lo);
+    for (int i = tid; i < 1024; i += 256) {
+        unsigned hi = 0xFFFFFFFFu, lo = 0xFFFFFFFFu;
+        if (i < ncand && s_csync[i] >= syncmin) {
+            unsigned u = __float_as_uint(s_csync[i]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            hi = ~u;                                              // descending sync
+            lo = ((unsigned)s_cbin[i] << 20) | ((unsigned)(s_clag[i] + FT8_JZ) << 12) | (unsigned)i;
         }
-        if (rank < maxcand) {
+        s_hi[i] = hi; s_lo[i] = lo;
+    }
+    __syncthreads();
+    for (int size = 2; size <= 1024; size <<= 1) {
+        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+            for (int t = tid; t < 512; t += 256) {
+                const int l0 = 2 * t - (t & (stride - 1));
+                const int h0 = l0 + stride;
+                const bool up = (l0 & size) == 0;
+                const unsigned long long ka = ((unsigned long long)s_hi[l0] << 32) | s_lo[l0];
+                const unsigned long long kb = ((unsigned long long)s_hi[h0] << 32) | s_lo[h0];
+                const bool sw = up ? (kb < ka) : (ka < kb);
+                if (sw) { s_hi[l0] = (unsigned)(kb >> 32); s_lo[l0] = (unsigned)kb; s_hi[h0] = (unsigned)(ka >> 32); s_lo[h0] = (unsigned)ka; }
+            }
+            __syncthreads();
+        }
+    }
+    int nout = 0;
+    for (int r = tid; r < 1024; r += 256) {
+        if (s_hi[r] == 0xFFFFFFFFu && s_lo[r] == 0xFFFFFFFFu) continue;
+        ++nout;
+        if (r < maxcand) {
+            const int i = (int)(s_lo[r] & 0xFFFu);
             SyncChannelBuffers::Cand c;
-            c.freq_bin = s_cbin[i]; c.time_step = s_clag[i]; c.sync = si; c.freq_hz = s_cf[i]; c.dt_s = s_ct[i];
-            w->cand[rank] = c;
+            c.freq_bin = s_cbin[i]; c.time_step = s_clag[i]; c.sync = s_csync[i]; c.freq_hz = s_cf[i]; c.dt_s = s_ct[i];
+            w->cand[r] = c;
         }
-        ++nout_local;
     }
     if (tid == 0) s_n = 0;
     __syncthreads();
-    if (nout_local) atomicAdd(&s_n, nout_local);
+    if (nout) atomicAdd(&s_n, nout);
     __syncthreads();
     if (tid == 0) *w->ncand = min(s_n, maxcand);
 }

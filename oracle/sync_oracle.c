@@ -190,20 +190,21 @@ int orc_ft8_sync(const int16_t *frame, int nfa_hz, int nfb_hz, float syncmin, in
     qsort(ord2, (size_t)iz, sizeof(keyed_t), cmp_keyed);
     int npct = (int)lroundf(0.40f * (float)iz);
     int ncand = 0;
-    orc_candidate_t *c0 = (orc_candidate_t *)calloc((size_t)(2 * maxcand + 2), sizeof(orc_candidate_t));
+    const int maxpre = 1000;                              /* MAXPRECAND of sync8.f90 */
+    orc_candidate_t *c0 = (orc_candidate_t *)calloc((size_t)(maxpre + 2), sizeof(orc_candidate_t));
     if (npct >= 1) {
         const float base = red[ord[npct - 1].idx];
         const float base2 = red2[ord2[npct - 1].idx];
         for (int i = ia; i <= ib; ++i) { red[i] = red[i] / base; red2[i] = red2[i] / base2; }
-        const int lim = (maxcand < iz) ? maxcand : iz;
+        const int lim = (maxpre < iz) ? maxpre : iz;
         for (int r = 1; r <= lim; ++r) {
             const int n = ord[iz - r].idx;                /* descending red (order fixed before normalisation) */
-            if (ncand >= maxcand) break;
+            if (ncand >= maxpre) break;
             if (red[n] >= syncmin && !isnan(red[n])) {
                 c0[ncand].freq_bin = n; c0[ncand].time_step = jpeak[n]; c0[ncand].sync = red[n]; ncand++;
             }
             if (jpeak2[n] == jpeak[n]) continue;
-            if (ncand >= maxcand) break;
+            if (ncand >= maxpre) break;
             if (red2[n] >= syncmin && !isnan(red2[n])) {
                 c0[ncand].freq_bin = n; c0[ncand].time_step = jpeak2[n]; c0[ncand].sync = red2[n]; ncand++;
             }

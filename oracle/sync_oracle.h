@@ -12,7 +12,9 @@
  *   sync2d(i,j) = max( (ta+tb+tc)/((t0a+t0b+t0c-(ta+tb+tc))/6) , (tb+tc)/((t0b+t0c-(tb+tc))/6) )
  *                 over the three Costas arrays icos7 = 3,1,4,0,6,5,2 at symbols 0/36/72
  *   red/jpeak   = per-bin max over |lag|<=10, red2/jpeak2 over |lag|<=62, each divided by its 40th percentile
- *   candidates  : bins in descending red, threshold syncmin, near-dupe suppression (4 Hz, 0.04 s), sorted.
+ *   candidates  : bins in descending red (up to MAXPRECAND=1000 pre-candidates: the +-10 peak and, if at a
+ *                 different lag, the +-62 peak of each bin), threshold syncmin, near-dupe suppression
+ *                 (4 Hz, 0.04 s), sorted by sync, first maxcand kept.
  *
  * Because no external implementation can arbitrate, the ARITHMETIC is fully specified here (un-fused float32
  * operations in a fixed order, a fixed FFT factorisation 3840 -> real-pack 1920 = 15 x 128 radix-2 DIT, host
