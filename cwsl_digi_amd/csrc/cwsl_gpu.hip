@@ -112,6 +112,8 @@ using namespace cwslg;
 struct cwslg_ctx {
     std::mutex mu;
     int device = 0;
+    int cu_count = 256;
+    int demod_variant = 0;             // 0 = one workgroup per tile (default), 1 = persistent + prefetch (CWSLG_DEMOD_VARIANT=1)
     hipStream_t stream = nullptr;
     std::string last_error;
     float scale_ft = 0.90f, scale_wspr = 0.20f;    // CWSL_DIGI.cpp:100-101
@@ -274,8 +276,18 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     const long long per_xcd = (total + 7) / 8;
     hipEvent_t ea, eb;
     span_begin(c, 0, &ea, &eb);
-    hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
-                       c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
+    if (c->demod_variant == 1) {
+        // persistent variant (measured alternative): as many workgroups as are resident at once
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, demod_kernel<D, kTile, kDemodThreads, true>, kDemodThreads, 0) != hipSuccess || occ < 1) occ = 3;
+        long long wgs = std::min<long long>((long long)c->cu_count * occ, per_xcd * 8);
+        wgs = (wgs + 7) / 8 * 8;
+        hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, true>), dim3((unsigned)wgs), dim3(kDemodThreads), 0,
+                           c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
+    } else {
+        hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, false>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
+                           c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
+    }
     span_end(c, eb);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(w->done, c->stream));
@@ -307,6 +319,8 @@ int process_locked(cwslg_ctx *c)
         w.n_blocks = ch.pend_n / rx.D;
         w.inc = make_float2(ch.k.inc.real(), ch.k.inc.imag());
         w.sign = ch.k.sign;
+        w.lo_mod = (unsigned)((uint64_t)ch.pend_lo % rx.cap);
+        w.q_first = (ch.pend_lo - ch.origin_abs) / (int64_t)rx.D;
         by_fs[rx.fs].push_back(w);
         max_blocks[rx.fs] = std::max(max_blocks[rx.fs], w.n_blocks);
         c->stats.demod_samples += ch.pend_n;
@@ -506,6 +520,8 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return CWSLG_ERR_NO_DEVICE;   // code object is gfx950-only
     std::unique_ptr<cwslg_ctx> c(new cwslg_ctx);
     c->device = device_ordinal;
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *v = std::getenv("CWSLG_DEMOD_VARIANT")) c->demod_variant = std::atoi(v);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
     if (hipHostMalloc((void **)&c->h_stage, 2 * kStageHalf, hipHostMallocDefault) != hipSuccess) return CWSLG_ERR_NOMEM;
     hipEventCreateWithFlags(&c->stage_ev[0], hipEventDisableTiming);

@@ -70,7 +70,8 @@ struct alignas(16) ChanWork {
     unsigned      n_blocks;   // pending outputs (= pending samples / D)
     float2        inc;        // phase_inc
     float         sign;       // +1 USB, -1 LSB
-    unsigned      pad_;
+    unsigned      lo_mod;     // lo_abs mod ring_cap (host-computed: no 64-bit division on the device)
+    long long     q_first;    // (lo_abs - origin_abs) / D : block index of the first pending output
 };
 
 // One entry per channel per finalize launch.
@@ -211,193 +212,282 @@ struct DemodGeom {
     static constexpr int LDS_BYTES    = (2 * PLANE_FLOATS + AUX_FLOATS) * 4;
 };
 
+// ---------------------------------------------------------------------------------------------
+// demod_kernel<D, T, NT, PERSIST>: one tile = T outputs of one channel (see the file header for the phases).
+//   PERSIST = false  one workgroup per (channel, tile) work item; 4 workgroups per CU hide each other's HBM latency.
+//                    This is the default: measured 3.05 ms per 512-slot launch.
+//   PERSIST = true   a persistent workgroup walks a run of work items and keeps the NEXT item's HBM loads in
+//                    flight (registers) while it computes the current one.  Kept as a measured alternative
+//                    (3.31 ms): the PMC profile shows the kernel is bounded by VALU issue (~58 %), LDS (~45 %)
+//                    and HBM (~67 % of the achievable rate) together rather than by exposed latency, and the
+//                    prefetch registers cost a workgroup of occupancy (163 VGPRs -> 3 per CU).
+// Barriers are raw `s_barrier` behind an `s_waitcnt lgkmcnt(0)`: __syncthreads() would also drain vmcnt, i.e.
+// wait for the prefetch.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+constexpr int kDescWords = sizeof(ChanWork) / 4;
+
+template <int D, int T>
+struct TileCtx {                 // wave-uniform description of one work item (held in SGPRs)
+    const float2 *ring, *ckpt, *tone;
+    float *out;
+    unsigned *peak;
+    float2 inc;
+    float sign;
+    int tile, n_out;             // n_out == 0: nothing to do (ragged tail of a channel with fewer pending blocks)
+    int first_valid;             // samples r < first_valid precede the demodulator's origin (x[i<0] = 0)
+    unsigned base, cap;          // ring index of tile sample r = 0, ring capacity
+    int ck_first;                // checkpoint index of lane 0 in phase 0 (may be negative)
+    int pb0;                     // s_phase index of block 16*ck_first
+};
+
+__device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+template <typename P>
+__device__ __forceinline__ P *uni_ptr(P *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    return (P *)(((unsigned long long)uni((unsigned)(v >> 32)) << 32) | uni((unsigned)v));
+}
+
+// The descriptor was staged in LDS by the workgroup (never read from global memory inside the tile loop: a
+// vector-memory read there would force s_waitcnt vmcnt(0) and drain the prefetch).
+template <int D, int T>
+__device__ __forceinline__ void decode_item(const ChanWork *sd, int tile, TileCtx<D, T> &c)
+{
+    using Geo = DemodGeom<D, T>;
+    c.ring = uni_ptr(sd->ring); c.ckpt = uni_ptr(sd->ckpt); c.tone = uni_ptr(sd->tone);
+    c.out = uni_ptr(sd->out); c.peak = uni_ptr(sd->peak);
+    c.inc = make_float2(__uint_as_float(uni(__float_as_uint(sd->inc.x))), __uint_as_float(uni(__float_as_uint(sd->inc.y))));
+    c.sign = __uint_as_float(uni(__float_as_uint(sd->sign)));
+    c.tile = tile;
+    const unsigned nb = uni(sd->n_blocks);
+    c.n_out = ((unsigned)tile * T >= nb) ? 0 : (int)min((unsigned)T, nb - (unsigned)tile * T);
+    const unsigned long long qf = ((unsigned long long)uni((unsigned)((unsigned long long)sd->q_first >> 32)) << 32) |
+                                  uni((unsigned)(unsigned long long)sd->q_first);
+    const long long qlo = (long long)qf + (long long)tile * T - 31;         // first input block of the tile
+    c.first_valid = (qlo >= 0) ? 0 : ((-qlo * D > (long long)Geo::NSAMP) ? Geo::NSAMP : (int)(-qlo * D));
+    c.cap = uni(sd->ring_cap);
+    long long b = (long long)uni(sd->lo_mod) + ((long long)tile * T - 31) * D;   // > -cap, < 2*cap
+    if (b < 0) b += c.cap;
+    if (b >= (long long)c.cap) b -= c.cap;
+    c.base = (unsigned)b;
+    const long long c0 = (qlo >= 0) ? (qlo >> 4) : -((15 - qlo) >> 4);          // floor(qlo/16)
+    c.ck_first = (int)c0;
+    c.pb0 = (int)((c0 << 4) - qlo);                                             // in (-16, 0]
+}
+
 template <int D, int T, int NT>
-__global__ __launch_bounds__(NT) void demod_kernel(const ChanWork *__restrict__ works,
-                                                    const float *__restrict__ taps,
-                                                    int tiles_x, int n_ch)
+__device__ __forceinline__ void issue_tile_loads(const TileCtx<D, T> &c, int tid, v4f (&xs)[(DemodGeom<D, T>::NSAMP + 2 * NT - 1) / (2 * NT)],
+                                                 float2 &ck, v4f &tn)
+{
+    using Geo = DemodGeom<D, T>;
+    constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
+    const CWSLG_GLOBAL v4f *ring4 = as_global(reinterpret_cast<const v4f *>(c.ring));
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int r = 2 * tid + it * 2 * NT;
+        if (r > Geo::NSAMP - 2) r = Geo::NSAMP - 2;            // clamp: the load is unconditional
+        unsigned idx = c.base + (unsigned)r;
+        if (idx >= c.cap) idx -= c.cap;
+        xs[it] = ring4[idx >> 1];
+    }
+    // unconditional (clamped) checkpoint load: a predicated load would be merged with a default right away,
+    // and that copy makes hipcc wait for every load issued so far
+    int cidx = c.ck_first + ((tid < Geo::NCK) ? tid : 0);
+    if (cidx < 0) cidx = 0;
+    const v2f t = as_global(reinterpret_cast<const v2f *>(c.ckpt))[cidx];
+    ck = make_float2(t.x, t.y);
+    tn = as_global(reinterpret_cast<const v4f *>(c.tone))[((2 * tid) % D) >> 1];   // tone[m0], tone[m0+1]
+}
+
+template <int D, int T, int NT, bool PERSIST>
+__global__ __launch_bounds__(NT, PERSIST ? 3 : 4) void demod_kernel(const ChanWork *__restrict__ works,
+                                                                     const float *__restrict__ taps,
+                                                                     int tiles_x, int n_ch)
 {
     using Geo = DemodGeom<D, T>;
     constexpr int G = Geo::G;
     constexpr int PITCH = Geo::PITCH;
     constexpr int NWAVE = NT / 64;
-    constexpr int NG = 64 / G;                 // lane groups per wave
-    constexpr int CPW = (NG >= 2) ? NG / 2 : 1; // 16-output chunks (x2 planes) per wave iteration
-    static_assert(G <= 32, "one group must hold both planes in a wave");
-    static_assert(T % (32 * CPW) == 0, "tile must be a whole number of wave iterations");
-    static_assert((2 * NT) % D == 0, "per-thread tone index must be loop invariant");
+    constexpr int NG = 64 / G;
+    constexpr int CPW = (NG >= 2) ? NG / 2 : 1;
+    constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
+    static_assert(G <= 32 && T % (32 * CPW) == 0 && (2 * NT) % D == 0, "geometry");
+    static_assert(kDescWords <= 64 && NT >= 128, "descriptor staging uses one wave");
 
     __shared__ __attribute__((aligned(16))) float s_plane[2 * Geo::PLANE_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_aux[Geo::AUX_FLOATS];
+    __shared__ __attribute__((aligned(16))) unsigned s_desc[2][kDescWords];
     float2 *s_phase = reinterpret_cast<float2 *>(s_aux);
 
-    // ---- XCD-aware work mapping: workgroups are dealt round-robin over the 8 XCDs, so give each
-    // XCD one contiguous run of (channel, tile) pairs: neighbouring tiles re-read 31 blocks of halo,
-    // which then hits that XCD's own L2.
+    // XCD-aware persistent schedule: XCD x owns items [x*per_xcd, (x+1)*per_xcd); its workgroups walk them with
+    // stride n_slots, so neighbouring tiles (which share 31 blocks of halo) run on the same XCD at about the same time.
     const int total = tiles_x * n_ch;
     const int per_xcd = (total + 7) >> 3;
-    const int wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (wid >= total) return;
-    const int ch = wid / tiles_x;
-    const int tile = wid - ch * tiles_x;
-
-    const ChanWork *cw = works + ch;
-    const unsigned n_blocks = cw->n_blocks;
-    if ((unsigned)tile * T >= n_blocks) return;
-    const int n_out = min((unsigned)T, n_blocks - (unsigned)tile * T);
-
-    const long long origin = cw->origin_abs;
-    const long long q_first = (cw->lo_abs - origin) / D;          // block index of first pending output
-    const long long qs = q_first + (long long)tile * T;           // first output block of this tile
-    const long long qlo = qs - 31;                                // first input block of this tile (may be < 0)
-    const int tid = threadIdx.x;
-
-    // ---- issue every HBM load of the tile up front (IQ, checkpoint, tone, taps) so that ONE memory
-    // latency is paid per tile, overlapped with the serial phasor rebuild below.
-    constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
-    const unsigned cap = cw->ring_cap;
-    const long long tile_abs0 = origin + qlo * D;              // absolute index of tile sample r = 0
-    long long base = tile_abs0 % (long long)cap;
-    if (base < 0) base += cap;
-    // r >= first_valid  <=>  sample at/after the demodulator's origin (x[i<0] = 0)
-    const int first_valid = (qlo >= 0) ? 0 : ((-qlo * D > (long long)Geo::NSAMP) ? Geo::NSAMP : (int)(-qlo * D));
-    const CWSLG_GLOBAL v4f *ring4 = as_global(reinterpret_cast<const v4f *>(cw->ring));
-    v4f xs[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        int r = 2 * tid + it * 2 * NT;
-        if (r > Geo::NSAMP - 2) r = Geo::NSAMP - 2;            // clamp: the load is unconditional
-        unsigned idx = (unsigned)base + (unsigned)r;
-        if (idx >= cap) idx -= cap;
-        xs[it] = ring4[idx >> 1];
-    }
-    float2 ck = make_float2(1.0f, 0.0f);
-    const long long c0 = (qlo >= 0) ? (qlo >> 4) : -((15 - qlo) >> 4);   // floor(qlo/16)
-    const long long cidx = c0 + tid;
-    if (tid < Geo::NCK && cidx >= 0) {
-        const v2f t = as_global(reinterpret_cast<const v2f *>(cw->ckpt))[cidx];
-        ck = make_float2(t.x, t.y);
-    }
-    // per-thread constants of the mix
-    const int m0 = (2 * tid) % D;
-    const v4f tn01 = as_global(reinterpret_cast<const v4f *>(cw->tone))[m0 >> 1];   // tone[m0], tone[m0+1]
-    const float2 tn0 = make_float2(tn01.x, tn01.y);
-    const float2 tn1 = make_float2(tn01.z, tn01.w);
-    // polyphase taps of this lane's branch: H[u][v] = h[G*v + u]
-    const int lane = tid & 63;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, n_slots = gridDim.x >> 3;
+    const int hi_item = min((xcd + 1) * per_xcd, total);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int u = lane % G;
+    int item = xcd * per_xcd + slot;
+    if (item >= hi_item) return;
     float tap[16];
 #pragma unroll
     for (int v = 0; v < 16; ++v) tap[v] = taps[G * v + u];
 
-    // ---- phase 0: bit-exact phasor for blocks qlo .. qlo+NBLK-1
-    if (tid < Geo::NCK && cidx >= 0) {
-        const float2 inc = cw->inc;
-        float2 p = ck;
-        const long long qb = cidx << 4;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const long long pb = qb + s - qlo;
-            if (pb >= 0 && pb < Geo::NBLK) s_phase[pb] = p;
-            p = cmul_exact(p, inc);
-        }
-    }
-    __syncthreads();
+    // the first descriptor is read straight from global memory (scalar loads: nothing has been stored yet);
+    // later ones are staged through LDS so that no vector-memory read sits between the prefetch and its use
+    const CWSLG_GLOBAL unsigned *wwords = as_global(reinterpret_cast<const unsigned *>(works));
+    int cb = 0;
+    TileCtx<D, T> cur;
+    decode_item<D, T>(works + item / tiles_x, item % tiles_x, cur);
+    v4f xs[NIT];
+    float2 ck;
+    v4f tn;
+    issue_tile_loads<D, T, NT>(cur, tid, xs, ck, tn);
 
-    // ---- phase 1: mix + scatter into the branch-major planes
-    {
-        float *plane0 = s_plane;
-        float *plane1 = s_plane + Geo::PLANE_FLOATS;
+    // per-thread LDS addresses of the scatter: r = 2*tid + 2*NT*it  ->  row uu (constant), column w0 + WSTEP*it
+    const int r0 = 2 * tid;
+    float *p0 = s_plane + (r0 % G) * PITCH + r0 / G;                                // plane 0: rel = r
+    const int rel1 = r0 - D + 2 * NT;                                               // plane 1: rel = r - D, taken at it = 1
+    float *p1 = s_plane + Geo::PLANE_FLOATS + (rel1 % G) * PITCH + rel1 / G - (2 * NT) / G;
+    constexpr int WSTEP = (2 * NT) / G;                                             // columns per iteration
+
+    for (;;) {
+        const int nitem = item + n_slots;
+        const bool has_next = PERSIST && nitem < hi_item;                           // wave-uniform
+        // wave 1 fetches the NEXT descriptor (one dword per lane) while wave 0 rebuilds the phasor
+        unsigned dword = 0;
+        const bool desc_lane = has_next && tid >= 64 && tid < 64 + kDescWords;
+        if (desc_lane) dword = wwords[(size_t)(nitem / tiles_x) * kDescWords + (tid - 64)];
+        // ---- phase 0: bit-exact phasor for the tile's T+31 blocks (lanes 0..NCK-1, <=16 un-fused steps each)
+        {
+            const int cidx = cur.ck_first + tid;
+            if (tid < Geo::NCK && cidx >= 0) {
+                float2 p = ck;
+                const int pbase = cur.pb0 + 16 * tid;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int r = 2 * tid + it * 2 * NT;
-            if (r < Geo::NSAMP) {
-                const bool live = r >= first_valid;
+                for (int s = 0; s < 16; ++s) {
+                    const int pb = pbase + s;
+                    if (pb >= 0 && pb < Geo::NBLK) s_phase[pb] = p;
+                    p = cmul_exact(p, cur.inc);
+                }
+            }
+        }
+        if (desc_lane) s_desc[cb ^ 1][tid - 64] = dword;
+        lds_barrier();
+
+        // ---- prefetch: the NEXT item's loads go out now and land while this item is computed
+        TileCtx<D, T> nxt = cur;
+        v4f xs_n[NIT];
+        float2 ck_n;
+        v4f tn_n;
+        // "defined" without an instruction: these are only read when has_next, and then they hold the loads
+        asm volatile("" : "=v"(ck_n.x), "=v"(ck_n.y), "=v"(tn_n.x), "=v"(tn_n.y), "=v"(tn_n.z), "=v"(tn_n.w));
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) asm volatile("" : "=v"(xs_n[it].x), "=v"(xs_n[it].y), "=v"(xs_n[it].z), "=v"(xs_n[it].w));
+        if (has_next) {
+            decode_item<D, T>(reinterpret_cast<const ChanWork *>(s_desc[cb ^ 1]), nitem % tiles_x, nxt);
+            issue_tile_loads<D, T, NT>(nxt, tid, xs_n, ck_n, tn_n);
+        }
+
+        if (cur.n_out > 0) {
+        // ---- phase 1: mix (x*tone)*phase, scatter Re -> plane 0, Im -> plane 1
+        {
+            float2 ph[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                int blk = (2 * tid) / D + it * (2 * NT / D);
+                if (blk > Geo::NBLK - 1) blk = Geo::NBLK - 1;
+                ph[it] = s_phase[blk];
+            }
+            const float2 tn0 = make_float2(tn.x, tn.y), tn1 = make_float2(tn.z, tn.w);
+            const int fv = cur.first_valid;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int r = 2 * tid + it * 2 * NT;
                 const v4f x = xs[it];
-                const float2 ph = s_phase[r / D];
-                // (x * tone) * phase : same association as the reference's sum*phase (SSBD.hpp:167-170)
                 float ar = __builtin_fmaf(x.x, tn0.x, -(x.y * tn0.y));
                 float ai = __builtin_fmaf(x.x, tn0.y, x.y * tn0.x);
-                float y0r = __builtin_fmaf(ar, ph.x, -(ai * ph.y));
-                float y0i = __builtin_fmaf(ar, ph.y, ai * ph.x);
+                float y0r = __builtin_fmaf(ar, ph[it].x, -(ai * ph[it].y));
+                float y0i = __builtin_fmaf(ar, ph[it].y, ai * ph[it].x);
                 ar = __builtin_fmaf(x.z, tn1.x, -(x.w * tn1.y));
                 ai = __builtin_fmaf(x.z, tn1.y, x.w * tn1.x);
-                float y1r = __builtin_fmaf(ar, ph.x, -(ai * ph.y));
-                float y1i = __builtin_fmaf(ar, ph.y, ai * ph.x);
-                if (!live) { y0r = 0.f; y0i = 0.f; y1r = 0.f; y1i = 0.f; }   // x[i<0] = 0 (fresh demodulator)
-                // plane 0 (even outputs, Re): rel = r
-                {
-                    const int w = r / G, uu = r % G;
-                    if (w < T / 2 + 15) {
-                        plane0[uu * PITCH + w] = y0r;
-                        plane0[(uu + 1) * PITCH + w] = y1r;
+                float y1r = __builtin_fmaf(ar, ph[it].x, -(ai * ph[it].y));
+                float y1i = __builtin_fmaf(ar, ph[it].y, ai * ph[it].x);
+                if (fv != 0) {                                   // wave-uniform: only the first tiles of a slot
+                    if (r < fv) { y0r = 0.f; y0i = 0.f; y1r = 0.f; y1i = 0.f; }
+                }
+                const bool in0 = (it < NIT - 1) || (r < G * (T / 2 + 15));          // plane 0 drops the last D samples
+                const bool in1 = (it > 0) ? ((it < NIT - 1) || (r < Geo::NSAMP)) : (r >= D);   // plane 1 drops the first D
+                if (in0) { p0[it * WSTEP] = y0r; p0[it * WSTEP + PITCH] = y1r; }
+                if (in1) { p1[it * WSTEP] = y0i; p1[it * WSTEP + PITCH] = y1i; }
+            }
+        }
+        lds_barrier();
+
+        // ---- phase 2: branch FIRs + cross-branch reduction.  s_aux becomes the output row.
+        {
+            const int g = lane / G;
+            const int pl = g & 1;
+            const float sgn_plane = pl ? -cur.sign : 1.0f;
+            for (int it = wv; it < T / (32 * CPW); it += NWAVE) {
+                const int chunk = it * CPW + (g >> 1);
+                const float4 *src = reinterpret_cast<const float4 *>(
+                    s_plane + pl * Geo::PLANE_FLOATS + u * PITCH + 16 * chunk);
+                float x[32];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float4 t4 = src[k];
+                    x[4 * k] = t4.x; x[4 * k + 1] = t4.y; x[4 * k + 2] = t4.z; x[4 * k + 3] = t4.w;
+                }
+                float acc[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = x[r] * tap[0];
+#pragma unroll
+                for (int v = 1; v < 16; ++v)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(x[r + v], tap[v], acc[r]);
+                const int rbase = reduce_branches<G>(acc, u);
+                constexpr int NV = (G == 8) ? 2 : 1;
+                const bool writer = (G == 32) ? ((u & 1) == 0) : true;
+                if (writer) {
+#pragma unroll
+                    for (int r = 0; r < NV; ++r) {
+                        const int wq = 16 * chunk + rbase + r;
+                        const float s = (wq & 1) ? -sgn_plane : sgn_plane;
+                        s_aux[2 * wq + pl] = s * acc[r];
                     }
                 }
-                // plane 1 (odd outputs, Im): rel = r - D
-                {
-                    const int rel = r - D;
-                    if (rel >= 0) {
-                        const int w = rel / G, uu = rel % G;
-                        plane1[uu * PITCH + w] = y0i;
-                        plane1[(uu + 1) * PITCH + w] = y1i;
-                    }
-                }
             }
         }
-    }
-    __syncthreads();
+        lds_barrier();
 
-    // ---- phase 2: branch FIRs + cross-branch reduction.  s_aux is now the output row.
-    {
-        const int wv = tid >> 6;
-        const int g = lane / G;
-        const int pl = g & 1;                       // plane = output parity
-        const float sgn_plane = pl ? -cw->sign : 1.0f;
-        for (int it = wv; it < T / (32 * CPW); it += NWAVE) {
-            const int chunk = it * CPW + (g >> 1);   // 16 outputs of one parity
-            const float4 *src = reinterpret_cast<const float4 *>(
-                s_plane + pl * Geo::PLANE_FLOATS + u * PITCH + 16 * chunk);
-            float x[32];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float4 t4 = src[k];
-                x[4 * k] = t4.x; x[4 * k + 1] = t4.y; x[4 * k + 2] = t4.z; x[4 * k + 3] = t4.w;
+        // ---- epilogue: whole-row store + frame peak
+        {
+            CWSLG_GLOBAL float *out = as_global_rw(cur.out) + (size_t)cur.tile * T;
+            float mx = 0.0f;
+            for (int o = tid; o < cur.n_out; o += NT) {
+                const float v = s_aux[o];
+                out[o] = v;
+                mx = fmaxf(mx, fabsf(v));
             }
-            float acc[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = x[r] * tap[0];
-#pragma unroll
-            for (int v = 1; v < 16; ++v)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(x[r + v], tap[v], acc[r]);
-
-            // sum the branches: halving butterfly over the G lanes of the group (DPP / permlane, no LDS)
-            const int rbase = reduce_branches<G>(acc, u);
-            constexpr int NV = (G == 8) ? 2 : 1;
-            const bool writer = (G == 32) ? ((u & 1) == 0) : true;
-            if (writer) {
-#pragma unroll
-                for (int r = 0; r < NV; ++r) {
-                    const int wq = 16 * chunk + rbase + r;         // w' within the plane
-                    const float s = (wq & 1) ? -sgn_plane : sgn_plane;
-                    s_aux[2 * wq + pl] = s * acc[r];
-                }
-            }
+            for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+            if (lane == 0 && mx > 0.0f) atomicMax(cur.peak, __float_as_uint(mx));
         }
-    }
-    __syncthreads();
-
-    // ---- epilogue: whole-row store + frame peak
-    {
-        CWSLG_GLOBAL float *out = as_global_rw(cw->out) + (size_t)tile * T;
-        float mx = 0.0f;
-        for (int o = tid; o < n_out; o += NT) {
-            const float v = s_aux[o];
-            out[o] = v;
-            mx = fmaxf(mx, fabsf(v));
-        }
+        }   // n_out > 0
+        if (!has_next) break;
+        lds_barrier();                                           // s_aux (= s_phase) is rewritten by the next phase 0
+        cur = nxt;
+        item = nitem;
+        cb ^= 1;
+        ck = ck_n;
+        tn = tn_n;
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-        if (lane == 0 && mx > 0.0f) atomicMax(cw->peak, __float_as_uint(mx));
+        for (int it = 0; it < NIT; ++it) xs[it] = xs_n[it];
     }
 }
 
