@@ -90,8 +90,14 @@ __device__ __forceinline__ float2 cmul_u(float2 a, float2 b)          // un-fuse
 // 15-point DFTs over a (m = 128a + b) -> twiddle W1920^(bc) -> 15 radix-2 DIT FFTs of 128 points (bit-reversed
 // input) -> real-input unpack with W3840^k.  Any schedule that evaluates the same butterflies gives the same
 // bits; here each lane does 8-point groups (three radix-2 stages) in registers per LDS pass.
+// LDS image of the 15 x 128 work array: row pitch 129 (rows start 2 banks apart) and, after pass A, logical
+// column i stored at i ^ ((i >> 3) & 7) -- together they keep every pass at <= 2-way bank conflicts
+// (the plain [15][128] image ran the LDS at 94 % busy, two thirds of it conflict cycles).
+constexpr int SY_PITCH = 129;
+__device__ __forceinline__ int sy_col(int i) { return i ^ ((i >> 3) & 7); }
+
 template <int CH>
-__device__ __forceinline__ void spectra_stage1(const float *s_x, float2 (*s_y)[128], const float2 *s_w15,
+__device__ __forceinline__ void spectra_stage1(const float *s_x, float2 (*s_y)[SY_PITCH], const float2 *s_w15,
                                                const float2 *__restrict__ w1920, int b)
 {
     float2 z[8];
@@ -101,7 +107,6 @@ __device__ __forceinline__ void spectra_stage1(const float *s_x, float2 (*s_y)[1
         z[a] = (m < 960) ? make_float2(s_x[2 * m], s_x[2 * m + 1]) : make_float2(0.f, 0.f);
     }
     const bool a7 = (128 * 7 + b) < 960;
-    const int rb = (int)(__brev((unsigned)b) >> 25);
     float2 tw[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -124,7 +129,7 @@ __device__ __forceinline__ void spectra_stage1(const float *s_x, float2 (*s_y)[1
                 acc.x = acc.x + p.x;
                 acc.y = acc.y + p.y;
             }
-            s_y[c][rb] = cmul_u(acc, tw[i]);
+            s_y[c][b] = cmul_u(acc, tw[i]);        // natural order; pass A gathers the bit-reversed inputs
         }
     }
 }
@@ -142,7 +147,7 @@ __device__ __forceinline__ void bfly(float2 &u, float2 &v, float2 w)
 __global__ __launch_bounds__(256) void ft8_spectra_kernel(const SyncWork *__restrict__ works, SyncTables tb, int nbins)
 {
     __shared__ float s_x[FT8_NSPS];
-    __shared__ float2 s_y[15][128];
+    __shared__ float2 s_y[15][SY_PITCH];
     __shared__ float2 s_w15[16];
     __shared__ float2 s_w128[64];
     const SyncWork *w = works + blockIdx.y;
@@ -170,31 +175,39 @@ __global__ __launch_bounds__(256) void ft8_spectra_kernel(const SyncWork *__rest
     else spectra_stage1<1>(s_x, s_y, s_w15, tb.w1920, tid & 127);
     __syncthreads();
 
-    // stage 2, pass A: DIT stages len = 2,4,8 on 8 consecutive points; 15 x 16 = 240 groups
-    if (tid < 240) {
+    // stage 2, pass A: DIT stages len = 2,4,8 on logical points 8g..8g+7 of row c; the DIT input order is
+    // bit-reversed, i.e. logical point i is stage-1 column bitrev7(i) = 16*bitrev3(i & 7) + bitrev4(g)
+    {
         const int c = tid >> 4, g = tid & 15;
-        float2 *row = &s_y[c][8 * g];
+        const int gb = (int)(__brev((unsigned)g) >> 28);
         float2 e[8];
+        if (tid < 240) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) e[k] = row[k];
-        // len 2: pairs (0,1)(2,3)(4,5)(6,7), twiddle W128^0
-        bfly(e[0], e[1], s_w128[0]); bfly(e[2], e[3], s_w128[0]); bfly(e[4], e[5], s_w128[0]); bfly(e[6], e[7], s_w128[0]);
-        // len 4: pairs (0,2)(1,3)(4,6)(5,7), twiddles W128^(k*32)
-        bfly(e[0], e[2], s_w128[0]); bfly(e[1], e[3], s_w128[32]); bfly(e[4], e[6], s_w128[0]); bfly(e[5], e[7], s_w128[32]);
-        // len 8: pairs (k, k+4), twiddles W128^(k*16)
-        bfly(e[0], e[4], s_w128[0]); bfly(e[1], e[5], s_w128[16]); bfly(e[2], e[6], s_w128[32]); bfly(e[3], e[7], s_w128[48]);
+            for (int k = 0; k < 8; ++k) {
+                const int k3 = ((k & 1) << 2) | (k & 2) | ((k >> 2) & 1);
+                e[k] = s_y[c][16 * k3 + gb];
+            }
+        }
+        __syncthreads();                     // everyone has gathered: the image may now be rewritten
+        if (tid < 240) {
+            // len 2: pairs (0,1)(2,3)(4,5)(6,7), twiddle W128^0
+            bfly(e[0], e[1], s_w128[0]); bfly(e[2], e[3], s_w128[0]); bfly(e[4], e[5], s_w128[0]); bfly(e[6], e[7], s_w128[0]);
+            // len 4: pairs (0,2)(1,3)(4,6)(5,7), twiddles W128^(k*32)
+            bfly(e[0], e[2], s_w128[0]); bfly(e[1], e[3], s_w128[32]); bfly(e[4], e[6], s_w128[0]); bfly(e[5], e[7], s_w128[32]);
+            // len 8: pairs (k, k+4), twiddles W128^(k*16)
+            bfly(e[0], e[4], s_w128[0]); bfly(e[1], e[5], s_w128[16]); bfly(e[2], e[6], s_w128[32]); bfly(e[3], e[7], s_w128[48]);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) row[k] = e[k];
+            for (int k = 0; k < 8; ++k) s_y[c][sy_col(8 * g + k)] = e[k];
+        }
     }
     __syncthreads();
-    // pass B: stages len = 16,32,64 on points {r + 8 q : q<8} within each 64-block; groups: 15 x 2 blocks x 8 r
+    // pass B: stages len = 16,32,64 on logical points {64 blk + r + 8 q : q<8}; groups: 15 x 2 blocks x 8 r
     if (tid < 240) {
         const int c = tid >> 4, g = tid & 15;
         const int blk = g >> 3, r = g & 7;
-        float2 *row = &s_y[c][64 * blk + r];
         float2 e[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) e[q] = row[8 * q];
+        for (int q = 0; q < 8; ++q) e[q] = s_y[c][sy_col(64 * blk + r + 8 * q)];
         // len 16: index i = r + 8q, pairs differ in q bit0: k = i mod 8 = r, twiddle W128^(r*8)
         {
             const float2 w0 = s_w128[r * 8];
@@ -211,16 +224,16 @@ __global__ __launch_bounds__(256) void ft8_spectra_kernel(const SyncWork *__rest
             bfly(e[2], e[6], s_w128[(r + 16) * 2]); bfly(e[3], e[7], s_w128[(r + 24) * 2]);
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) row[8 * q] = e[q];
+        for (int q = 0; q < 8; ++q) s_y[c][sy_col(64 * blk + r + 8 * q)] = e[q];
     }
     __syncthreads();
     // pass C: stage len = 128: pairs (k, k+64), twiddle W128^k ; 960 butterflies
     for (int idx = tid; idx < 960; idx += 256) {
         const int c = idx >> 6, k = idx & 63;
-        float2 u = s_y[c][k], v = s_y[c][k + 64];
+        float2 u = s_y[c][sy_col(k)], v = s_y[c][sy_col(k + 64)];
         bfly(u, v, s_w128[k]);
-        s_y[c][k] = u;
-        s_y[c][k + 64] = v;
+        s_y[c][sy_col(k)] = u;
+        s_y[c][sy_col(k + 64)] = v;
     }
     __syncthreads();
 
@@ -230,8 +243,8 @@ __global__ __launch_bounds__(256) void ft8_spectra_kernel(const SyncWork *__rest
         float pw = 0.0f;
         if (k <= FT8_NH1) {
             const int k2 = (1920 - k) % 1920, kk = k % 1920;
-            const float2 A = s_y[kk % 15][kk / 15];
-            float2 B = s_y[k2 % 15][k2 / 15];
+            const float2 A = s_y[kk % 15][sy_col(kk / 15)];
+            float2 B = s_y[k2 % 15][sy_col(k2 / 15)];
             B.y = -B.y;
             const float er = (A.x + B.x) * 0.5f, ei = (A.y + B.y) * 0.5f;
             const float2 o = make_float2((A.x - B.x) * 0.5f, (A.y - B.y) * 0.5f);
