@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--slots", type=int, default=512, help="FT8 slots per GPU")
     ap.add_argument("--sync", type=int, default=1, help="run the FT8 sync stage (symbol spectra + Costas search) at every boundary")
+    ap.add_argument("--exact", action="store_true", help="reference-order arithmetic (cwslg_set_exact): bit-exact, slower")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU tensors; for checking the N>1 path on a 1-GPU box)")
+    ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses GPU 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
     ap.add_argument("--verify", type=int, default=1, help="slots checked against the oracle after the timed region")
@@ -76,13 +79,20 @@ def main():
     import numpy as np
     import cwsl_digi_amd as P
 
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
+    dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
 
     S = args.slots
     ctx = P.Context(local_rank)
+    if args.exact:
+        ctx.set_exact(True)
     if args.sync:
         ctx.enable_sync(True, 1.5, 200, 200, 3000)    # jt9 -8 defaults used by the reference: syncmin 1.5, 200..3000 Hz (-H highestdecodefreq)
     ring_blocks = SLOT_SAMPLES // IQ_LEN + 2 + (SLOT_SAMPLES % IQ_LEN != 0)
@@ -111,7 +121,9 @@ def main():
         ctx.slot_boundary("FT8", 15 * (k + 2))         # batched peak-normalise + int16 (+ sync) ; frames swap
         if world > 1:
             ctx.synchronize()                          # frames of this epoch are final on this GPU ...
-            dist.all_reduce(flag)                      # ... and on every other GPU: 4-byte RCCL all-reduce
+            flag.fill_(S)
+            dist.all_reduce(flag)                      # ... and on every other GPU: 4-byte RCCL all-reduce (frames finalised)
+            assert int(flag.item()) == S * world
     def barrier():
         ctx.synchronize()
         torch.cuda.synchronize()
@@ -208,7 +220,7 @@ def main():
                        "slots_per_gpu": S, "fs_hz": FS, "iq_block": IQ_LEN, "stages": "nco-mix+polyphase-decimate, peak-normalise+int16" + (", ft8 symbol-spectra+costas-sync+candidates" if args.sync else ""),
                        "sharding": f"slots x{world}, RCCL 4-byte all-reduce per slot boundary" if world > 1 else "single GPU"},
             "realtime_ft8_slots": msps / 0.192,
-            "roofline": {"bound": "hbm", "kernel": "demod_kernel<16,256,256>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "demod_exact_kernel<16,256,256>" if args.exact else "demod_kernel<16,256,256,false>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_sample": BYTES_PER_SAMPLE_DEMOD, "samples_per_launch": samples_per_launch,
                          "avg_launch_ms": avg_ms, "launches": st["demod_launches"],

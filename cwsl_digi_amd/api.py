@@ -70,7 +70,7 @@ _lib = None
 # every symbol include/cwsl_gpu.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = [
     "cwslg_abi_version", "cwslg_create", "cwslg_destroy", "cwslg_strerror", "cwslg_last_error",
-    "cwslg_set_scale_factors", "cwslg_receiver_open", "cwslg_receiver_close", "cwslg_push_iq",
+    "cwslg_set_scale_factors", "cwslg_set_exact", "cwslg_receiver_open", "cwslg_receiver_close", "cwslg_push_iq",
     "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_channel_open", "cwslg_channel_close",
     "cwslg_channel_info", "cwslg_process", "cwslg_slot_boundary", "cwslg_slot_boundary_channel",
     "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
@@ -102,6 +102,7 @@ def load_library(build_if_missing=True):
     L.cwslg_strerror.argtypes = [i32]; L.cwslg_strerror.restype = C.c_char_p
     L.cwslg_last_error.argtypes = [vp]; L.cwslg_last_error.restype = C.c_char_p
     L.cwslg_set_scale_factors.argtypes = [vp, f32, f32]
+    L.cwslg_set_exact.argtypes = [vp, i32]
     L.cwslg_receiver_open.argtypes = [vp, u32, u32, C.c_int32, u32, C.POINTER(i32)]
     L.cwslg_receiver_close.argtypes = [vp, i32]
     L.cwslg_push_iq.argtypes = [vp, i32, vp, u32]
@@ -287,6 +288,10 @@ class Context:
 
     def set_scale_factors(self, ft=0.90, wspr=0.20):
         self._chk(self.L.cwslg_set_scale_factors(self.h, ft, wspr))
+
+    def set_exact(self, on=True):
+        """Reference-order arithmetic: float and int16 frames bit-identical to the compiled reference."""
+        self._chk(self.L.cwslg_set_exact(self.h, 1 if on else 0))
 
     def stream(self):
         return self.L.cwslg_stream(self.h)

@@ -113,6 +113,7 @@ struct cwslg_ctx {
     std::mutex mu;
     int device = 0;
     int cu_count = 256;
+    bool exact = false;                // cwslg_set_exact: reference-order arithmetic (bit-exact, slower)
     int demod_variant = 0;             // 0 = one workgroup per tile (default), 1 = persistent + prefetch (CWSLG_DEMOD_VARIANT=1)
     hipStream_t stream = nullptr;
     std::string last_error;
@@ -276,7 +277,10 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     const long long per_xcd = (total + 7) / 8;
     hipEvent_t ea, eb;
     span_begin(c, 0, &ea, &eb);
-    if (c->demod_variant == 1) {
+    if (c->exact) {
+        hipLaunchKernelGGL((demod_exact_kernel<D, kTile, kDemodThreads>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
+                           c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
+    } else if (c->demod_variant == 1) {
         // persistent variant (measured alternative): as many workgroups as are resident at once
         int occ = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, demod_kernel<D, kTile, kDemodThreads, true>, kDemodThreads, 0) != hipSuccess || occ < 1) occ = 3;
@@ -573,6 +577,17 @@ int cwslg_set_scale_factors(cwslg_ctx *c, float ft, float wspr)
     std::lock_guard<std::mutex> g(c->mu);
     c->scale_ft = ft;
     c->scale_wspr = wspr;
+    return CWSLG_OK;
+}
+
+int cwslg_set_exact(cwslg_ctx *c, int on)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    hipSetDevice(c->device);
+    int rc = process_locked(c);         // pending samples keep the mode they were pushed under
+    if (rc) return rc;
+    c->exact = on != 0;
     return CWSLG_OK;
 }
 

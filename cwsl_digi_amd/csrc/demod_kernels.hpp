@@ -492,6 +492,107 @@ __global__ __launch_bounds__(NT, PERSIST ? 3 : 4) void demod_kernel(const ChanWo
 }
 
 // ---------------------------------------------------------------------------------------------
+// demod_exact_kernel: the reference's arithmetic, operation for operation (SSBD.hpp:160-183), for bit-exact
+// verification.  Same tiles, same HBM layout, same phasor rebuild as demod_kernel; what differs is phase 2:
+//   thread = one output b.  For n = 0..31 (oldest block first, like the workspace slot's accumulation order):
+//       sum  = 0;  for m = 0..D-1:  sum += (x[D(b-31+n)+m] * tone[m]) * h[m + D n]      (complex*complex, complex*real, +=)
+//       ws  += sum * phase_{b-31+n}
+//   audio[b] = the Re/Im pick of Iterate() (SSBD.hpp:132-135)
+// every product and sum un-fused (-ffp-contract=off), so the float frame -- and therefore the int16 frame -- equals the
+// compiled reference bit for bit.  x*tone is computed once per sample into LDS (pitch D+1 complex per block: the 64
+// lanes' reads land in 32 distinct bank pairs).  ~2.3x the VALU work and 14x the LDS traffic of demod_kernel: this is
+// the checking mode (cwslg_set_exact), not the throughput path.
+template <int D, int T, int NT>
+__global__ __launch_bounds__(NT) void demod_exact_kernel(const ChanWork *__restrict__ works,
+                                                          const float *__restrict__ taps,
+                                                          int tiles_x, int n_ch)
+{
+    using Geo = DemodGeom<D, T>;
+    constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
+    static_assert(NT == T, "one thread per output");
+    __shared__ float2 s_t[Geo::NBLK * (D + 1)];
+    __shared__ float2 s_phase[Geo::NBLK + 1];
+
+    const int total = tiles_x * n_ch;
+    const int per_xcd = (total + 7) >> 3;
+    const int wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (wid >= total) return;
+    const int tid = threadIdx.x;
+    TileCtx<D, T> cur;
+    decode_item<D, T>(works + wid / tiles_x, wid % tiles_x, cur);
+    if (cur.n_out == 0) return;
+    v4f xs[NIT];
+    float2 ck;
+    v4f tn;
+    issue_tile_loads<D, T, NT>(cur, tid, xs, ck, tn);
+    {
+        const int cidx = cur.ck_first + tid;
+        if (tid < Geo::NCK && cidx >= 0) {
+            float2 p = ck;
+            const int pbase = cur.pb0 + 16 * tid;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int pb = pbase + s;
+                if (pb >= 0 && pb < Geo::NBLK) s_phase[pb] = p;
+                p = cmul_exact(p, cur.inc);
+            }
+        }
+    }
+    // t = in[m] * tone[m]  (SSBD.hpp:167), un-fused
+    {
+        const float2 tn0 = make_float2(tn.x, tn.y), tn1 = make_float2(tn.z, tn.w);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = 2 * tid + it * 2 * NT;
+            if (r < Geo::NSAMP) {
+                const v4f x = xs[it];
+                const float2 a = cmul_exact(make_float2(x.x, x.y), tn0);
+                const float2 b = cmul_exact(make_float2(x.z, x.w), tn1);
+                const int blk = r / D, m = r % D;
+                s_t[blk * (D + 1) + m] = a;
+                s_t[blk * (D + 1) + m + 1] = b;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < cur.n_out) {
+        const int o = tid;                                   // output qs + o ; its blocks are tile blocks o .. o+31
+        const int first_blk = cur.first_valid / D;           // tile blocks before this precede the demodulator's origin
+        float wr = 0.0f, wi = 0.0f;                          // the workspace slot, zero after its last read-out (:178)
+        for (int n = 0; n < 32; ++n) {
+            const int blk = o + n;
+            if (blk < first_blk) continue;                   // the reference never touched the slot for these
+            const float2 *tp = s_t + blk * (D + 1);
+            float sr = 0.0f, si = 0.0f;
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                const float2 t = tp[m];
+                const float h = taps[m + D * n];
+                sr = sr + t.x * h;
+                si = si + t.y * h;
+            }
+            const float2 ph = s_phase[blk];
+            const float2 pr = cmul_exact(make_float2(sr, si), ph);      // sum * phase (:170)
+            wr = wr + pr.x;
+            wi = wi + pr.y;
+        }
+        // Iterate(): out[k] for block index mod 4 (qs is a multiple of 4; T is too)
+        float v;
+        switch (o & 3) {
+        case 0: v = wr; break;
+        case 1: v = -wi * cur.sign; break;
+        case 2: v = -wr; break;
+        default: v = wi * cur.sign; break;
+        }
+        as_global_rw(cur.out)[(size_t)cur.tile * T + o] = v;
+        float mx = fabsf(v);
+#pragma unroll
+        for (int msk = 32; msk >= 1; msk >>= 1) mx = fmaxf(mx, __shfl_xor(mx, msk, 64));
+        if ((tid & 63) == 0 && mx > 0.0f) atomicMax(cur.peak, __float_as_uint(mx));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Slot finalise: prepareAudio + float->int16 (Instance.cpp:294-338, 238-241), bit-exact:
 //   factor = 32767.0f / (peak + 1.0f); factor *= scale;  buf[k] *= factor;  (int16)(buf[k] + 0.5f)
 // The peak is max|audio| (max(maxVal, |minVal|) == max|x| for every frame).

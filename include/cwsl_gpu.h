@@ -76,6 +76,11 @@ const char *cwslg_last_error(cwslg_ctx *ctx);
 /* wsjtx.ftaudioscalefactor / wsjtx.wspraudioscalefactor (CWSL_DIGI.cpp:100-101; defaults 0.90 / 0.20) */
 int  cwslg_set_scale_factors(cwslg_ctx *ctx, float scale_ft, float scale_wspr);
 
+/* Verification mode: demodulate with the reference's exact operation order (SSBD.hpp:160-183, un-fused float32)
+ * instead of the fused polyphase form.  The float frame and the int16 frame then equal the compiled reference
+ * bit for bit (the default mode is within ~4e-7 of frame peak).  About 3x slower; not the throughput path. */
+int  cwslg_set_exact(cwslg_ctx *ctx, int on);
+
 /* ---- receivers: replaces Receiver::init + the SPMC ring (Receiver.hpp:115-163, ring_buffer_spmc.h) ----
  * fs, iq_len, lo_hz are SM_HDR.SampleRate / BlockInSamples / L0 (SharedMemory.h:10-21, Receiver.hpp:86-88).
  * ring_blocks = 0 selects the reference depth 3*(fs/iq_len+1) blocks (Receiver.hpp:132).  The ring lives in HBM. */
