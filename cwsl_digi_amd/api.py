@@ -13,7 +13,7 @@ import numpy as np
 from . import build as _build
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "libcwslgpu.so")
+_LIB_PATH = os.environ.get("CWSLG_LIB") or os.path.join(_HERE, "lib", "libcwslgpu.so")   # CWSLG_LIB: A/B of kernel builds
 
 STATUS_NAMES = {
     0: "OK", -1: "ERR_RATIO", -2: "ERR_BAND_LOW", -3: "ERR_BAND_HIGH", -4: "ERR_NOMEM", -5: "ERR_MODE",

@@ -143,52 +143,37 @@ __device__ __forceinline__ float halve_dpp(float lo, float hi, bool bit_set)
     return keep + dpp_get<CTRL>(send);
 }
 
-// Same across the two 16-lane rows of a 32-lane group (lane bit 4) with v_permlane16_swap:
-// afterwards even rows hold lo(row r)+lo(row r+1) and odd rows hold hi(row r-1)+hi(row r).
-__device__ __forceinline__ float halve_rows(float lo, float hi)
+// Sum acc[0..15] over the GL (16, 8 or 4) lanes of a group by halving: after the step on lane bit B the lanes with
+// the bit clear hold the lower half of the remaining outputs, the others the upper half.  On return lane k holds
+// NV = 16/GL results acc[0..NV-1] for output indices rbase .. rbase+NV-1.
+template <int GL>
+__device__ __forceinline__ int reduce_lanes(float (&acc)[16], int k)
 {
-    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
-    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-}
-
-// Sum acc[0..15] over the G lanes of a group.  On return lane u holds NV results acc[0..NV-1] for
-// output indices rbase .. rbase+NV-1 (NV = 1 for G >= 16, 2 for G = 8); for G = 32 lanes u and u^1
-// hold the same result.
-template <int G>
-__device__ __forceinline__ int reduce_branches(float (&acc)[16], int u)
-{
+    static_assert(GL == 16 || GL == 8 || GL == 4, "group width");
     int rbase = 0;
-    if constexpr (G == 32) {
+    if constexpr (GL >= 16) {
+        const bool b = (k & 8) != 0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) acc[r] = halve_rows(acc[r], acc[r + 8]);
-        if (u & 16) rbase += 8;
+        for (int r = 0; r < 8; ++r) acc[r] = halve_dpp<DPP_ROR8>(acc[r], acc[r + 8], b);
+        if (b) rbase += 8;
     }
-    if constexpr (G >= 16) {
-        const bool b = (u & 8) != 0;
-        constexpr int N = (G == 32) ? 8 : 16;
-#pragma unroll
-        for (int r = 0; r < N / 2; ++r) acc[r] = halve_dpp<DPP_ROR8>(acc[r], acc[r + N / 2], b);
-        if (b) rbase += N / 2;
-    }
-    {
-        const bool b = (u & 4) != 0;
-        constexpr int N = (G == 32) ? 4 : (G == 16 ? 8 : 16);
+    if constexpr (GL >= 8) {
+        const bool b = (k & 4) != 0;
+        constexpr int N = (GL == 16) ? 8 : 16;
 #pragma unroll
         for (int r = 0; r < N / 2; ++r) acc[r] = halve_dpp<DPP_HALF_MIRROR>(acc[r], acc[r + N / 2], b);
         if (b) rbase += N / 2;
     }
     {
-        const bool b = (u & 2) != 0;
-        constexpr int N = (G == 32) ? 2 : (G == 16 ? 4 : 8);
+        const bool b = (k & 2) != 0;
+        constexpr int N = (GL == 16) ? 4 : (GL == 8 ? 8 : 16);
 #pragma unroll
         for (int r = 0; r < N / 2; ++r) acc[r] = halve_dpp<DPP_XOR2>(acc[r], acc[r + N / 2], b);
         if (b) rbase += N / 2;
     }
-    if constexpr (G == 32) {
-        acc[0] = acc[0] + dpp_get<DPP_XOR1>(acc[0]);
-    } else {
-        const bool b = (u & 1) != 0;
-        constexpr int N = (G == 16) ? 2 : 4;
+    {
+        const bool b = (k & 1) != 0;
+        constexpr int N = (GL == 16) ? 2 : (GL == 8 ? 4 : 8);
 #pragma unroll
         for (int r = 0; r < N / 2; ++r) acc[r] = halve_dpp<DPP_XOR1>(acc[r], acc[r + N / 2], b);
         if (b) rbase += N / 2;
@@ -199,18 +184,24 @@ __device__ __forceinline__ int reduce_branches(float (&acc)[16], int u)
 // ---------------------------------------------------------------------------------------------
 template <int D, int T>
 struct DemodGeom {
-    static constexpr int G      = 2 * D;              // polyphase branches = lanes per group
+    static constexpr int G      = 2 * D;              // polyphase branches
+    static constexpr int GL     = D;                  // lanes per group: each lane owns the branch PAIR (2k, 2k+1)
     static constexpr int NBLK   = T + 31;             // input blocks per tile
     static constexpr int NSAMP  = D * NBLK;           // input samples per tile
     static constexpr int NW     = T / 2 + 16;         // columns per plane (T/2+15 used, +1 read slack)
-    static constexpr int PITCH0 = (NW + 3) / 4 * 4;
-    // PITCH/4 odd: the 16 lanes of a ds_read_b128 group land in 16 distinct 16-B slots of a bank row
-    static constexpr int PITCH  = ((PITCH0 / 4) % 2 == 1) ? PITCH0 : PITCH0 + 4;
+    // LDS image of one plane: D pair-rows; row k holds branches 2k and 2k+1 interleaved per column:
+    //   float index = k*PR + 2*w + (u & 1)
+    // so the two samples a lane mixes per load (branches uu, uu+1, same column) are ONE ds_write_b64, and the FIR lane
+    // reads its pair-row as contiguous ds_read_b128.  PR/4 odd: the 16 lanes of a b128 group hit 16 distinct 16-B
+    // slots, and the 16 lanes of a b64 write spread over 8 bank pairs (2-way; the [2D][148] image was 4-way on b32).
+    static constexpr int PR0    = (2 * NW + 3) / 4 * 4;
+    static constexpr int PR     = ((PR0 / 4) % 2 == 1) ? PR0 : PR0 + 4;
     static constexpr int NCK    = (NBLK + 15) / 16 + 1;   // checkpoints touched by a tile
-    static constexpr int PLANE_FLOATS = G * PITCH;
+    static constexpr int PLANE_FLOATS = D * PR;
     static constexpr int AUX_FLOATS   = (2 * (NBLK + 1) > T) ? 2 * (NBLK + 1) : T;  // phases, later the output row
     static constexpr int LDS_BYTES    = (2 * PLANE_FLOATS + AUX_FLOATS) * 4;
 };
+
 
 // ---------------------------------------------------------------------------------------------
 // demod_kernel<D, T, NT, PERSIST>: one tile = T outputs of one channel (see the file header for the phases).
@@ -310,12 +301,13 @@ __global__ __launch_bounds__(NT, PERSIST ? 3 : 4) void demod_kernel(const ChanWo
 {
     using Geo = DemodGeom<D, T>;
     constexpr int G = Geo::G;
-    constexpr int PITCH = Geo::PITCH;
+    constexpr int GL = Geo::GL;
+    constexpr int PR = Geo::PR;
     constexpr int NWAVE = NT / 64;
-    constexpr int NG = 64 / G;
-    constexpr int CPW = (NG >= 2) ? NG / 2 : 1;
+    constexpr int NG = 64 / GL;                 // lane groups per wave
+    constexpr int CPW = NG / 2;                 // 16-output chunks (x2 planes) per wave iteration
     constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
-    static_assert(G <= 32 && T % (32 * CPW) == 0 && (2 * NT) % D == 0, "geometry");
+    static_assert(GL <= 16 && T % (32 * CPW) == 0 && (2 * NT) % D == 0, "geometry");
     static_assert(kDescWords <= 64 && NT >= 128, "descriptor staging uses one wave");
 
     __shared__ __attribute__((aligned(16))) float s_plane[2 * Geo::PLANE_FLOATS];
@@ -330,12 +322,12 @@ __global__ __launch_bounds__(NT, PERSIST ? 3 : 4) void demod_kernel(const ChanWo
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, n_slots = gridDim.x >> 3;
     const int hi_item = min((xcd + 1) * per_xcd, total);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int u = lane % G;
+    const int k = lane % GL;                    // this lane's branch pair (2k, 2k+1)
     int item = xcd * per_xcd + slot;
     if (item >= hi_item) return;
-    float tap[16];
+    float2 tap[16];                             // H[2k][v], H[2k+1][v] = h[G*v + 2k], h[G*v + 2k + 1]
 #pragma unroll
-    for (int v = 0; v < 16; ++v) tap[v] = taps[G * v + u];
+    for (int v = 0; v < 16; ++v) tap[v] = *reinterpret_cast<const float2 *>(taps + G * v + 2 * k);
 
     // the first descriptor is read straight from global memory (scalar loads: nothing has been stored yet);
     // later ones are staged through LDS so that no vector-memory read sits between the prefetch and its use
@@ -348,11 +340,11 @@ __global__ __launch_bounds__(NT, PERSIST ? 3 : 4) void demod_kernel(const ChanWo
     v4f tn;
     issue_tile_loads<D, T, NT>(cur, tid, xs, ck, tn);
 
-    // per-thread LDS addresses of the scatter: r = 2*tid + 2*NT*it  ->  row uu (constant), column w0 + WSTEP*it
+    // per-thread LDS addresses of the scatter: r = 2*tid + 2*NT*it  ->  pair-row (r % G)/2 (constant), column w0 + WSTEP*it
     const int r0 = 2 * tid;
-    float *p0 = s_plane + (r0 % G) * PITCH + r0 / G;                                // plane 0: rel = r
+    float *p0 = s_plane + ((r0 % G) >> 1) * PR + 2 * (r0 / G);                      // plane 0: rel = r
     const int rel1 = r0 - D + 2 * NT;                                               // plane 1: rel = r - D, taken at it = 1
-    float *p1 = s_plane + Geo::PLANE_FLOATS + (rel1 % G) * PITCH + rel1 / G - (2 * NT) / G;
+    float *p1 = s_plane + Geo::PLANE_FLOATS + ((rel1 % G) >> 1) * PR + 2 * (rel1 / G - (2 * NT) / G);
     constexpr int WSTEP = (2 * NT) / G;                                             // columns per iteration
 
     for (;;) {
@@ -422,44 +414,49 @@ __global__ __launch_bounds__(NT, PERSIST ? 3 : 4) void demod_kernel(const ChanWo
                 }
                 const bool in0 = (it < NIT - 1) || (r < G * (T / 2 + 15));          // plane 0 drops the last D samples
                 const bool in1 = (it > 0) ? ((it < NIT - 1) || (r < Geo::NSAMP)) : (r >= D);   // plane 1 drops the first D
-                if (in0) { p0[it * WSTEP] = y0r; p0[it * WSTEP + PITCH] = y1r; }
-                if (in1) { p1[it * WSTEP] = y0i; p1[it * WSTEP + PITCH] = y1i; }
+                if (in0) *reinterpret_cast<float2 *>(p0 + 2 * it * WSTEP) = make_float2(y0r, y1r);
+                if (in1) *reinterpret_cast<float2 *>(p1 + 2 * it * WSTEP) = make_float2(y0i, y1i);
             }
         }
         lds_barrier();
 
-        // ---- phase 2: branch FIRs + cross-branch reduction.  s_aux becomes the output row.
+        // ---- phase 2: branch-pair FIRs + cross-lane reduction.  s_aux becomes the output row.
         {
-            const int g = lane / G;
+            const int g = lane / GL;
             const int pl = g & 1;
             const float sgn_plane = pl ? -cur.sign : 1.0f;
             for (int it = wv; it < T / (32 * CPW); it += NWAVE) {
                 const int chunk = it * CPW + (g >> 1);
                 const float4 *src = reinterpret_cast<const float4 *>(
-                    s_plane + pl * Geo::PLANE_FLOATS + u * PITCH + 16 * chunk);
-                float x[32];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float4 t4 = src[k];
-                    x[4 * k] = t4.x; x[4 * k + 1] = t4.y; x[4 * k + 2] = t4.z; x[4 * k + 3] = t4.w;
-                }
+                    s_plane + pl * Geo::PLANE_FLOATS + k * PR + 2 * 16 * chunk);
                 float acc[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = x[r] * tap[0];
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                // column j = w - 16*chunk (0..30) feeds acc[j - v], v = 0..15; one float4 = columns 2q, 2q+1 x both branches
 #pragma unroll
-                for (int v = 1; v < 16; ++v)
+                for (int q = 0; q < 16; ++q) {
+                    const float4 c4 = src[q];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = __builtin_fmaf(x[r + v], tap[v], acc[r]);
-                const int rbase = reduce_branches<G>(acc, u);
-                constexpr int NV = (G == 8) ? 2 : 1;
-                const bool writer = (G == 32) ? ((u & 1) == 0) : true;
-                if (writer) {
+                    for (int h = 0; h < 2; ++h) {
+                        const int j = 2 * q + h;
+                        const float xe = h ? c4.z : c4.x, xo = h ? c4.w : c4.y;
 #pragma unroll
-                    for (int r = 0; r < NV; ++r) {
-                        const int wq = 16 * chunk + rbase + r;
-                        const float s = (wq & 1) ? -sgn_plane : sgn_plane;
-                        s_aux[2 * wq + pl] = s * acc[r];
+                        for (int v = 0; v < 16; ++v) {
+                            const int r = j - v;
+                            if (r >= 0 && r < 16) {
+                                acc[r] = __builtin_fmaf(xe, tap[v].x, acc[r]);
+                                acc[r] = __builtin_fmaf(xo, tap[v].y, acc[r]);
+                            }
+                        }
                     }
+                }
+                const int rbase = reduce_lanes<GL>(acc, k);
+                constexpr int NV = 16 / GL;
+#pragma unroll
+                for (int r = 0; r < NV; ++r) {
+                    const int wq = 16 * chunk + rbase + r;
+                    const float s = (wq & 1) ? -sgn_plane : sgn_plane;
+                    s_aux[2 * wq + pl] = s * acc[r];
                 }
             }
         }
