@@ -52,6 +52,24 @@ class CwslGpuError(RuntimeError):
         super().__init__(f"libcwslgpu: {name}" + (f": {detail}" if detail else ""))
 
 
+class DecoderSpec(C.Structure):
+    _fields_ = [("freq_hz", C.c_uint32), ("calibrated_hz", C.c_uint32), ("mode", C.c_char * 16), ("smnum", C.c_int32),
+                ("freqcal", C.c_double), ("callsign", C.c_char * 16), ("group", C.c_int32),
+                ("frame_len", C.c_uint32), ("period_s", C.c_float)]
+
+
+def parse_decoder_line(line, freqcal_global=1.0):
+    """config.ini `decoder=` value -> dict (CWSL_DIGI.cpp:731-837).  Raises CwslGpuError on the reference's error cases."""
+    L = load_library()
+    sp = DecoderSpec()
+    rc = L.cwslg_parse_decoder_line(line.encode(), float(freqcal_global), C.byref(sp))
+    if rc != 0:
+        raise CwslGpuError(rc, "Error parsing decoder line: " + line)
+    return dict(freq_hz=sp.freq_hz, calibrated_hz=sp.calibrated_hz, mode=sp.mode.decode(), smnum=sp.smnum,
+                freqcal=sp.freqcal, callsign=sp.callsign.decode(), group=sp.group, frame_len=sp.frame_len,
+                period_s=sp.period_s)
+
+
 class Candidate(C.Structure):
     _fields_ = [("freq_bin", C.c_int32), ("time_step", C.c_int32), ("sync", C.c_float),
                 ("freq_hz", C.c_float), ("dt_s", C.c_float)]
@@ -71,7 +89,7 @@ _lib = None
 ABI_SYMBOLS = [
     "cwslg_abi_version", "cwslg_create", "cwslg_destroy", "cwslg_strerror", "cwslg_last_error",
     "cwslg_set_scale_factors", "cwslg_set_exact", "cwslg_receiver_open", "cwslg_receiver_close", "cwslg_push_iq",
-    "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_channel_open", "cwslg_channel_close",
+    "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_parse_decoder_line", "cwslg_channel_open_line", "cwslg_channel_open", "cwslg_channel_close",
     "cwslg_channel_info", "cwslg_process", "cwslg_slot_boundary", "cwslg_slot_boundary_channel",
     "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
     "cwslg_enable_sync", "cwslg_fetch_candidates", "cwslg_sync_debug_fetch", "cwslg_get_stats", "cwslg_reset_stats",
@@ -111,6 +129,8 @@ def load_library(build_if_missing=True):
     L.cwslg_ring_commit.argtypes = [vp, i32, u32, u32]
     L.cwslg_ring_commit_all.argtypes = [vp, u32, u32]
     L.cwslg_ring_info.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(u32), C.POINTER(u64)]
+    L.cwslg_parse_decoder_line.argtypes = [C.c_char_p, C.c_double, C.POINTER(DecoderSpec)]
+    L.cwslg_channel_open_line.argtypes = [vp, i32, C.c_char_p, C.c_double, C.POINTER(i32)]
     L.cwslg_channel_open.argtypes = [vp, i32, C.c_int32, i32, C.c_char_p, C.POINTER(i32)]
     L.cwslg_channel_close.argtypes = [vp, i32]
     L.cwslg_channel_info.argtypes = [vp, i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_size_t)]
@@ -206,6 +226,13 @@ class Context:
         cid = C.c_int(-1)
         self._chk(self.L.cwslg_channel_open(self.h, rx, int(demod_hz), 1 if usb else 0, mode.encode(), C.byref(cid)))
         self._modes[cid.value] = mode
+        return cid.value
+
+    def channel_open_line(self, rx, line, freqcal_global=1.0):
+        """Open a channel from an unchanged config.ini `decoder=` value."""
+        cid = C.c_int(-1)
+        self._chk(self.L.cwslg_channel_open_line(self.h, rx, line.encode(), float(freqcal_global), C.byref(cid)))
+        self._modes[cid.value] = parse_decoder_line(line, freqcal_global)["mode"]
         return cid.value
 
     def channel_close(self, ch):

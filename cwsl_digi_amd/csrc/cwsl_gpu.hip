@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -837,6 +838,93 @@ int cwslg_channel_open(cwslg_ctx *c, int rx_id, int32_t demod_hz, int usb, const
     rx.channels.push_back(id);
     *ch_id = id;
     return CWSLG_OK;
+}
+
+// ---- decoder= lines: the reference's grammar, field for field (CWSL_DIGI.cpp:731-837)
+static bool parse_int_like_stoi(const std::string &t, long long *v)
+{
+    // std::stoi: optional leading whitespace and sign, at least one digit, trailing garbage ignored
+    size_t i = 0;
+    while (i < t.size() && std::isspace((unsigned char)t[i])) ++i;
+    bool neg = false;
+    if (i < t.size() && (t[i] == '+' || t[i] == '-')) { neg = t[i] == '-'; ++i; }
+    if (i >= t.size() || !std::isdigit((unsigned char)t[i])) return false;
+    long long acc = 0;
+    while (i < t.size() && std::isdigit((unsigned char)t[i])) {
+        acc = acc * 10 + (t[i] - '0');
+        if (acc > 2147483648LL) return false;            // out_of_range
+        ++i;
+    }
+    acc = neg ? -acc : acc;
+    if (acc > 2147483647LL || acc < -2147483648LL) return false;
+    *v = acc;
+    return true;
+}
+
+int cwslg_parse_decoder_line(const char *line, double freqcal_global, cwslg_decoder_spec *out)
+{
+    if (!line || !out) return CWSLG_ERR_ARG;
+    std::vector<std::string> f;                           // splitStringByDelim(line, ' '): getline semantics
+    {
+        const std::string in(line);
+        size_t pos = 0;
+        if (!in.empty()) {
+            for (;;) {
+                const size_t sp = in.find(' ', pos);
+                if (sp == std::string::npos) { f.push_back(in.substr(pos)); break; }
+                f.push_back(in.substr(pos, sp - pos));
+                pos = sp + 1;
+                if (pos == in.size()) break;              // getline does not emit a trailing empty field
+            }
+        }
+    }
+    if (f.size() < 2 || f.size() > 5) return CWSLG_ERR_ARG;               // :737-741
+    long long freq = 0;
+    if (!parse_int_like_stoi(f[0], &freq)) return CWSLG_ERR_ARG;          // :742 std::stoi
+    const ModeInfo *mi = find_mode(f[1].c_str());
+    if (!mi) return CWSLG_ERR_MODE;                                       // :797-801 unknown mode
+    std::memset(out, 0, sizeof(*out));
+    out->freq_hz = (uint32_t)(int)freq;
+    std::snprintf(out->mode, sizeof(out->mode), "%s", mi->name);
+    out->smnum = -1;
+    if (f.size() >= 3) {                                                  // :815-817
+        long long sm = 0;
+        if (!parse_int_like_stoi(f[2], &sm)) return CWSLG_ERR_ARG;
+        out->smnum = (int32_t)sm;
+    }
+    out->freqcal = 1.0;
+    if (f.size() >= 4) {                                                  // :819-822 std::stod
+        char *end = nullptr;
+        const double v = std::strtod(f[3].c_str(), &end);
+        if (end == f[3].c_str()) return CWSLG_ERR_ARG;
+        out->freqcal = v;
+    }
+    if (f.size() >= 5) {                                                  // :824-830
+        if (std::strcmp(mi->name, "WSPR") != 0) return CWSLG_ERR_ARG;     // "Callsigns are only supported per-decoder for WSPR decoders"
+        std::snprintf(out->callsign, sizeof(out->callsign), "%s", f[4].c_str());
+    }
+    out->calibrated_hz = (uint32_t)((double)out->freq_hz / (freqcal_global * out->freqcal));   // :834
+    out->group = mi->group;
+    out->frame_len = (uint32_t)frame_length(*mi);
+    out->period_s = mi->period_s;
+    return CWSLG_OK;
+}
+
+int cwslg_channel_open_line(cwslg_ctx *c, int rx_id, const char *line, double freqcal_global, int *ch_id)
+{
+    if (!c || !ch_id) return CWSLG_ERR_ARG;
+    cwslg_decoder_spec spec;
+    int rc = cwslg_parse_decoder_line(line, freqcal_global, &spec);
+    if (rc) return fail(c, rc, "Error parsing decoder line: %s", line ? line : "(null)");
+    int32_t lo = 0;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        if (rx_id < 0 || rx_id >= (int)c->rxs.size() || !c->rxs[rx_id].open) return fail(c, CWSLG_ERR_ARG, "bad receiver id");
+        lo = c->rxs[rx_id].lo_hz;
+    }
+    // Instance.cpp:183 : int32 demodFreq = calibratedSSBFreq - LO (both uint32 in the reference)
+    const int32_t demod = (int32_t)(spec.calibrated_hz - (uint32_t)lo);
+    return cwslg_channel_open(c, rx_id, demod, 1, spec.mode, ch_id);
 }
 
 int cwslg_channel_close(cwslg_ctx *c, int ch_id)

@@ -118,6 +118,25 @@ int cwslg_channel_close(cwslg_ctx *ctx, int ch_id);
 int cwslg_channel_info(cwslg_ctx *ctx, int ch_id, uint32_t *in_size, uint32_t *out_size,
                        uint32_t *out_rate, uint32_t *delay, size_t *frame_len);
 
+/* ---- config.ini `decoder=` lines (source/CWSL_DIGI.cpp:731-837), accepted unchanged ----
+ * "<freqHz> <MODE> [smnum [freqcal [callsign]]]" split on single spaces exactly like splitStringByDelim
+ * (StringUtils.hpp:48-66: consecutive spaces yield empty fields), 2..5 fields, callsign only for WSPR.
+ * calibrated_hz = (uint32)(freq / (freqcal_global * freqcal)) (:834).  No context needed. */
+typedef struct {
+    uint32_t freq_hz;          /* dial frequency as written                                   */
+    uint32_t calibrated_hz;    /* what Instance tunes to (before subtracting the LO)          */
+    char     mode[16];
+    int32_t  smnum;            /* shared-memory interface number, -1 if not given (use radio.sharedmem) */
+    double   freqcal;          /* per-decoder calibration factor (default 1.0)                */
+    char     callsign[16];     /* per-decoder callsign (WSPR only), "" if not given           */
+    int32_t  group;            /* CWSLG_GROUP_* of the mode                                   */
+    uint32_t frame_len;        /* 12000*(period+5)                                            */
+    float    period_s;
+} cwslg_decoder_spec;
+int cwslg_parse_decoder_line(const char *line, double freqcal_global, cwslg_decoder_spec *out);
+/* Parse + open in one step: demod_hz = calibrated_hz - lo_hz of the receiver (Instance.cpp:183), USB. */
+int cwslg_channel_open_line(cwslg_ctx *ctx, int rx_id, const char *line, double freqcal_global, int *ch_id);
+
 /* ---- processing ----
  * Demodulate everything pushed so far for every channel (enqueued on the context stream; returns
  * without waiting).  push/slot_boundary/fetch call it implicitly when they have to. */

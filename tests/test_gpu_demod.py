@@ -247,3 +247,18 @@ def test_synth_source_matches_oracle_and_private_streams(ctx, oracle):
         g = ctx.fetch_frame(ch)
         assert_frames_match(a, r["f32"])
         assert_int16_match(g["i16"], r["i16"], r["f32"] * r["factor"])
+
+
+def test_channel_from_unchanged_decoder_line(ctx, oracle):
+    """`decoder=28074000 FT8` on a receiver whose LO is 28.1 MHz tunes demod_hz = -26000 (Instance.cpp:183)."""
+    n = 40 * IQ_LEN
+    iq = oracle.synth_iq(8, n, FS, tones_hz=[-26000 + 1200.0], amp=1e4)
+    rx = ctx.receiver_open(FS, IQ_LEN, 28100000)
+    a = ctx.channel_open_line(rx, "28074000 FT8")
+    b = ctx.channel_open(rx, -26000, "FT8")
+    ctx.slot_boundary("FT8", 1); ctx.push_iq(rx, iq); ctx.slot_boundary("FT8", 2)
+    fa, fb = ctx.fetch_frame(a), ctx.fetch_frame(b)
+    assert np.array_equal(fa["i16"], fb["i16"]) and fa["i16"].any()
+    ref = oracle.Channel("FT8", FS, IQ_LEN, -26000); ref.boundary(1); ref.push_many(iq)
+    r = ref.boundary(2, want_f32=True)
+    assert_int16_match(fa["i16"], r["i16"], r["f32"] * r["factor"])
