@@ -92,7 +92,7 @@ ABI_SYMBOLS = [
     "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_parse_decoder_line", "cwslg_channel_open_line", "cwslg_channel_open", "cwslg_channel_close",
     "cwslg_channel_info", "cwslg_process", "cwslg_slot_boundary", "cwslg_slot_boundary_channel",
     "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
-    "cwslg_enable_sync", "cwslg_fetch_candidates", "cwslg_sync_debug_fetch", "cwslg_get_stats", "cwslg_reset_stats",
+    "cwslg_enable_sync", "cwslg_fetch_candidates", "cwslg_set_ft4_syncmin", "cwslg_sync_debug_fetch", "cwslg_get_stats", "cwslg_reset_stats",
     "cwslg_set_timing", "cwslg_stream", "cwslg_channel_constants", "cwslg_channel_phasor_checkpoints",
 ]
 
@@ -143,6 +143,7 @@ def load_library(build_if_missing=True):
     L.cwslg_frame_device_ptrs.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
     L.cwslg_enable_sync.argtypes = [vp, i32, f32, i32, i32, i32]
     L.cwslg_fetch_candidates.argtypes = [vp, i32, C.POINTER(Candidate), i32, C.POINTER(i32)]
+    L.cwslg_set_ft4_syncmin.argtypes = [vp, f32]
     L.cwslg_sync_debug_fetch.argtypes = [vp, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i32)]
     L.cwslg_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.cwslg_reset_stats.argtypes = [vp]
@@ -293,14 +294,18 @@ class Context:
         self._chk(self.L.cwslg_fetch_candidates(self.h, ch, buf, max_cand, C.byref(n)))
         return [(buf[k].freq_bin, buf[k].time_step, buf[k].sync, buf[k].freq_hz, buf[k].dt_s) for k in range(n.value)]
 
+    def set_ft4_syncmin(self, syncmin=1.2):
+        self._chk(self.L.cwslg_set_ft4_syncmin(self.h, syncmin))
+
     def sync_debug(self, ch, what):
-        """what: 'spectra' -> float32[372, nbins]; 'red'/'red2' -> float32[1921]; 'jpeak'/'jpeak2' -> int32[1921]."""
+        """what: 'spectra' -> float32[steps, row]; 'red'/'red2' -> float32[1921]; 'jpeak'/'jpeak2' -> int32[1921].
+        FT4 channels: 'red' = savsm/sbase, 'red2' = sbase (first 1153 entries meaningful)."""
         sel = {"spectra": 0, "red": 1, "red2": 2, "jpeak": 3, "jpeak2": 4}[what]
         buf = np.empty(372 * 1936 if sel == 0 else 1921, np.float32 if sel < 3 else np.int32)
         n, row = C.c_size_t(), C.c_int()
         self._chk(self.L.cwslg_sync_debug_fetch(self.h, ch, sel, buf.ctypes.data, buf.nbytes, C.byref(n), C.byref(row)))
         buf = buf[: n.value]
-        return buf.reshape(372, row.value) if sel == 0 else buf
+        return buf.reshape(-1, row.value) if sel == 0 else buf
 
     def stats(self):
         s = Stats()

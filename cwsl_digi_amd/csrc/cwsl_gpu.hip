@@ -655,10 +655,28 @@ static int push_prologue(cwslg_ctx *c, int rx_id, uint32_t n, Receiver **out)
     return CWSLG_OK;
 }
 
+static int push_iq_locked(cwslg_ctx *c, int rx_id, const float *iq, uint32_t n);
+
 int cwslg_push_iq(cwslg_ctx *c, int rx_id, const float *iq, uint32_t n)
 {
     if (!c || !iq) return CWSLG_ERR_ARG;
     std::lock_guard<std::mutex> g(c->mu);
+    if (rx_id < 0 || rx_id >= (int)c->rxs.size() || !c->rxs[rx_id].open) return fail(c, CWSLG_ERR_ARG, "bad receiver id");
+    // a push larger than the ring is fed through it in ring-sized pieces (whole Receiver blocks)
+    const Receiver &r = c->rxs[rx_id];
+    const uint32_t piece = std::max<uint32_t>(r.iq_len, (r.cap / 2) / r.iq_len * r.iq_len);
+    uint32_t done = 0;
+    while (done < n) {
+        const uint32_t m = std::min(piece, n - done);
+        int rc = push_iq_locked(c, rx_id, iq + 2 * (size_t)done, m);
+        if (rc) return rc;
+        done += m;
+    }
+    return CWSLG_OK;
+}
+
+static int push_iq_locked(cwslg_ctx *c, int rx_id, const float *iq, uint32_t n)
+{
     Receiver *rx = nullptr;
     int rc = push_prologue(c, rx_id, n, &rx);
     if (rc) return rc;

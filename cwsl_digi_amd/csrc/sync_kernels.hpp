@@ -9,7 +9,7 @@
 // fixed, so the candidate lists are BIT-IDENTICAL to that restatement (tests/test_gpu_sync.py).
 //
 // Three launches per slot boundary, all channels of the group batched in each:
-//   ft8_spectra_kernel    one workgroup per (symbol step, channel): 1920 int16 -> packed 1920-point complex
+//   symbol_spectra_kernel one workgroup per (symbol step, channel): 1920 int16 -> packed 1920-point complex
 //                         FFT (15 x 128: 15-point DFTs + radix-2 DIT butterflies in LDS) -> |X|^2 rows
 //   ft8_sync2d_kernel     one workgroup per (32-bin band, channel): band of the spectra staged in LDS once,
 //                         lane = time lag, Costas correlation for 125 lags, wavefront-shuffle arg-max for the
@@ -26,6 +26,9 @@
 namespace cwslg {
 
 constexpr int FT8_NSPS = 1920, FT8_NSTEP = 480, FT8_NHSYM = 372, FT8_NH1 = 1920, FT8_JZ = 62, FT8_NMAX = 180000;
+// FT4 (getcandidates4.f90, ft4_params.f90): Nuttall-windowed 2304-point spectra every 576 samples
+constexpr int FT4_NFFT1 = 2304, FT4_NSTEP = 576, FT4_NHSYM = 122, FT4_NH1 = 1152, FT4_NMAX = 72576;
+constexpr int FT4_ROW = 1168;           // stored row length (bins 0..1152, padded to a multiple of 16)
 constexpr int SYNC_BAND = 32;           // bins per sync2d workgroup
 constexpr int SYNC_MAXCAND_CAP = 600;   // MAXCAND of the upstream decoder
 constexpr int SYNC_MAXPRE = 1000;       // MAXPRECAND of sync8.f90: pre-candidates before de-duplication
@@ -33,18 +36,22 @@ constexpr int SYNC_MAXPRE = 1000;       // MAXPRECAND of sync8.f90: pre-candidat
 struct SyncConfig {
     bool enabled = false;
     float syncmin = 1.5f;
+    float syncmin_ft4 = 1.2f;             // ft4_decode's threshold for getcandidates4
     int max_cand = 200;
     int f_lo_hz = 200, f_hi_hz = 3000;
     int ia = 64, ib = 960, nbins = 976;   // derived: bin range and stored row length (ib+13 rounded up to 16)
 };
 
-struct SyncTables {                       // device pointers
+struct SyncTables {                       // device pointers: W_NA, W_NZ, W_128, W_2NZ twiddles, optional window
     const float2 *w15, *w1920, *w128, *w3840;
+    const float *win;
 };
 
 struct SyncShared {
-    float2 *d_tables = nullptr;           // w15[15] | w1920[1920] | w128[64] | w3840[1921]
-    SyncTables t{};
+    float2 *d_tables = nullptr;           // FT8: w15[15] | w1920[1920] | w128[64] | w3840[1921] ; FT4: w9[9] | w1152[1152] | w2304[1153]
+    float *d_win = nullptr;               // Nuttall window, 2304 floats
+    SyncTables t{};                       // FT8 set
+    SyncTables t4{};                      // FT4 set (w15 -> W_9, w1920 -> W_1152, w3840 -> W_2304)
 };
 
 struct SyncChannelBuffers {
@@ -55,6 +62,7 @@ struct SyncChannelBuffers {
     struct Cand { int freq_bin, time_step; float sync, freq_hz, dt_s; } *d_cand = nullptr;   // [max_cand]
     int *d_ncand = nullptr;
     int nbins = 0, max_cand = 0;
+    bool ft4 = false;                     // FT4 layout: spectra [122][FT4_ROW]; red = normalised savsm, red2 = sbase
 };
 
 struct alignas(16) SyncWork {
@@ -74,6 +82,7 @@ inline void sync_free_channel(SyncChannelBuffers &b)
 inline void sync_free_shared(SyncShared &s)
 {
     if (s.d_tables) (void)hipFree(s.d_tables);
+    if (s.d_win) (void)hipFree(s.d_win);
     s = SyncShared();
 }
 
@@ -96,41 +105,39 @@ __device__ __forceinline__ float2 cmul_u(float2 a, float2 b)          // un-fuse
 constexpr int SY_PITCH = 129;
 __device__ __forceinline__ int sy_col(int i) { return i ^ ((i >> 3) & 7); }
 
-template <int CH>
-__device__ __forceinline__ void spectra_stage1(const float *s_x, float2 (*s_y)[SY_PITCH], const float2 *s_w15,
-                                               const float2 *__restrict__ w1920, int b)
+// NA = 15 (FT8: 1920 = 15 x 128, only the first NPACK = 960 packed inputs are non-zero) or 9 (FT4: 1152 = 9 x 128)
+template <int CH, int NA, int NPACK>
+__device__ __forceinline__ void spectra_stage1(const float *s_x, float2 (*s_y)[SY_PITCH], const float2 *s_wa,
+                                               const float2 *__restrict__ wn, int b)
 {
-    float2 z[8];
+    constexpr int AMAX = (NPACK + 127) / 128;            // 8 (FT8), 9 (FT4)
+    constexpr int NC = (NA - CH + 1) / 2;                // outputs c = CH, CH+2, ... handled by this half
+    float2 z[AMAX];
 #pragma unroll
-    for (int a = 0; a < 8; ++a) {
+    for (int a = 0; a < AMAX; ++a) {
         const int m = 128 * a + b;
-        z[a] = (m < 960) ? make_float2(s_x[2 * m], s_x[2 * m + 1]) : make_float2(0.f, 0.f);
+        z[a] = (m < NPACK) ? make_float2(s_x[2 * m], s_x[2 * m + 1]) : make_float2(0.f, 0.f);
     }
-    const bool a7 = (128 * 7 + b) < 960;
-    float2 tw[8];
+    const bool last_ok = (128 * (AMAX - 1) + b) < NPACK;
+    float2 tw[NC];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < NC; ++i) tw[i] = wn[b * (CH + 2 * i)];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
         const int c = CH + 2 * i;
-        tw[i] = (c < 15) ? w1920[b * c] : make_float2(0.f, 0.f);
-    }
+        float2 acc = z[0];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = CH + 2 * i;
-        if (c < 15) {
-            float2 acc = z[0];
-#pragma unroll
-            for (int a = 1; a < 7; ++a) {
-                const float2 p = cmul_u(z[a], s_w15[(a * c) % 15]);
-                acc.x = acc.x + p.x;
-                acc.y = acc.y + p.y;
-            }
-            if (a7) {
-                const float2 p = cmul_u(z[7], s_w15[(7 * c) % 15]);
-                acc.x = acc.x + p.x;
-                acc.y = acc.y + p.y;
-            }
-            s_y[c][b] = cmul_u(acc, tw[i]);        // natural order; pass A gathers the bit-reversed inputs
+        for (int a = 1; a < AMAX - 1; ++a) {
+            const float2 p = cmul_u(z[a], s_wa[(a * c) % NA]);
+            acc.x = acc.x + p.x;
+            acc.y = acc.y + p.y;
         }
+        if (last_ok) {
+            const float2 p = cmul_u(z[AMAX - 1], s_wa[((AMAX - 1) * c) % NA]);
+            acc.x = acc.x + p.x;
+            acc.y = acc.y + p.y;
+        }
+        s_y[c][b] = cmul_u(acc, tw[i]);        // natural order; pass A gathers the bit-reversed inputs
     }
 }
 
@@ -144,35 +151,42 @@ __device__ __forceinline__ void bfly(float2 &u, float2 &v, float2 w)
     v = d;
 }
 
-__global__ __launch_bounds__(256) void ft8_spectra_kernel(const SyncWork *__restrict__ works, SyncTables tb, int nbins)
+// NA rows x 128: FT8 <15, 1920, 480, false>, FT4 <9, 2304, 576, true>.  grid (symbol steps, channels), 256 threads.
+template <int NA, int NIN, int STEP, bool WINDOW>
+__global__ __launch_bounds__(256) void symbol_spectra_kernel(const SyncWork *__restrict__ works, SyncTables tb, int nbins)
 {
-    __shared__ float s_x[FT8_NSPS];
-    __shared__ float2 s_y[15][SY_PITCH];
-    __shared__ float2 s_w15[16];
+    constexpr int NZ = NA * 128;                          // packed complex length; real transform length 2*NZ
+    constexpr int NPACK = NIN / 2;                        // non-zero packed inputs
+    constexpr int NGRP = NA * 16;                         // 8-point groups per pass
+    static_assert(NGRP <= 256 && NIN % 8 == 0, "geometry");
+    __shared__ float s_x[NIN];
+    __shared__ float2 s_y[NA][SY_PITCH];
+    __shared__ float2 s_wa[16];
     __shared__ float2 s_w128[64];
     const SyncWork *w = works + blockIdx.y;
     const int j = blockIdx.x;
     const int tid = threadIdx.x;
-    const int16_t *d = w->frame + (size_t)FT8_NSTEP * j;
+    const int16_t *d = w->frame + (size_t)STEP * j;
     const float fac = 1.0f / 300.0f;
-    {   // 1920 int16 = 240 x 16 B
-        if (tid < 240) {
-            const uint4 q = reinterpret_cast<const uint4 *>(d)[tid];
-            const unsigned v[4] = {q.x, q.y, q.z, q.w};
+    for (int t = tid; t < NIN / 8; t += 256) {            // 16 B = 8 samples per lane
+        const uint4 q = reinterpret_cast<const uint4 *>(d)[t];
+        const unsigned v[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                s_x[8 * tid + 2 * k] = fac * (float)(short)(v[k] & 0xFFFFu);
-                s_x[8 * tid + 2 * k + 1] = fac * (float)(short)(v[k] >> 16);
-            }
+        for (int k = 0; k < 4; ++k) {
+            float lo = fac * (float)(short)(v[k] & 0xFFFFu);
+            float hi = fac * (float)(short)(v[k] >> 16);
+            if (WINDOW) { lo = lo * tb.win[8 * t + 2 * k]; hi = hi * tb.win[8 * t + 2 * k + 1]; }
+            s_x[8 * t + 2 * k] = lo;
+            s_x[8 * t + 2 * k + 1] = hi;
         }
-        if (tid < 15) s_w15[tid] = tb.w15[tid];
-        if (tid >= 64 && tid < 128) s_w128[tid - 64] = tb.w128[tid - 64];
     }
+    if (tid < NA) s_wa[tid] = tb.w15[tid];
+    if (tid >= 64 && tid < 128) s_w128[tid - 64] = tb.w128[tid - 64];
     __syncthreads();
 
-    // stage 1 (wave-uniform split of the 15 outputs c: even c on waves 0-1, odd c on waves 2-3)
-    if (tid < 128) spectra_stage1<0>(s_x, s_y, s_w15, tb.w1920, tid & 127);
-    else spectra_stage1<1>(s_x, s_y, s_w15, tb.w1920, tid & 127);
+    // stage 1 (wave-uniform split of the NA outputs c: even c on waves 0-1, odd c on waves 2-3)
+    if (tid < 128) spectra_stage1<0, NA, NPACK>(s_x, s_y, s_wa, tb.w1920, tid & 127);
+    else spectra_stage1<1, NA, NPACK>(s_x, s_y, s_wa, tb.w1920, tid & 127);
     __syncthreads();
 
     // stage 2, pass A: DIT stages len = 2,4,8 on logical points 8g..8g+7 of row c; the DIT input order is
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(256) void ft8_spectra_kernel(const SyncWork *__rest
         const int c = tid >> 4, g = tid & 15;
         const int gb = (int)(__brev((unsigned)g) >> 28);
         float2 e[8];
-        if (tid < 240) {
+        if (tid < NGRP) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int k3 = ((k & 1) << 2) | (k & 2) | ((k >> 2) & 1);
@@ -189,36 +203,30 @@ __global__ __launch_bounds__(256) void ft8_spectra_kernel(const SyncWork *__rest
             }
         }
         __syncthreads();                     // everyone has gathered: the image may now be rewritten
-        if (tid < 240) {
-            // len 2: pairs (0,1)(2,3)(4,5)(6,7), twiddle W128^0
+        if (tid < NGRP) {
             bfly(e[0], e[1], s_w128[0]); bfly(e[2], e[3], s_w128[0]); bfly(e[4], e[5], s_w128[0]); bfly(e[6], e[7], s_w128[0]);
-            // len 4: pairs (0,2)(1,3)(4,6)(5,7), twiddles W128^(k*32)
             bfly(e[0], e[2], s_w128[0]); bfly(e[1], e[3], s_w128[32]); bfly(e[4], e[6], s_w128[0]); bfly(e[5], e[7], s_w128[32]);
-            // len 8: pairs (k, k+4), twiddles W128^(k*16)
             bfly(e[0], e[4], s_w128[0]); bfly(e[1], e[5], s_w128[16]); bfly(e[2], e[6], s_w128[32]); bfly(e[3], e[7], s_w128[48]);
 #pragma unroll
             for (int k = 0; k < 8; ++k) s_y[c][sy_col(8 * g + k)] = e[k];
         }
     }
     __syncthreads();
-    // pass B: stages len = 16,32,64 on logical points {64 blk + r + 8 q : q<8}; groups: 15 x 2 blocks x 8 r
-    if (tid < 240) {
+    // pass B: stages len = 16,32,64 on logical points {64 blk + r + 8 q : q<8}; groups: NA x 2 blocks x 8 r
+    if (tid < NGRP) {
         const int c = tid >> 4, g = tid & 15;
         const int blk = g >> 3, r = g & 7;
         float2 e[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) e[q] = s_y[c][sy_col(64 * blk + r + 8 * q)];
-        // len 16: index i = r + 8q, pairs differ in q bit0: k = i mod 8 = r, twiddle W128^(r*8)
         {
             const float2 w0 = s_w128[r * 8];
             bfly(e[0], e[1], w0); bfly(e[2], e[3], w0); bfly(e[4], e[5], w0); bfly(e[6], e[7], w0);
         }
-        // len 32: pairs differ in q bit1: k = i mod 16 = r + 8*(q&1), twiddle W128^(k*4)
         {
             const float2 w0 = s_w128[r * 4], w1 = s_w128[(r + 8) * 4];
             bfly(e[0], e[2], w0); bfly(e[1], e[3], w1); bfly(e[4], e[6], w0); bfly(e[5], e[7], w1);
         }
-        // len 64: pairs differ in q bit2: k = i mod 32 = r + 8*(q&3), twiddle W128^(k*2)
         {
             bfly(e[0], e[4], s_w128[r * 2]); bfly(e[1], e[5], s_w128[(r + 8) * 2]);
             bfly(e[2], e[6], s_w128[(r + 16) * 2]); bfly(e[3], e[7], s_w128[(r + 24) * 2]);
@@ -227,8 +235,8 @@ __global__ __launch_bounds__(256) void ft8_spectra_kernel(const SyncWork *__rest
         for (int q = 0; q < 8; ++q) s_y[c][sy_col(64 * blk + r + 8 * q)] = e[q];
     }
     __syncthreads();
-    // pass C: stage len = 128: pairs (k, k+64), twiddle W128^k ; 960 butterflies
-    for (int idx = tid; idx < 960; idx += 256) {
+    // pass C: stage len = 128: pairs (k, k+64), twiddle W128^k ; NA*64 butterflies
+    for (int idx = tid; idx < NA * 64; idx += 256) {
         const int c = idx >> 6, k = idx & 63;
         float2 u = s_y[c][sy_col(k)], v = s_y[c][sy_col(k + 64)];
         bfly(u, v, s_w128[k]);
@@ -241,10 +249,10 @@ __global__ __launch_bounds__(256) void ft8_spectra_kernel(const SyncWork *__rest
     float *out = w->spectra + (size_t)j * nbins;
     for (int k = tid; k < nbins; k += 256) {
         float pw = 0.0f;
-        if (k <= FT8_NH1) {
-            const int k2 = (1920 - k) % 1920, kk = k % 1920;
-            const float2 A = s_y[kk % 15][sy_col(kk / 15)];
-            float2 B = s_y[k2 % 15][sy_col(k2 / 15)];
+        if (k <= NZ) {
+            const int k2 = (NZ - k) % NZ, kk = k % NZ;
+            const float2 A = s_y[kk % NA][sy_col(kk / NA)];
+            float2 B = s_y[k2 % NA][sy_col(k2 / NA)];
             B.y = -B.y;
             const float er = (A.x + B.x) * 0.5f, ei = (A.y + B.y) * 0.5f;
             const float2 o = make_float2((A.x - B.x) * 0.5f, (A.y - B.y) * 0.5f);
@@ -623,6 +631,238 @@ __global__ __launch_bounds__(256) void ft8_candidates_kernel(const SyncWork *__r
     if (nout) atomicAdd(&s_n, nout);
     __syncthreads();
     if (tid == 0) *w->ncand = min(s_n, maxcand);
+}
+
+// ---------------------------------------------------------------------------------------------
+// FT4 candidate search (getcandidates4.f90 + ft4_baseline.f90), one workgroup per channel.  PARITY UNPINNED by the
+// reference; bit-exact against oracle/sync_oracle.c, whose builder-defined pieces are mirrored here operation for
+// operation: fixed-series double log10 / 10^x, 5x5 normal equations in the scaled variable, Gaussian elimination
+// with partial pivoting.
+__device__ __forceinline__ double log10_fixed(double x)
+{
+    if (!(x > 0.0)) return -1.0e300;
+    int e = 0;
+    double m = x;
+    while (m >= 1.4142135623730951) { m = m * 0.5; ++e; }
+    while (m < 0.7071067811865476) { m = m * 2.0; --e; }
+    const double t = (m - 1.0) / (m + 1.0), t2 = t * t;
+    double s = 0.0;
+    for (int k = 21; k >= 1; k -= 2) s = s * t2 + 1.0 / (double)k;
+    const double ln_m = 2.0 * t * s;
+    return ((double)e * 0.6931471805599453 + ln_m) * 0.4342944819032518;
+}
+__device__ __forceinline__ double exp10_fixed(double y)
+{
+    const double z = y * 3.321928094887362;
+    double fl = (double)(long long)z;
+    if (fl > z) fl = fl - 1.0;
+    const double f = (z - fl) * 0.6931471805599453;
+    double s = 1.0;
+    for (int k = 22; k >= 1; --k) s = 1.0 + s * f / (double)k;
+    long long n = (long long)fl;
+    double p = 1.0;
+    if (n >= 0) { for (long long q = 0; q < n && q < 2000; ++q) p = p * 2.0; }
+    else { for (long long q = 0; q < -n && q < 2000; ++q) p = p * 0.5; }
+    return s * p;
+}
+
+__global__ __launch_bounds__(256) void ft4_candidates_kernel(const SyncWork *__restrict__ works, int nfa, int nfb,
+                                                              float syncmin, int maxcand)
+{
+    constexpr int NB1 = FT4_NH1 + 1;
+    __shared__ float s_savg[NB1], s_savsm[NB1], s_sdb[NB1], s_sbase[NB1];
+    __shared__ float s_segbase[10];
+    __shared__ double s_a[5];
+    __shared__ int s_scan[256];
+    __shared__ int s_ok;
+    __shared__ int s_cbin[SYNC_MAXCAND_CAP];
+    __shared__ float s_cs[SYNC_MAXCAND_CAP], s_cf[SYNC_MAXCAND_CAP];
+    __shared__ unsigned s_hi[1024], s_lo[1024];
+    const SyncWork *w = works + blockIdx.x;
+    const int tid = threadIdx.x;
+    const float *sp = w->spectra;
+    const float df = 12000.0f / (float)FT4_NFFT1;
+    // averaged spectrum: sum over the 122 symbol steps in order, then /NHSYM
+    for (int i = tid; i < NB1; i += 256) {
+        float acc = 0.0f;
+        if (i >= 1) {
+            for (int j = 0; j < FT4_NHSYM; ++j) acc = acc + sp[(size_t)j * FT4_ROW + i];
+            acc = acc / (float)FT4_NHSYM;
+        }
+        s_savg[i] = acc; s_sbase[i] = 0.0f; s_sdb[i] = 0.0f;
+    }
+    if (tid == 0) s_ok = 1;
+    __syncthreads();
+    for (int i = tid; i < NB1; i += 256) {
+        float t = 0.0f;
+        if (i >= 8 && i <= FT4_NH1 - 7) {
+#pragma unroll
+            for (int q = -7; q <= 7; ++q) t = t + s_savg[i + q];
+            t = t / 15.0f;
+        }
+        s_savsm[i] = t;
+    }
+    const int ia = nfa, ib = min(nfb, FT4_NH1);
+    const int nseg = 10;
+    const int nlen = (ib - ia + 1) / nseg, i0 = (ib - ia + 1) / 2;
+    const double half = (double)(ib - ia + 1) / 2.0;
+    const bool range_ok = (nfb - nfa) >= 20;
+    if (!range_ok) { if (tid == 0) *w->ncand = 0; return; }
+    for (int i = ia + tid; i <= ib; i += 256) s_sdb[i] = (float)(10.0 * log10_fixed((double)s_savg[i]));
+    __syncthreads();
+    // 10th percentile of each of the 10 segments (rank of every element inside its segment)
+    {
+        int jp = (int)lroundf(((float)nlen * 0.01f) * 10.0f);
+        if (jp < 1) jp = 1;
+        if (jp > nlen) jp = nlen;
+        for (int e = tid; e < nseg * nlen; e += 256) {
+            const int seg = e / nlen, q = e - seg * nlen;
+            const int ja = ia + seg * nlen;
+            const float v = s_sdb[ja + q];
+            int less = 0, eq = 0;
+            for (int x = 0; x < nlen; ++x) {
+                const float o = s_sdb[ja + x];
+                less += (o < v) ? 1 : 0;
+                eq += (o == v) ? 1 : 0;
+            }
+            if (less <= jp - 1 && jp - 1 < less + eq) s_segbase[seg] = v;
+        }
+    }
+    __syncthreads();
+    // lower-envelope points in order -> normal equations -> 5 coefficients (serial: ~100 points, 5x5 system)
+    if (tid == 0) {
+        double S[9], Tm[5];
+        for (int q = 0; q < 9; ++q) S[q] = 0.0;
+        for (int q = 0; q < 5; ++q) Tm[q] = 0.0;
+        int kz = 0;
+        for (int n = 0; n < nseg; ++n) {
+            const int ja = ia + n * nlen, jb = ja + nlen - 1;
+            const float base = s_segbase[n];
+            for (int i = ja; i <= jb; ++i) {
+                if (s_sdb[i] <= base && kz < 1000) {
+                    ++kz;
+                    const double u = (double)(i - i0) / half, y = (double)s_sdb[i];
+                    double p = 1.0;
+                    for (int q = 0; q < 9; ++q) { S[q] = S[q] + p; if (q < 5) Tm[q] = Tm[q] + y * p; p = p * u; }
+                }
+            }
+        }
+        int ok = kz >= 5;
+        double A[5][6];
+        for (int r = 0; r < 5; ++r) { for (int cc = 0; cc < 5; ++cc) A[r][cc] = S[r + cc]; A[r][5] = Tm[r]; }
+        for (int col = 0; col < 5 && ok; ++col) {
+            int piv = col;
+            for (int r = col + 1; r < 5; ++r) if (fabs(A[r][col]) > fabs(A[piv][col])) piv = r;
+            if (A[piv][col] == 0.0) { ok = 0; break; }
+            if (piv != col) for (int cc = 0; cc < 6; ++cc) { const double t = A[col][cc]; A[col][cc] = A[piv][cc]; A[piv][cc] = t; }
+            for (int r = col + 1; r < 5; ++r) {
+                const double f = A[r][col] / A[col][col];
+                for (int cc = col; cc < 6; ++cc) A[r][cc] = A[r][cc] - f * A[col][cc];
+            }
+        }
+        double a[5] = {0, 0, 0, 0, 0};
+        if (ok) {
+            for (int r = 4; r >= 0; --r) {
+                double t = A[r][5];
+                for (int cc = r + 1; cc < 5; ++cc) t = t - A[r][cc] * a[cc];
+                a[r] = t / A[r][r];
+            }
+        }
+        for (int q = 0; q < 5; ++q) s_a[q] = a[q];
+        s_ok = ok;
+    }
+    __syncthreads();
+    if (!s_ok) { if (tid == 0) *w->ncand = 0; return; }
+    int bad = 0;
+    for (int i = ia + tid; i <= ib; i += 256) {
+        const double u = (double)(i - i0) / half;
+        const float db = (float)(s_a[0] + u * (s_a[1] + u * (s_a[2] + u * (s_a[3] + u * s_a[4]))) + 0.65);
+        const float b = (float)exp10_fixed((double)db / 10.0);
+        s_sbase[i] = b;
+        if (!(b > 0.0f)) bad = 1;
+    }
+    if (__syncthreads_or(bad)) { if (tid == 0) *w->ncand = 0; return; }
+    for (int i = nfa + tid; i <= nfb; i += 256) s_savsm[i] = s_savsm[i] / s_sbase[i];
+    __syncthreads();
+    for (int i = tid; i < NB1; i += 256) { w->red[i] = s_savsm[i]; w->red2[i] = s_sbase[i]; }   // for parity tests
+    // local maxima, ascending bin, first maxcand kept
+    constexpr int PER = 5;
+    const float f_offset = -1.5f * 12000.0f / 576.0f;
+    float spk[PER], fpk[PER];
+    int flg[PER];
+    int local = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int i = tid * PER + q;
+        flg[q] = 0;
+        if (i >= nfa + 1 && i <= nfb - 1) {
+            const float c = s_savsm[i], l = s_savsm[i - 1], r = s_savsm[i + 1];
+            if (c >= l && c >= r && c >= syncmin) {
+                const float den = l - 2.0f * c + r;
+                float del = 0.0f;
+                if (den != 0.0f) del = 0.5f * (l - r) / den;
+                const float fpeak = ((float)i + del) * df + f_offset;
+                if (!(fpeak < 200.0f || fpeak > 4910.0f)) {
+                    flg[q] = 1;
+                    fpk[q] = fpeak;
+                    spk[q] = c - 0.25f * (l - r) * del;
+                }
+            }
+        }
+        local += flg[q];
+    }
+    s_scan[tid] = local;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = (tid >= off) ? s_scan[tid - off] : 0;
+        __syncthreads();
+        s_scan[tid] += v;
+        __syncthreads();
+    }
+    int pos = s_scan[tid] - local;
+    const int keep = min(maxcand, SYNC_MAXCAND_CAP);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        if (flg[q]) {
+            if (pos < keep) { s_cbin[pos] = tid * PER + q; s_cs[pos] = spk[q]; s_cf[pos] = fpk[q]; }
+            ++pos;
+        }
+    }
+    const int ncand = min(s_scan[255], keep);
+    __syncthreads();
+    // descending height, ties by ascending bin
+    for (int i = tid; i < 1024; i += 256) {
+        unsigned hi = 0xFFFFFFFFu, lo = 0xFFFFFFFFu;
+        if (i < ncand) {
+            unsigned u = __float_as_uint(s_cs[i]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            hi = ~u;
+            lo = ((unsigned)s_cbin[i] << 12) | (unsigned)i;
+        }
+        s_hi[i] = hi; s_lo[i] = lo;
+    }
+    __syncthreads();
+    for (int size = 2; size <= 1024; size <<= 1) {
+        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+            for (int t = tid; t < 512; t += 256) {
+                const int l0 = 2 * t - (t & (stride - 1));
+                const int h0 = l0 + stride;
+                const bool up = (l0 & size) == 0;
+                const unsigned long long ka = ((unsigned long long)s_hi[l0] << 32) | s_lo[l0];
+                const unsigned long long kb = ((unsigned long long)s_hi[h0] << 32) | s_lo[h0];
+                const bool sw = up ? (kb < ka) : (ka < kb);
+                if (sw) { s_hi[l0] = (unsigned)(kb >> 32); s_lo[l0] = (unsigned)kb; s_hi[h0] = (unsigned)(ka >> 32); s_lo[h0] = (unsigned)ka; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int r = tid; r < ncand; r += 256) {
+        const int i = (int)(s_lo[r] & 0xFFFu);
+        SyncChannelBuffers::Cand c;
+        c.freq_bin = s_cbin[i]; c.time_step = 0; c.sync = s_cs[i]; c.freq_hz = s_cf[i]; c.dt_s = 0.0f;
+        w->cand[r] = c;
+    }
+    if (tid == 0) *w->ncand = ncand;
 }
 
 } // namespace cwslg

@@ -162,9 +162,13 @@ int cwslg_frame_device_ptrs(cwslg_ctx *ctx, int ch_id, const int16_t **d_i16, co
 /* Sync candidates of the last finalised frame (FT8/FT4 channels with sync enabled). */
 int cwslg_enable_sync(cwslg_ctx *ctx, int enable, float syncmin, int max_cand, int f_lo_hz, int f_hi_hz);
 int cwslg_fetch_candidates(cwslg_ctx *ctx, int ch_id, cwslg_candidate *dst, int max, int *n);
+/* FT4 channels run getcandidates4's spectral-peak search instead (freq_hz = interpolated peak - 1.5 tone spacings,
+ * sync = normalised peak height, time_step/dt_s = 0); its threshold defaults to upstream's 1.2. */
+int cwslg_set_ft4_syncmin(cwslg_ctx *ctx, float syncmin);
 
 /* Intermediate products of the sync stage for parity tests: what = 0 symbol spectra [372][nbins] float,
- * 1 red, 2 red2 (float[1921], before normalisation), 3 jpeak, 4 jpeak2 (int32[1921]).  *n_items = items available. */
+ * 1 red, 2 red2 (float[1921], before normalisation), 3 jpeak, 4 jpeak2 (int32[1921]).  *n_items = items available.
+ * FT4 channels: 0 = [122][1168] windowed spectra, 1 = savsm/sbase (first 1153 entries), 2 = sbase. */
 int cwslg_sync_debug_fetch(cwslg_ctx *ctx, int ch_id, int what, void *dst, size_t cap_bytes, size_t *n_items, int *row_len);
 
 /* ---- introspection for bench / tests ---- */

@@ -79,6 +79,10 @@ def lib():
         L.orc_ft8_spectra.argtypes = [_i16p, _f32p, C.c_int]
         L.orc_ft8_sync.argtypes = [_i16p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ft4_spectra.argtypes = [_i16p, _f32p]
+        L.orc_ft4_candidates.argtypes = [_i16p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_log10_fixed.argtypes = [C.c_double]; L.orc_log10_fixed.restype = C.c_double
+        L.orc_exp10_fixed.argtypes = [C.c_double]; L.orc_exp10_fixed.restype = C.c_double
         L.orc_bench_cpu.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint64]
         L.orc_bench_cpu.restype = C.c_double
         L.orc_crc32.argtypes = [C.c_void_p, C.c_size_t]; L.orc_crc32.restype = C.c_uint32
@@ -358,3 +362,24 @@ def ft8_sync(frame_i16, f_lo_hz=200, f_hi_hz=3000, syncmin=1.5, maxcand=200, wan
     if want_arrays:
         return cands, dict(red=red, red2=red2, jpeak=jp, jpeak2=jp2)
     return cands
+
+
+def ft4_spectra(frame_i16):
+    """PARITY UNPINNED.  float32[122, 1153] Nuttall-windowed symbol power spectra of an FT4 int16 frame."""
+    fr = np.ascontiguousarray(frame_i16, dtype=np.int16)
+    assert fr.shape[0] >= 72576
+    out = np.empty(122 * 1153, np.float32)
+    assert lib().orc_ft4_spectra(fr, out) == 0
+    return out.reshape(122, 1153)
+
+
+def ft4_candidates(frame_i16, fa_hz=200.0, fb_hz=4000.0, syncmin=1.2, maxcand=200, want_arrays=False):
+    """PARITY UNPINNED.  -> list of (freq_bin, 0, height, freq_hz, 0.0) [, dict(savsm, sbase)]."""
+    fr = np.ascontiguousarray(frame_i16, dtype=np.int16)
+    assert fr.shape[0] >= 72576
+    buf = (_Cand * maxcand)()
+    sm = np.zeros(1153, np.float32); sb = np.zeros(1153, np.float32)
+    n = lib().orc_ft4_candidates(fr, fa_hz, fb_hz, syncmin, maxcand, C.addressof(buf), maxcand, sm.ctypes.data, sb.ctypes.data)
+    assert n >= 0
+    cands = [(buf[k].freq_bin, buf[k].time_step, buf[k].sync, buf[k].freq_hz, buf[k].dt_s) for k in range(n)]
+    return (cands, dict(savsm=sm, sbase=sb)) if want_arrays else cands

@@ -240,3 +240,264 @@ int orc_ft8_sync(const int16_t *frame, int nfa_hz, int nfb_hz, float syncmin, in
     free(ord); free(ord2); free(c0); free(red); free(red2); free(jpeak); free(jpeak2);
     return nout;
 }
+
+
+/* ====================================================================================================
+ * FT4 candidate search -- *** PARITY UNPINNED *** like everything in this file.
+ * Restates, from memory of WSJT-X 2.6.x lib/ft4/getcandidates4.f90 + ft4_baseline.f90 + ft4_params.f90:
+ *   NSPS=576 NFFT1=2304 NH1=1152 NSTEP=576 NMAX=72576 NHSYM=122, df = 12000/2304, Nuttall window
+ *   s(i,j) = |FFT_2304(fac*dd*window)|^2 ; savg = mean_j s ; savsm = 15-bin moving average of savg
+ *   baseline: savg in dB, 10 segments, lower 10 % of each -> 5-term polynomial least squares, +0.65 dB, back to power
+ *   candidates: local maxima of savsm/sbase >= syncmin with parabolic interpolation, 200..4910 Hz, sorted by height.
+ * Builder-defined arithmetic where upstream leaves it to libm / a fitting routine (so that the GPU can be bit-exact):
+ *   log10 and 10^x are the fixed double-precision series below; the fit solves the 5x5 normal equations in the
+ *   scaled variable u = (i - i0)/half_span by Gaussian elimination with partial pivoting.
+ */
+#define F4_NFFT   2304
+#define F4_NH1    1152
+#define F4_NSTEP  576
+#define F4_NHSYM  122
+#define F4_NA     9
+
+static float f4_w9r[F4_NA], f4_w9i[F4_NA];
+static float f4_wNr[F4_NH1], f4_wNi[F4_NH1];          /* exp(-2 pi i k/1152) */
+static float f4_w2Nr[F4_NH1 + 1], f4_w2Ni[F4_NH1 + 1]; /* exp(-2 pi i k/2304), k = 0..1152 */
+static float f4_win[F4_NFFT];
+static int f4_ready = 0;
+
+static void f4_tables(void)
+{
+    const double pi = 3.14159265358979323846;
+    if (!tables_ready) make_tables();
+    for (int k = 0; k < F4_NA; ++k) { f4_w9r[k] = (float)cos(2.0 * pi * k / 9.0); f4_w9i[k] = (float)(-sin(2.0 * pi * k / 9.0)); }
+    for (int k = 0; k < F4_NH1; ++k) { f4_wNr[k] = (float)cos(2.0 * pi * k / 1152.0); f4_wNi[k] = (float)(-sin(2.0 * pi * k / 1152.0)); }
+    for (int k = 0; k <= F4_NH1; ++k) { f4_w2Nr[k] = (float)cos(2.0 * pi * k / 2304.0); f4_w2Ni[k] = (float)(-sin(2.0 * pi * k / 2304.0)); }
+    for (int i = 0; i < F4_NFFT; ++i)                   /* nuttal_window */
+        f4_win[i] = (float)(0.3635819 - 0.4891775 * cos(2.0 * pi * i / 2304.0) + 0.1365995 * cos(4.0 * pi * i / 2304.0)
+                            - 0.0106411 * cos(6.0 * pi * i / 2304.0));
+    f4_ready = 1;
+}
+
+/* 2304 real -> |X[k]|^2, k = 0..1152: pack to 1152 complex = 9 x 128, same structure as spectrum_3840 */
+static void spectrum_2304(const float *x, float *pw)
+{
+    static float yr[F4_NA][NB], yi[F4_NA][NB];
+    for (int b = 0; b < NB; ++b) {
+        for (int c = 0; c < F4_NA; ++c) {
+            float ar = x[2 * b], ai = x[2 * b + 1];
+            for (int a = 1; a < F4_NA; ++a) {
+                const int m = NB * a + b;
+                const float zr = x[2 * m], zi = x[2 * m + 1];
+                const float wr = f4_w9r[(a * c) % F4_NA], wi = f4_w9i[(a * c) % F4_NA];
+                const float pr = zr * wr - zi * wi;
+                const float pi_ = zr * wi + zi * wr;
+                ar = ar + pr;
+                ai = ai + pi_;
+            }
+            const float tr = f4_wNr[b * c], ti = f4_wNi[b * c];
+            yr[c][rev7[b]] = ar * tr - ai * ti;
+            yi[c][rev7[b]] = ar * ti + ai * tr;
+        }
+    }
+    for (int c = 0; c < F4_NA; ++c) {
+        for (int len = 2; len <= NB; len <<= 1) {
+            const int half = len >> 1, step = NB / len;
+            for (int base = 0; base < NB; base += len) {
+                for (int k = 0; k < half; ++k) {
+                    const float wr = w128r[k * step], wi = w128i[k * step];
+                    const float ur = yr[c][base + k], ui = yi[c][base + k];
+                    const float vr = yr[c][base + k + half], vi = yi[c][base + k + half];
+                    const float tr = vr * wr - vi * wi;
+                    const float ti = vr * wi + vi * wr;
+                    yr[c][base + k] = ur + tr;        yi[c][base + k] = ui + ti;
+                    yr[c][base + k + half] = ur - tr; yi[c][base + k + half] = ui - ti;
+                }
+            }
+        }
+    }
+    for (int k = 0; k <= F4_NH1; ++k) {
+        const int k2 = (F4_NH1 - k) % F4_NH1, kk = k % F4_NH1;
+        const float ar = yr[kk % F4_NA][kk / F4_NA], ai = yi[kk % F4_NA][kk / F4_NA];
+        const float br = yr[k2 % F4_NA][k2 / F4_NA], bi = -yi[k2 % F4_NA][k2 / F4_NA];
+        const float er = (ar + br) * 0.5f, ei = (ai + bi) * 0.5f;
+        const float orr = (ar - br) * 0.5f, oi = (ai - bi) * 0.5f;
+        const float wr = f4_w2Nr[k], wi = f4_w2Ni[k];
+        const float tr = orr * wr - oi * wi;
+        const float ti = orr * wi + oi * wr;
+        const float xr = er + ti, xi = ei - tr;
+        pw[k] = xr * xr + xi * xi;
+    }
+}
+
+/* s_out: NHSYM rows of 1153 floats (bins 0..1152) */
+int orc_ft4_spectra(const int16_t *frame, float *s_out)
+{
+    if (!f4_ready) f4_tables();
+    float x[F4_NFFT];
+    const float fac = 1.0f / 300.0f;
+    for (int j = 0; j < F4_NHSYM; ++j) {
+        const int16_t *d = frame + (size_t)F4_NSTEP * j;
+        for (int n = 0; n < F4_NFFT; ++n) x[n] = (fac * (float)d[n]) * f4_win[n];
+        spectrum_2304(x, s_out + (size_t)j * (F4_NH1 + 1));
+    }
+    return 0;
+}
+
+/* fixed-arithmetic double log10 / 10^x (plain * + / only: identical on any IEEE-754 machine, CPU or GPU) */
+double orc_log10_fixed(double x)
+{
+    if (!(x > 0.0)) return -1.0e300;
+    int e = 0;
+    double m = x;
+    while (m >= 1.4142135623730951) { m = m * 0.5; ++e; }
+    while (m < 0.7071067811865476) { m = m * 2.0; --e; }
+    const double t = (m - 1.0) / (m + 1.0), t2 = t * t;
+    double s = 0.0;
+    for (int k = 21; k >= 1; k -= 2) s = s * t2 + 1.0 / (double)k;      /* sum t^(k-1)/k, Horner in t2 */
+    const double ln_m = 2.0 * t * s;
+    return ((double)e * 0.6931471805599453 + ln_m) * 0.4342944819032518;
+}
+
+double orc_exp10_fixed(double y)
+{
+    const double z = y * 3.321928094887362;            /* y*log2(10) */
+    double fl = (double)(long long)z;
+    if (fl > z) fl = fl - 1.0;                         /* floor */
+    const double f = (z - fl) * 0.6931471805599453;    /* in [0, ln 2) */
+    double s = 1.0;
+    for (int k = 22; k >= 1; --k) s = 1.0 + s * f / (double)k;          /* Taylor of exp(f), Horner */
+    long long n = (long long)fl;
+    double p = 1.0;
+    if (n >= 0) { for (long long q = 0; q < n && q < 2000; ++q) p = p * 2.0; }
+    else { for (long long q = 0; q < -n && q < 2000; ++q) p = p * 0.5; }
+    return s * p;
+}
+
+static void shell_sort(float *a, int n)
+{
+    for (int gap = n / 2; gap > 0; gap /= 2)
+        for (int i = gap; i < n; ++i) {
+            const float v = a[i];
+            int j = i;
+            while (j >= gap && a[j - gap] > v) { a[j] = a[j - gap]; j -= gap; }
+            a[j] = v;
+        }
+}
+
+/* out arrays (optional): savsm_norm[1153], sbase[1153].  Returns candidate count (<= max_out). */
+int orc_ft4_candidates(const int16_t *frame, float fa_hz, float fb_hz, float syncmin, int maxcand,
+                       orc_candidate_t *out, int max_out, float *savsm_o, float *sbase_o)
+{
+    const int NB1 = F4_NH1 + 1;
+    float *s = (float *)malloc(sizeof(float) * (size_t)NB1 * F4_NHSYM);
+    if (!s || orc_ft4_spectra(frame, s)) { free(s); return -1; }
+    float savg[F4_NH1 + 1], savsm[F4_NH1 + 1], sbase[F4_NH1 + 1], sdb[F4_NH1 + 1];
+    for (int i = 0; i <= F4_NH1; ++i) { savg[i] = 0.0f; savsm[i] = 0.0f; sbase[i] = 0.0f; sdb[i] = 0.0f; }
+    for (int j = 0; j < F4_NHSYM; ++j)
+        for (int i = 1; i <= F4_NH1; ++i) savg[i] = savg[i] + s[(size_t)j * NB1 + i];
+    free(s);
+    for (int i = 1; i <= F4_NH1; ++i) savg[i] = savg[i] / (float)F4_NHSYM;
+    for (int i = 8; i <= F4_NH1 - 7; ++i) {
+        float t = 0.0f;
+        for (int q = i - 7; q <= i + 7; ++q) t = t + savg[q];
+        savsm[i] = t / 15.0f;
+    }
+    const float df = 12000.0f / F4_NFFT;
+    int nfa = (int)(fa_hz / df); if (nfa < (int)lroundf(200.0f / df)) nfa = (int)lroundf(200.0f / df);
+    int nfb = (int)(fb_hz / df); if (nfb > (int)lroundf(4910.0f / df)) nfb = (int)lroundf(4910.0f / df);
+    int ncand = 0;
+    orc_candidate_t *c0 = (orc_candidate_t *)calloc((size_t)maxcand + 1, sizeof(orc_candidate_t));
+    do {
+        if (nfb - nfa < 20) break;
+        /* ---- baseline ---- */
+        const int ia = nfa, ib = (nfb < F4_NH1) ? nfb : F4_NH1;
+        for (int i = ia; i <= ib; ++i) sdb[i] = (float)(10.0 * orc_log10_fixed((double)savg[i]));
+        const int nseg = 10, npct = 10;
+        const int nlen = (ib - ia + 1) / nseg, i0 = (ib - ia + 1) / 2;
+        const double half = (double)(ib - ia + 1) / 2.0;
+        double S[9] = {0}, Tm[5] = {0};
+        int kz = 0;
+        float tmp[F4_NH1 + 1];
+        for (int n = 0; n < nseg; ++n) {
+            const int ja = ia + n * nlen, jb = ja + nlen - 1;
+            for (int q = 0; q < nlen; ++q) tmp[q] = sdb[ja + q];
+            shell_sort(tmp, nlen);
+            int jp = (int)lroundf(((float)nlen * 0.01f) * (float)npct);
+            if (jp < 1) jp = 1;
+            if (jp > nlen) jp = nlen;
+            const float base = tmp[jp - 1];
+            for (int i = ja; i <= jb; ++i) {
+                if (sdb[i] <= base && kz < 1000) {
+                    ++kz;
+                    const double u = (double)(i - i0) / half, y = (double)sdb[i];
+                    double p = 1.0;
+                    for (int q = 0; q < 9; ++q) { S[q] = S[q] + p; if (q < 5) Tm[q] = Tm[q] + y * p; p = p * u; }
+                }
+            }
+        }
+        if (kz < 5) break;
+        double A[5][6];
+        for (int r = 0; r < 5; ++r) { for (int cc = 0; cc < 5; ++cc) A[r][cc] = S[r + cc]; A[r][5] = Tm[r]; }
+        int singular = 0;
+        for (int col = 0; col < 5; ++col) {
+            int piv = col;
+            for (int r = col + 1; r < 5; ++r) if (fabs(A[r][col]) > fabs(A[piv][col])) piv = r;
+            if (A[piv][col] == 0.0) { singular = 1; break; }
+            if (piv != col) for (int cc = 0; cc < 6; ++cc) { const double t = A[col][cc]; A[col][cc] = A[piv][cc]; A[piv][cc] = t; }
+            for (int r = col + 1; r < 5; ++r) {
+                const double f = A[r][col] / A[col][col];
+                for (int cc = col; cc < 6; ++cc) A[r][cc] = A[r][cc] - f * A[col][cc];
+            }
+        }
+        if (singular) break;
+        double a[5];
+        for (int r = 4; r >= 0; --r) {
+            double t = A[r][5];
+            for (int cc = r + 1; cc < 5; ++cc) t = t - A[r][cc] * a[cc];
+            a[r] = t / A[r][r];
+        }
+        int bad = 0;
+        for (int i = ia; i <= ib; ++i) {
+            const double u = (double)(i - i0) / half;
+            const float db = (float)(a[0] + u * (a[1] + u * (a[2] + u * (a[3] + u * a[4]))) + 0.65);
+            sbase[i] = (float)orc_exp10_fixed((double)db / 10.0);
+            if (!(sbase[i] > 0.0f)) bad = 1;
+        }
+        if (bad) break;
+        for (int i = nfa; i <= nfb; ++i) savsm[i] = savsm[i] / sbase[i];
+        /* ---- local maxima ---- */
+        const float f_offset = -1.5f * 12000.0f / 576.0f;
+        for (int i = nfa + 1; i <= nfb - 1; ++i) {
+            if (savsm[i] >= savsm[i - 1] && savsm[i] >= savsm[i + 1] && savsm[i] >= syncmin) {
+                const float den = savsm[i - 1] - 2.0f * savsm[i] + savsm[i + 1];
+                float del = 0.0f;
+                if (den != 0.0f) del = 0.5f * (savsm[i - 1] - savsm[i + 1]) / den;
+                const float fpeak = ((float)i + del) * df + f_offset;
+                if (fpeak < 200.0f || fpeak > 4910.0f) continue;
+                const float speak = savsm[i] - 0.25f * (savsm[i - 1] - savsm[i + 1]) * del;
+                c0[ncand].freq_bin = i; c0[ncand].time_step = 0; c0[ncand].sync = speak;
+                c0[ncand].freq_hz = fpeak; c0[ncand].dt_s = 0.0f;
+                ++ncand;
+                if (ncand == maxcand) break;
+            }
+        }
+    } while (0);
+    if (savsm_o) memcpy(savsm_o, savsm, sizeof(savsm));
+    if (sbase_o) memcpy(sbase_o, sbase, sizeof(sbase));
+    /* descending height, ties by ascending bin */
+    int nout = 0;
+    for (int pass = 0; pass < ncand && nout < max_out; ++pass) {
+        int bi = -1;
+        for (int i = 0; i < ncand; ++i) {
+            if (c0[i].time_step) continue;
+            if (bi < 0 || c0[i].sync > c0[bi].sync || (c0[i].sync == c0[bi].sync && c0[i].freq_bin < c0[bi].freq_bin)) bi = i;
+        }
+        if (bi < 0) break;
+        c0[bi].time_step = 1;
+        out[nout] = c0[bi];
+        out[nout].time_step = 0;
+        ++nout;
+    }
+    free(c0);
+    return nout;
+}

@@ -53,6 +53,18 @@ int orc_ft8_sync(const int16_t *frame, int nfa_hz, int nfb_hz, float syncmin, in
                  orc_candidate_t *out, int max_out,
                  float *red, int32_t *jpeak, float *red2, int32_t *jpeak2);
 
+/* ---- FT4 (getcandidates4): PARITY UNPINNED, see sync_oracle.c ---- */
+#define FT4_NFFT1 2304
+#define FT4_NH1   1152
+#define FT4_NSTEP 576
+#define FT4_NMAX  72576
+#define FT4_NHSYM 122
+int orc_ft4_spectra(const int16_t *frame, float *s_out /* [122][1153] */);
+int orc_ft4_candidates(const int16_t *frame, float fa_hz, float fb_hz, float syncmin, int maxcand,
+                       orc_candidate_t *out, int max_out, float *savsm_norm /*[1153]*/, float *sbase /*[1153]*/);
+double orc_log10_fixed(double x);
+double orc_exp10_fixed(double y);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,3 +25,17 @@ def ft8_iq(fs, n, rf_hz, audio_hz, t0_s, amp, rng):
     m = min(len(sig), n - i0)
     out[i0:i0 + m] = sig[:m]
     return out
+
+
+def ft4_iq(fs, n, rf_hz, audio_hz, t0_s, amp, rng):
+    """FT4-like 4-FSK burst: 103 symbols of 48 ms, tone spacing 20.8333 Hz, tone 0 at audio_hz (no pulse shaping)."""
+    tones = rng.integers(0, 4, 103)
+    sps = int(round(fs * 0.048))
+    f = rf_hz + audio_hz + (12000.0 / 576.0) * np.repeat(tones, sps)
+    ph = 2 * np.pi * np.cumsum(f) / fs
+    sig = amp * np.exp(1j * ph)
+    out = np.zeros(n, np.complex64)
+    i0 = int(round(t0_s * fs))
+    m = min(len(sig), n - i0)
+    out[i0:i0 + m] = sig[:m]
+    return out

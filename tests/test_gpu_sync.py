@@ -95,3 +95,80 @@ def test_sync_many_channels_one_launch(ctx, oracle):
                [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in ref]
         want_bin = int(round((500.0 + 140 * k) / 3.125))
         assert any(abs(c[0] - want_bin) <= 1 for c in got)
+
+
+# ---------------------------------------------------------------------------------------------- FT4
+from ft8_signal import ft4_iq
+
+
+def _run_ft4(ctx, oracle, f, specs, seed, maxcand=200, lo=200, hi=4000, syncmin4=1.2):
+    n = 1440000 // BLK * BLK
+    rng = np.random.default_rng(seed)
+    iq = oracle.synth_iq(seed, n, FS)
+    for audio_hz, t0, amp in specs:
+        iq = iq + ft4_iq(FS, n, f, audio_hz, t0, amp, rng)
+    iq = iq.astype(np.complex64)
+    ctx.enable_sync(True, 1.5, maxcand, lo, hi)
+    ctx.set_ft4_syncmin(syncmin4)
+    rx = ctx.receiver_open(FS, BLK, 0)
+    ch = ctx.channel_open(rx, f, "FT4")
+    ctx.slot_boundary("FT4", 1)
+    for k in range(0, n, 128 * BLK):
+        ctx.push_iq(rx, iq[k:k + 128 * BLK])
+    ctx.slot_boundary("FT4", 8)
+    return ch, ctx.fetch_frame(ch)["i16"]
+
+
+def _key(cands):
+    return [(c[0], np.float32(c[2]).view(np.uint32), np.float32(c[3]).view(np.uint32)) for c in cands]
+
+
+def test_ft4_bit_exact_vs_restatement(ctx, oracle):
+    specs = [(700.0, 0.3, 2500.0), (1800.0, 0.6, 1500.0), (3100.0, 0.2, 2000.0), (3150.0, 1.0, 800.0)]
+    ch, fr = _run_ft4(ctx, oracle, -40000, specs, 9)
+    ref, arr = oracle.ft4_candidates(fr, 200.0, 4000.0, 1.2, 200, want_arrays=True)
+    s_gpu = ctx.sync_debug(ch, "spectra")
+    assert s_gpu.shape == (122, 1168)
+    s_ref = oracle.ft4_spectra(fr)
+    assert np.array_equal(s_gpu[:, :1153].view(np.uint32), s_ref.view(np.uint32))
+    assert np.array_equal(ctx.sync_debug(ch, "red2")[:1153].view(np.uint32), arr["sbase"].view(np.uint32))     # baseline
+    assert np.array_equal(ctx.sync_debug(ch, "red")[:1153].view(np.uint32), arr["savsm"].view(np.uint32))      # savsm/sbase
+    got = ctx.fetch_candidates(ch, 200)
+    assert len(got) == len(ref) >= 3 and _key(got) == _key(ref)
+    assert all(c[1] == 0 and c[4] == 0.0 for c in got)
+
+
+@pytest.mark.parametrize("maxcand,lo,hi,smin", [(5, 200, 4000, 1.2), (600, 100, 5000, 1.05), (50, 500, 2500, 2.0)])
+def test_ft4_parameter_sweep(ctx, oracle, maxcand, lo, hi, smin):
+    specs = [(600.0 + 290 * k, 0.1 + 0.1 * k, 2600.0 - 200 * k) for k in range(8)]
+    ch, fr = _run_ft4(ctx, oracle, 20000, specs, 21, maxcand, lo, hi, smin)
+    ref = oracle.ft4_candidates(fr, float(lo), float(hi), smin, maxcand)
+    got = ctx.fetch_candidates(ch, 600)
+    assert _key(got) == _key(ref) and len(got) <= maxcand
+
+
+def test_mixed_ft8_ft4_sync_in_one_context(ctx, oracle):
+    """BASELINE configs[2]: FT8 and FT4 slots side by side, each with its own sync stage."""
+    n8 = 2880000 // BLK * BLK
+    rng = np.random.default_rng(4)
+    iq = oracle.synth_iq(31, n8, FS)
+    iq = iq + ft8_iq(FS, n8, 10000, 1200.0, 0.5, 2500.0, rng) + ft4_iq(FS, n8, -30000, 900.0, 0.3, 2500.0, rng) \
+        + ft4_iq(FS, n8, -30000, 2100.0, 7.8, 2000.0, rng)
+    iq = iq.astype(np.complex64)
+    ctx.enable_sync(True, 1.5, 100, 200, 3000)
+    rx = ctx.receiver_open(FS, BLK, 0)
+    c8 = ctx.channel_open(rx, 10000, "FT8")
+    c4 = ctx.channel_open(rx, -30000, "FT4")
+    ctx.slot_boundary("FT8", 1); ctx.slot_boundary("FT4", 1)
+    half = n8 // 2 // BLK * BLK
+    ctx.push_iq(rx, iq[:half]); ctx.slot_boundary("FT4", 8)
+    fr4a = ctx.fetch_frame(c4)["i16"]; got4a = ctx.fetch_candidates(c4, 100)
+    ctx.push_iq(rx, iq[half:]); ctx.slot_boundary("FT4", 15); ctx.slot_boundary("FT8", 15)
+    fr4b = ctx.fetch_frame(c4)["i16"]; got4b = ctx.fetch_candidates(c4, 100)
+    fr8 = ctx.fetch_frame(c8)["i16"]; got8 = ctx.fetch_candidates(c8, 100)
+    assert _key(got4a) == _key(oracle.ft4_candidates(fr4a, 200.0, 3000.0, 1.2, 100))
+    assert _key(got4b) == _key(oracle.ft4_candidates(fr4b, 200.0, 3000.0, 1.2, 100))
+    ref8 = oracle.ft8_sync(fr8, 200, 3000, 1.5, 100)
+    assert [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in got8] == [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in ref8]
+    assert any(abs(c[3] - 900.0) <= 40 for c in got4a[:4]) and any(abs(c[3] - 2100.0) <= 40 for c in got4b[:4])
+    assert any(abs(c[3] - 1200.0) <= 4 for c in got8[:3])

@@ -64,3 +64,56 @@ def test_candidate_fields_and_dedupe(oracle):
         for b in cands[:i]:
             fd = abs(np.float32(a[3]) - np.float32(b[3])); td = abs(np.float32(a[4]) - np.float32(b[4]))   # float32, as the code
             assert not (fd < np.float32(4.0) and td < np.float32(0.04))
+
+
+# ---------------------------------------------------------------------------------------------- FT4
+from ft8_signal import ft4_iq
+
+
+def _ft4_frame(oracle, specs, seed=9):
+    fs, blk, f = 192000, 2048, -40000
+    n = 1440000 // blk * blk
+    rng = np.random.default_rng(seed)
+    iq = oracle.synth_iq(seed, n, fs)
+    for audio_hz, t0, amp in specs:
+        iq = iq + ft4_iq(fs, n, f, audio_hz, t0, amp, rng)
+    c = oracle.Channel("FT4", fs, blk, f)
+    c.boundary(1)
+    c.push_many(iq.astype(np.complex64))
+    return c.boundary(2)["i16"]
+
+
+def test_ft4_spectra_match_numpy_fft(oracle):
+    fr = _ft4_frame(oracle, [(1000.0, 0.5, 3000.0)])
+    s = oracle.ft4_spectra(fr)
+    i = np.arange(2304); pi = np.pi
+    win = (0.3635819 - 0.4891775 * np.cos(2 * pi * i / 2304) + 0.1365995 * np.cos(4 * pi * i / 2304)
+           - 0.0106411 * np.cos(6 * pi * i / 2304)).astype(np.float32)
+    for j in (0, 60, 121):
+        x = fr[576 * j:576 * j + 2304].astype(np.float32) * np.float32(1 / 300.0) * win
+        ref = np.abs(np.fft.rfft(x.astype(np.float64))) ** 2
+        assert np.abs(s[j] - ref).max() <= 2e-6 * ref.max()
+
+
+def test_fixed_log_exp_are_accurate(oracle):
+    import math
+    L = oracle.lib()
+    for x in (1e-12, 3e-5, 0.3, 1.0, 2.5, 1234.5, 7e12):
+        assert abs(L.orc_log10_fixed(x) - math.log10(x)) <= 4e-15 * max(1.0, abs(math.log10(x)))
+    for y in (-6.0, -3.2, -0.5, 0.0, 0.33, 2.75, 9.1):
+        assert abs(L.orc_exp10_fixed(y) / 10 ** y - 1) <= 4e-15
+
+
+def test_ft4_finds_signals(oracle):
+    specs = [(700.0, 0.3, 2500.0), (1800.0, 0.6, 1500.0), (3100.0, 0.2, 2000.0)]
+    fr = _ft4_frame(oracle, specs)
+    cands, arr = oracle.ft4_candidates(fr, 200.0, 4000.0, 1.2, 200, want_arrays=True)
+    heights = [c[2] for c in cands]
+    assert heights == sorted(heights, reverse=True) and len(cands) >= 3
+    # candidate frequency = interpolated peak of the 15-bin-smoothed spectrum - 1.5 tone spacings: the occupied band is
+    # tone0 .. tone0 + 3*20.83 Hz, whose centre - 31.25 Hz is tone0; allow one smoothing half-width
+    for audio_hz, _, _ in specs:
+        assert any(abs(c[3] - audio_hz) <= 40.0 for c in cands[:6]), (audio_hz, cands[:6])
+    assert (arr["sbase"][39:768] > 0).all()
+    for b, _, h, fhz, _ in cands:
+        assert 200.0 <= fhz <= 4910.0 and h >= np.float32(1.2) and 38 < b < 943
