@@ -91,7 +91,7 @@ ABI_SYMBOLS = [
     "cwslg_set_scale_factors", "cwslg_set_exact", "cwslg_receiver_open", "cwslg_receiver_close", "cwslg_push_iq",
     "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_parse_decoder_line", "cwslg_channel_open_line", "cwslg_channel_open", "cwslg_channel_close",
     "cwslg_channel_info", "cwslg_process", "cwslg_slot_boundary", "cwslg_slot_boundary_channel",
-    "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
+    "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_write_wav", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
     "cwslg_enable_sync", "cwslg_fetch_candidates", "cwslg_set_ft4_syncmin", "cwslg_sync_debug_fetch", "cwslg_get_stats", "cwslg_reset_stats",
     "cwslg_set_timing", "cwslg_stream", "cwslg_channel_constants", "cwslg_channel_phasor_checkpoints",
 ]
@@ -139,6 +139,7 @@ def load_library(build_if_missing=True):
     L.cwslg_slot_boundary_channel.argtypes = [vp, i32, u64]
     L.cwslg_synchronize.argtypes = [vp]
     L.cwslg_fetch_frame.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(u64), C.POINTER(C.c_size_t), C.POINTER(f32)]
+    L.cwslg_write_wav.argtypes = [vp, i32, C.c_char_p]
     L.cwslg_fetch_audio_f32.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.cwslg_frame_device_ptrs.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
     L.cwslg_enable_sync.argtypes = [vp, i32, f32, i32, i32, i32]
@@ -269,6 +270,10 @@ class Context:
             return None
         self._chk(rc)
         return dict(i16=out, t_start=t0.value, n_valid=nv.value, factor=np.float32(fac.value))
+
+    def write_wav(self, ch, path):
+        """The reference's 46-byte-header 12 kHz mono int16 .wav of the last finalised frame (WaveFile.hpp:87-135)."""
+        self._chk(self.L.cwslg_write_wav(self.h, ch, str(path).encode()))
 
     def fetch_audio_f32(self, ch):
         n = frame_len(self._modes[ch])

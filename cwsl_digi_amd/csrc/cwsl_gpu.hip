@@ -825,22 +825,36 @@ int cwslg_channel_open(cwslg_ctx *c, int rx_id, int32_t demod_hz, int usb, const
     const size_t ibytes = (ch.frame_len * sizeof(int16_t) + 255) & ~size_t(255);
     const size_t total = 2 * fbytes + ibytes + 256 + 256;
     HIPCHK(c, hipMalloc((void **)&ch.d_block, total));
+    // from here on a failure must give the block back
+#define HIPCHK_FREE(expr)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (void)hipFree(ch.d_block);                                                             \
+            return fail(c, CWSLG_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));          \
+        }                                                                                          \
+    } while (0)
     ch.d_frame[0] = (float *)ch.d_block;
     ch.d_frame[1] = (float *)(ch.d_block + fbytes);
     ch.d_i16 = (int16_t *)(ch.d_block + 2 * fbytes);
     ch.d_peak = (unsigned *)(ch.d_block + 2 * fbytes + ibytes);
     ch.d_factor = (float *)(ch.d_block + 2 * fbytes + ibytes + 16);
     ch.d_tone = (float2 *)(ch.d_block + 2 * fbytes + ibytes + 256);
-    HIPCHK(c, hipMemsetAsync(ch.d_block + 2 * fbytes + ibytes, 0, 256, c->stream));
-    HIPCHK(c, hipMemcpyAsync(ch.d_tone, ch.k.tone.data(), ch.k.block * sizeof(float2), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));     // k.tone is a temporary host vector: finish the copy now
+    HIPCHK_FREE(hipMemsetAsync(ch.d_block + 2 * fbytes + ibytes, 0, 256, c->stream));
+    HIPCHK_FREE(hipMemcpyAsync(ch.d_tone, ch.k.tone.data(), ch.k.block * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    HIPCHK_FREE(hipStreamSynchronize(c->stream));   // k.tone is a temporary host vector: finish the copy now
     // phasor checkpoints: cover the first frame, which continues across the discarded partial slot
     // (up to 2 frames of blocks since creation), plus one tile of slack
     const size_t n_ckpt = (2 * ch.frame_len + kTile + 64) / kCkptStride + 2;
     ch.phasor_key = std::make_tuple(rx.fs, demod_hz, usb ? 1 : 0, n_ckpt);
     PhasorTable &pt = c->phasors[ch.phasor_key];
     if (pt.refs == 0) {
-        HIPCHK(c, hipMalloc(&pt.d_ckpt, n_ckpt * sizeof(float2)));
+        pt.d_ckpt = nullptr;
+        if (hipMalloc(&pt.d_ckpt, n_ckpt * sizeof(float2)) != hipSuccess) {
+            c->phasors.erase(ch.phasor_key);
+            (void)hipFree(ch.d_block);
+            return fail(c, CWSLG_ERR_NOMEM, "phasor table allocation failed");
+        }
         pt.n_ckpt = n_ckpt;
         pt.inc = make_float2(ch.k.inc.real(), ch.k.inc.imag());
         pt.built = false;
@@ -1034,6 +1048,35 @@ int cwslg_fetch_frame(cwslg_ctx *c, int ch_id, int16_t *dst, size_t cap, uint64_
     if (start_epoch) *start_epoch = ch.frame_t0;
     if (n_valid) *n_valid = ch.frame_valid;
     return CWSLG_OK;
+}
+
+int cwslg_write_wav(cwslg_ctx *c, int ch_id, const char *path)
+{
+    if (!c || !path) return CWSLG_ERR_ARG;
+    size_t n = 0;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
+        if (!c->chans[ch_id].have_frame) return CWSLG_ERR_NO_FRAME;
+        n = c->chans[ch_id].frame_len;
+    }
+    std::vector<int16_t> pcm(n);
+    int rc = cwslg_fetch_frame(c, ch_id, pcm.data(), n, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    // WavHdr (WaveFile.hpp:19-35), little endian, packed: 46 bytes
+    unsigned char h[46];
+    auto u32 = [&](int off, uint32_t v) { h[off] = v & 255; h[off + 1] = (v >> 8) & 255; h[off + 2] = (v >> 16) & 255; h[off + 3] = (v >> 24) & 255; };
+    auto u16 = [&](int off, uint16_t v) { h[off] = v & 255; h[off + 1] = (v >> 8) & 255; };
+    const uint32_t data_len = (uint32_t)(n * sizeof(int16_t));
+    std::memcpy(h + 0, "RIFF", 4); u32(4, 46 + data_len - 8);
+    std::memcpy(h + 8, "WAVE", 4); std::memcpy(h + 12, "fmt ", 4); u32(16, 18);
+    u16(20, 1); u16(22, 1); u32(24, 12000); u32(28, 24000); u16(32, 2); u16(34, 16); u16(36, 0);
+    std::memcpy(h + 38, "data", 4); u32(42, data_len);
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(c, CWSLG_ERR_ARG, "cannot open %s", path);
+    const bool ok = std::fwrite(h, 1, sizeof(h), f) == sizeof(h) && std::fwrite(pcm.data(), sizeof(int16_t), n, f) == n;
+    std::fclose(f);
+    return ok ? CWSLG_OK : fail(c, CWSLG_ERR_ARG, "short write to %s", path);
 }
 
 int cwslg_fetch_audio_f32(cwslg_ctx *c, int ch_id, float *dst, size_t cap, size_t *n_valid)

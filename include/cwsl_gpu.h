@@ -155,6 +155,11 @@ int cwslg_synchronize(cwslg_ctx *ctx);
  * startEpochTime.  Returns CWSLG_ERR_NO_FRAME until a frame has been finalised. */
 int cwslg_fetch_frame(cwslg_ctx *ctx, int ch_id, int16_t *dst, size_t cap,
                       uint64_t *start_epoch, size_t *n_valid, float *factor);
+/* The last finalised frame as the reference's .wav (WaveFile.hpp:19-35,87-135: 46-byte RIFF/WAVE/fmt(18-byte
+ * WAVEFORMATEX, PCM, mono, 12 kHz, 16 bit)/data header + the whole int16 frame) -- the file jt9/wsprd are given in
+ * transfermethod=wavefile mode (DecoderPool.hpp:966-1046).  For the shared-memory mode pass &dec_data->d2[0]
+ * to cwslg_fetch_frame instead (DecoderPool.hpp:588). */
+int cwslg_write_wav(cwslg_ctx *ctx, int ch_id, const char *path);
 /* The same frame as 12 kHz float audio BEFORE prepareAudio's scaling (for the 1e-5 check). */
 int cwslg_fetch_audio_f32(cwslg_ctx *ctx, int ch_id, float *dst, size_t cap, size_t *n_valid);
 /* Device pointers of the last finalised frame (valid until the next boundary of that channel). */

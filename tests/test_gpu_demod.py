@@ -262,3 +262,18 @@ def test_channel_from_unchanged_decoder_line(ctx, oracle):
     ref = oracle.Channel("FT8", FS, IQ_LEN, -26000); ref.boundary(1); ref.push_many(iq)
     r = ref.boundary(2, want_f32=True)
     assert_int16_match(fa["i16"], r["i16"], r["f32"] * r["factor"])
+
+
+def test_wav_file_is_the_reference_container(ctx, oracle, tmp_path):
+    """BASELINE configs[0] asks for a 12 kHz .wav: header bytes per WaveFile.hpp:96-113, then the whole int16 frame."""
+    n = 32 * IQ_LEN
+    iq = oracle.synth_iq(12, n, FS, tones_hz=[-26000 + 1500.0], amp=1e4)
+    rx = ctx.receiver_open(FS, IQ_LEN, 28100000)
+    ch = ctx.channel_open_line(rx, "28074000 FT8")
+    ctx.slot_boundary("FT8", 1); ctx.push_iq(rx, iq); ctx.slot_boundary("FT8", 2)
+    p = tmp_path / "slot.wav"
+    ctx.write_wav(ch, p)
+    raw = p.read_bytes()
+    fr = ctx.fetch_frame(ch)["i16"]
+    assert raw[:46] == oracle.wav_header(240000) and len(raw) == 46 + 480000
+    assert np.array_equal(np.frombuffer(raw[46:], np.int16), fr)
