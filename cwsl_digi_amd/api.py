@@ -93,7 +93,7 @@ ABI_SYMBOLS = [
     "cwslg_channel_info", "cwslg_process", "cwslg_slot_boundary", "cwslg_slot_boundary_channel",
     "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_write_wav", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
     "cwslg_enable_sync", "cwslg_fetch_candidates", "cwslg_set_ft4_syncmin", "cwslg_sync_debug_fetch", "cwslg_get_stats", "cwslg_reset_stats",
-    "cwslg_set_timing", "cwslg_stream", "cwslg_channel_constants", "cwslg_channel_phasor_checkpoints",
+    "cwslg_set_timing", "cwslg_stream", "cwslg_channel_constants", "cwslg_phasor_checkpoint_stride", "cwslg_channel_phasor_checkpoints",
 ]
 
 
@@ -341,6 +341,9 @@ class Context:
         inc = np.empty(2, np.float32)
         self._chk(self.L.cwslg_channel_constants(self.h, ch, taps.ctypes.data, tone.ctypes.data, inc.ctypes.data))
         return taps, tone.view(np.complex64), inc.view(np.complex64)[0]
+
+    def checkpoint_stride(self):
+        return int(self.L.cwslg_phasor_checkpoint_stride())
 
     def phasor_checkpoints(self, ch, n=None):
         tot = C.c_size_t()

@@ -32,7 +32,7 @@ namespace cwslg {
 constexpr int kTile = 256;             // outputs per demod workgroup
 constexpr int kDemodThreads = 256;
 constexpr int kFinThreads = 256;
-constexpr int kCkptStride = 16;        // blocks between phasor checkpoints
+constexpr int kCkptStride = cwslg::kCk;   // blocks between phasor checkpoints
 constexpr size_t kStageHalf = 16u << 20;   // pinned staging: two halves of 16 MiB
 constexpr int kWorkBufs = 8;
 
@@ -285,6 +285,7 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
         // persistent variant (measured alternative): as many workgroups as are resident at once
         int occ = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, demod_kernel<D, kTile, kDemodThreads, true>, kDemodThreads, 0) != hipSuccess || occ < 1) occ = 3;
+        if (const char *v = std::getenv("CWSLG_PERSIST_WGS_PER_CU")) occ = std::max(1, std::atoi(v));
         long long wgs = std::min<long long>((long long)c->cu_count * occ, per_xcd * 8);
         wgs = (wgs + 7) / 8 * 8;
         hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, true>), dim3((unsigned)wgs), dim3(kDemodThreads), 0,
@@ -1134,6 +1135,14 @@ int cwslg_set_timing(cwslg_ctx *c, int enable)
 
 void *cwslg_stream(cwslg_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
+#ifdef CWSLG_STAMP
+// diagnostic build only: copies the phase stamps of the last demod launch (8 x uint64 per workgroup)
+int cwslg_debug_read_stamps(unsigned long long *dst, size_t n_words)
+{
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), n_words * 8) == hipSuccess ? 0 : -8;
+}
+#endif
+
 int cwslg_channel_constants(cwslg_ctx *c, int ch_id, float *taps, float *tone_ri, float *phase_inc_ri)
 {
     if (!c) return CWSLG_ERR_ARG;
@@ -1146,6 +1155,8 @@ int cwslg_channel_constants(cwslg_ctx *c, int ch_id, float *taps, float *tone_ri
     if (phase_inc_ri) { phase_inc_ri[0] = ch.k.inc.real(); phase_inc_ri[1] = ch.k.inc.imag(); }
     return (int)ch.k.block;
 }
+
+int cwslg_phasor_checkpoint_stride(void) { return kCkptStride; }
 
 int cwslg_channel_phasor_checkpoints(cwslg_ctx *c, int ch_id, float *dst_ri, size_t n, size_t *n_total)
 {

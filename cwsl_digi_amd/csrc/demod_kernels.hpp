@@ -54,6 +54,10 @@ __device__ __forceinline__ CWSLG_GLOBAL T *as_global_rw(T *p)
     return (CWSLG_GLOBAL T *)(uintptr_t)p;
 }
 
+// Blocks between phasor checkpoints.  4 keeps the per-tile serial rebuild at <=4 dependent complex multiplies
+// (it sits at the head of every tile) for 1.6 % extra HBM traffic: 8 B per 4 blocks = per 512 B of IQ at 192 kHz.
+constexpr int kCk = 4;
+
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
@@ -116,7 +120,7 @@ __global__ void phasor_kernel(const PhasorJob *__restrict__ jobs, int n_jobs)
     for (unsigned c = 0; c < job.n_ckpt; ++c) {
         job.ckpt[c] = p;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) p = cmul_exact(p, job.inc);
+        for (int s = 0; s < kCk; ++s) p = cmul_exact(p, job.inc);
     }
 }
 
@@ -196,7 +200,7 @@ struct DemodGeom {
     // slots, and the 16 lanes of a b64 write spread over 8 bank pairs (2-way; the [2D][148] image was 4-way on b32).
     static constexpr int PR0    = (2 * NW + 3) / 4 * 4;
     static constexpr int PR     = ((PR0 / 4) % 2 == 1) ? PR0 : PR0 + 4;
-    static constexpr int NCK    = (NBLK + 15) / 16 + 1;   // checkpoints touched by a tile
+    static constexpr int NCK    = (NBLK + kCk - 1) / kCk + 1;   // checkpoints touched by a tile
     static constexpr int PLANE_FLOATS = D * PR;
     static constexpr int AUX_FLOATS   = (2 * (NBLK + 1) > T) ? 2 * (NBLK + 1) : T;  // phases, later the output row
     static constexpr int LDS_BYTES    = (2 * PLANE_FLOATS + AUX_FLOATS) * 4;
@@ -214,6 +218,22 @@ struct DemodGeom {
 //                    prefetch registers cost a workgroup of occupancy (163 VGPRs -> 3 per CU).
 // Barriers are raw `s_barrier` behind an `s_waitcnt lgkmcnt(0)`: __syncthreads() would also drain vmcnt, i.e.
 // wait for the prefetch.
+// Diagnostic build only (-DCWSLG_STAMP, scripts/gpu_stamps.sh): per-workgroup s_memtime stamps at the phase seams,
+// written to a buffer nothing else reads; the shipped library contains none of this.
+#ifdef CWSLG_STAMP
+__device__ unsigned long long g_stamps[8 * 65536];
+#define STAMP(slot)                                                                                 \
+    do {                                                                                            \
+        if (threadIdx.x == 0 && blockIdx.x < 65536 && stamp_on) {                                               \
+            unsigned long long t_;                                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+            g_stamps[8 * blockIdx.x + (slot)] = t_;                                                 \
+        }                                                                                           \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -265,9 +285,9 @@ __device__ __forceinline__ void decode_item(const ChanWork *sd, int tile, TileCt
     if (b < 0) b += c.cap;
     if (b >= (long long)c.cap) b -= c.cap;
     c.base = (unsigned)b;
-    const long long c0 = (qlo >= 0) ? (qlo >> 4) : -((15 - qlo) >> 4);          // floor(qlo/16)
+    const long long c0 = (qlo >= 0) ? (qlo / kCk) : -((kCk - 1 - qlo) / kCk);     // floor(qlo/kCk)
     c.ck_first = (int)c0;
-    c.pb0 = (int)((c0 << 4) - qlo);                                             // in (-16, 0]
+    c.pb0 = (int)(c0 * kCk - qlo);                                              // in (-kCk, 0]
 }
 
 template <int D, int T, int NT>
@@ -295,7 +315,7 @@ __device__ __forceinline__ void issue_tile_loads(const TileCtx<D, T> &c, int tid
 }
 
 template <int D, int T, int NT, bool PERSIST>
-__global__ __launch_bounds__(NT, PERSIST ? 3 : 4) void demod_kernel(const ChanWork *__restrict__ works,
+__global__ __launch_bounds__(NT, 4) void demod_kernel(const ChanWork *__restrict__ works,
                                                                      const float *__restrict__ taps,
                                                                      int tiles_x, int n_ch)
 {
@@ -314,6 +334,11 @@ __global__ __launch_bounds__(NT, PERSIST ? 3 : 4) void demod_kernel(const ChanWo
     __shared__ __attribute__((aligned(16))) float s_aux[Geo::AUX_FLOATS];
     __shared__ __attribute__((aligned(16))) unsigned s_desc[2][kDescWords];
     float2 *s_phase = reinterpret_cast<float2 *>(s_aux);
+#ifdef CWSLG_STAMP
+    bool stamp_on = !PERSIST;          // persistent mode: stamp the 100th tile of each workgroup only
+    int stamp_iter = 0;
+#endif
+    STAMP(0);
 
     // XCD-aware persistent schedule: XCD x owns items [x*per_xcd, (x+1)*per_xcd); its workgroups walk them with
     // stride n_slots, so neighbouring tiles (which share 31 blocks of halo) run on the same XCD at about the same time.
@@ -338,7 +363,9 @@ __global__ __launch_bounds__(NT, PERSIST ? 3 : 4) void demod_kernel(const ChanWo
     v4f xs[NIT];
     float2 ck;
     v4f tn;
+    STAMP(7);
     issue_tile_loads<D, T, NT>(cur, tid, xs, ck, tn);
+    STAMP(1);
 
     // per-thread LDS addresses of the scatter: r = 2*tid + 2*NT*it  ->  pair-row (r % G)/2 (constant), column w0 + WSTEP*it
     const int r0 = 2 * tid;
@@ -347,45 +374,62 @@ __global__ __launch_bounds__(NT, PERSIST ? 3 : 4) void demod_kernel(const ChanWo
     float *p1 = s_plane + Geo::PLANE_FLOATS + ((rel1 % G) >> 1) * PR + 2 * (rel1 / G - (2 * NT) / G);
     constexpr int WSTEP = (2 * NT) / G;                                             // columns per iteration
 
+    // PERSIST: descriptors run two items ahead of the tile being computed: `dword` (one lane = one descriptor word)
+    // holds item+2*n_slots' while s_desc[cb^1] holds item+n_slots', so no descriptor read is ever waited for.
+    unsigned dword = 0;
+    const bool desc_lane = PERSIST && tid >= 64 && tid < 64 + kDescWords;
+    if (PERSIST) {
+        const int i1 = item + n_slots;
+        if (desc_lane && i1 < hi_item) s_desc[1][tid - 64] = wwords[(size_t)(i1 / tiles_x) * kDescWords + (tid - 64)];
+        const int i2 = item + 2 * n_slots;
+        if (desc_lane && i2 < hi_item) dword = wwords[(size_t)(i2 / tiles_x) * kDescWords + (tid - 64)];
+    }
+
     for (;;) {
         const int nitem = item + n_slots;
         const bool has_next = PERSIST && nitem < hi_item;                           // wave-uniform
-        // wave 1 fetches the NEXT descriptor (one dword per lane) while wave 0 rebuilds the phasor
-        unsigned dword = 0;
-        const bool desc_lane = has_next && tid >= 64 && tid < 64 + kDescWords;
-        if (desc_lane) dword = wwords[(size_t)(nitem / tiles_x) * kDescWords + (tid - 64)];
-        // ---- phase 0: bit-exact phasor for the tile's T+31 blocks (lanes 0..NCK-1, <=16 un-fused steps each)
+        // ---- phase 0: bit-exact phasor for the tile's T+31 blocks (lanes 0..NCK-1, <=kCk un-fused steps each)
         {
             const int cidx = cur.ck_first + tid;
             if (tid < Geo::NCK && cidx >= 0) {
                 float2 p = ck;
-                const int pbase = cur.pb0 + 16 * tid;
+                const int pbase = cur.pb0 + kCk * tid;
 #pragma unroll
-                for (int s = 0; s < 16; ++s) {
+                for (int s = 0; s < kCk; ++s) {
                     const int pb = pbase + s;
                     if (pb >= 0 && pb < Geo::NBLK) s_phase[pb] = p;
                     p = cmul_exact(p, cur.inc);
                 }
             }
         }
-        if (desc_lane) s_desc[cb ^ 1][tid - 64] = dword;
-        lds_barrier();
+        lds_barrier();                                // s_phase ready; s_desc[cb^1] (written an iteration ago) visible
+        STAMP(2);
+#ifdef CWSLG_STAMP
+        if (!PERSIST) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        STAMP(3);
+#endif
 
-        // ---- prefetch: the NEXT item's loads go out now and land while this item is computed
+        // the descriptor two items ahead, loaded an iteration ago, moves into the slot the current item vacated (cur's
+        // fields live in registers); then fetch the one after it.  Placed BEFORE this iteration's prefetch loads so that
+        // the wait for `dword` cannot drain them (vmcnt retires in order).
+        if (PERSIST && desc_lane) {
+            if (nitem + n_slots < hi_item) s_desc[cb][tid - 64] = dword;
+            const int i3 = item + 3 * n_slots;
+            if (i3 < hi_item) dword = wwords[(size_t)(i3 / tiles_x) * kDescWords + (tid - 64)];
+        }
+        // ---- the NEXT item: decode now, its loads are issued in place as phase 1 frees the registers
         TileCtx<D, T> nxt = cur;
-        v4f xs_n[NIT];
-        float2 ck_n;
-        v4f tn_n;
-        // "defined" without an instruction: these are only read when has_next, and then they hold the loads
-        asm volatile("" : "=v"(ck_n.x), "=v"(ck_n.y), "=v"(tn_n.x), "=v"(tn_n.y), "=v"(tn_n.z), "=v"(tn_n.w));
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) asm volatile("" : "=v"(xs_n[it].x), "=v"(xs_n[it].y), "=v"(xs_n[it].z), "=v"(xs_n[it].w));
+        const CWSLG_GLOBAL v4f *nring4 = nullptr;
         if (has_next) {
             decode_item<D, T>(reinterpret_cast<const ChanWork *>(s_desc[cb ^ 1]), nitem % tiles_x, nxt);
-            issue_tile_loads<D, T, NT>(nxt, tid, xs_n, ck_n, tn_n);
+            nring4 = as_global(reinterpret_cast<const v4f *>(nxt.ring));
+            int cidx = nxt.ck_first + ((tid < Geo::NCK) ? tid : 0);
+            if (cidx < 0) cidx = 0;
+            const v2f t = as_global(reinterpret_cast<const v2f *>(nxt.ckpt))[cidx];       // ck was consumed by phase 0
+            ck = make_float2(t.x, t.y);
         }
 
-        if (cur.n_out > 0) {
+        if (cur.n_out > 0 || has_next) {
         // ---- phase 1: mix (x*tone)*phase, scatter Re -> plane 0, Im -> plane 1
         {
             float2 ph[NIT];
@@ -396,11 +440,18 @@ __global__ __launch_bounds__(NT, PERSIST ? 3 : 4) void demod_kernel(const ChanWo
                 ph[it] = s_phase[blk];
             }
             const float2 tn0 = make_float2(tn.x, tn.y), tn1 = make_float2(tn.z, tn.w);
+            if (has_next) tn = as_global(reinterpret_cast<const v4f *>(nxt.tone))[((2 * tid) % D) >> 1];
             const int fv = cur.first_valid;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int r = 2 * tid + it * 2 * NT;
                 const v4f x = xs[it];
+                if (has_next) {                                  // in-place prefetch: xs[it] is free from here on
+                    int rn = (r > Geo::NSAMP - 2) ? Geo::NSAMP - 2 : r;
+                    unsigned idx = nxt.base + (unsigned)rn;
+                    if (idx >= nxt.cap) idx -= nxt.cap;
+                    xs[it] = nring4[idx >> 1];
+                }
                 float ar = __builtin_fmaf(x.x, tn0.x, -(x.y * tn0.y));
                 float ai = __builtin_fmaf(x.x, tn0.y, x.y * tn0.x);
                 float y0r = __builtin_fmaf(ar, ph[it].x, -(ai * ph[it].y));
@@ -419,9 +470,10 @@ __global__ __launch_bounds__(NT, PERSIST ? 3 : 4) void demod_kernel(const ChanWo
             }
         }
         lds_barrier();
+        STAMP(4);
 
         // ---- phase 2: branch-pair FIRs + cross-lane reduction.  s_aux becomes the output row.
-        {
+        if (cur.n_out > 0) {
             const int g = lane / GL;
             const int pl = g & 1;
             const float sgn_plane = pl ? -cur.sign : 1.0f;
@@ -461,9 +513,10 @@ __global__ __launch_bounds__(NT, PERSIST ? 3 : 4) void demod_kernel(const ChanWo
             }
         }
         lds_barrier();
+        STAMP(5);
 
         // ---- epilogue: whole-row store + frame peak
-        {
+        if (cur.n_out > 0) {
             CWSLG_GLOBAL float *out = as_global_rw(cur.out) + (size_t)cur.tile * T;
             float mx = 0.0f;
             for (int o = tid; o < cur.n_out; o += NT) {
@@ -475,16 +528,18 @@ __global__ __launch_bounds__(NT, PERSIST ? 3 : 4) void demod_kernel(const ChanWo
             for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
             if (lane == 0 && mx > 0.0f) atomicMax(cur.peak, __float_as_uint(mx));
         }
-        }   // n_out > 0
+        STAMP(6);
+        }   // work in this iteration
         if (!has_next) break;
         lds_barrier();                                           // s_aux (= s_phase) is rewritten by the next phase 0
         cur = nxt;
         item = nitem;
         cb ^= 1;
-        ck = ck_n;
-        tn = tn_n;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) xs[it] = xs_n[it];
+#ifdef CWSLG_STAMP
+        ++stamp_iter;
+        stamp_on = (stamp_iter == 100);
+        STAMP(0); STAMP(7); STAMP(1);
+#endif
     }
 }
 
@@ -526,9 +581,9 @@ __global__ __launch_bounds__(NT) void demod_exact_kernel(const ChanWork *__restr
         const int cidx = cur.ck_first + tid;
         if (tid < Geo::NCK && cidx >= 0) {
             float2 p = ck;
-            const int pbase = cur.pb0 + 16 * tid;
+            const int pbase = cur.pb0 + kCk * tid;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
+            for (int s = 0; s < kCk; ++s) {
                 const int pb = pbase + s;
                 if (pb >= 0 && pb < Geo::NBLK) s_phase[pb] = p;
                 p = cmul_exact(p, cur.inc);

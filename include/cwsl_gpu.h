@@ -199,7 +199,9 @@ void *cwslg_stream(cwslg_ctx *ctx);
 /* Host-side DSP constants exactly as uploaded (tests pin them against the oracle):
  * taps[32*D], tone[2*D] (re,im), phase_inc[2]; returns D (= Fs/12000) or <0. */
 int cwslg_channel_constants(cwslg_ctx *ctx, int ch_id, float *taps, float *tone_ri, float *phase_inc_ri);
-/* Phasor checkpoints (every 16 blocks) as computed on the device: copies up to n complex values. */
+/* Phasor checkpoints as computed on the device: entry c is phase_{c*stride}, stride = cwslg_phasor_checkpoint_stride()
+ * blocks (one block = one 12 kHz output sample).  Copies up to n complex values. */
+int cwslg_phasor_checkpoint_stride(void);
 int cwslg_channel_phasor_checkpoints(cwslg_ctx *ctx, int ch_id, float *dst_ri, size_t n, size_t *n_total);
 
 #ifdef __cplusplus

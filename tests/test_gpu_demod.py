@@ -38,12 +38,13 @@ def test_phasor_checkpoints_bit_exact(ctx, oracle, f):
     """Device-built checkpoints == the float32 recurrence phase *= phase_inc (SSBD.hpp:174)."""
     rx = ctx.receiver_open(FS, IQ_LEN, 0)
     ch = ctx.channel_open(rx, f, "FT8")
-    ck = ctx.phasor_checkpoints(ch, 12000)           # 192000 blocks = 16 s
+    st = ctx.checkpoint_stride()
+    nblk = 192000                                      # 16 s
+    ck = ctx.phasor_checkpoints(ch, nblk // st)
     d = oracle.Demod(FS, f)
-    nblk = 192000
     _, tr = d.run(np.zeros(nblk * 16, np.complex64), trace=True)
-    assert len(ck) == 12000
-    assert np.array_equal(ck.view(np.uint64), tr[::16][:12000].view(np.uint64))
+    assert len(ck) == nblk // st
+    assert np.array_equal(ck.view(np.uint64), tr[::st][:nblk // st].view(np.uint64))
 
 
 def _run_gpu_slot(ctx, rx, chans, iq_a, iq_b, block=IQ_LEN):

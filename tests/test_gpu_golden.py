@@ -44,12 +44,13 @@ def test_slot_fixture(ctx, oracle, path):
     for got, want in ((fr["i16"][:256], g["i16_head"]), (fr["i16"][nv - 256:nv], g["i16_tail"])):
         assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1
     assert not fr["i16"][nv:].any()
-    # phasor: every stored index that is a checkpoint (multiple of 16) must be bit-exact
+    # phasor: every stored index that is a checkpoint (multiple of the stride) must be bit-exact
     idx = g["phasor_idx"]; bits = g["phasor_bits"]
-    ck = ctx.phasor_checkpoints(ch, int(idx.max()) // 16 + 1)
-    sel = idx % 16 == 0
+    st = ctx.checkpoint_stride()
+    ck = ctx.phasor_checkpoints(ch, int(idx.max()) // st + 1)
+    sel = idx % st == 0
     assert sel.sum() >= 3
-    assert np.array_equal(ck[idx[sel] // 16].view(np.uint64), bits[sel])
+    assert np.array_equal(ck[idx[sel] // st].view(np.uint64), bits[sel])
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "const_*.npz"))), ids=os.path.basename)
