@@ -333,11 +333,12 @@ __device__ __forceinline__ float costas_sync(const float (*s_s)[376], const floa
     return sy;
 }
 
-__global__ __launch_bounds__(256) void ft8_sync2d_kernel(const SyncWork *__restrict__ works, int ia, int ib, int nbins)
+constexpr int SYNC2D_NT = 512;          // 8 waves: one bin per wave at a time, 4 bins per wave per band
+__global__ __launch_bounds__(SYNC2D_NT) void ft8_sync2d_kernel(const SyncWork *__restrict__ works, int ia, int ib, int nbins)
 {
     constexpr int ROWS = SYNC_BAND + 12, PITCH = 376;
     __shared__ float s_s[ROWS][PITCH];
-    __shared__ float s_c0[4][PITCH];
+    __shared__ float s_c0[SYNC2D_NT / 64][PITCH];
     const SyncWork *w = works + blockIdx.y;
     const int i0 = ia + blockIdx.x * SYNC_BAND;
     const int tid = threadIdx.x;
@@ -345,18 +346,18 @@ __global__ __launch_bounds__(256) void ft8_sync2d_kernel(const SyncWork *__restr
     {
         const float *sp = w->spectra;
         constexpr int TOTAL = ROWS * FT8_NHSYM;            // 16368
-        for (int e0 = 0; e0 < TOTAL; e0 += 256 * 16) {
+        for (int e0 = 0; e0 < TOTAL; e0 += SYNC2D_NT * 16) {
             float v[16];
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int e = e0 + q * 256 + tid;
+                const int e = e0 + q * SYNC2D_NT + tid;
                 const int m = e / ROWS, r = e - m * ROWS;
                 const int bin = i0 + r;
                 v[q] = (e < TOTAL && bin < nbins) ? sp[(size_t)m * nbins + bin] : 0.0f;
             }
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int e = e0 + q * 256 + tid;
+                const int e = e0 + q * SYNC2D_NT + tid;
                 const int m = e / ROWS, r = e - m * ROWS;
                 if (e < TOTAL) s_s[r][m] = v[q];
             }
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(256) void ft8_sync2d_kernel(const SyncWork *__restr
     // one wave per bin from here on: no workgroup barriers, each wave owns s_c0[wv]
     const int lane = tid & 63, wv = tid >> 6;
     float *c0 = s_c0[wv];
-    for (int rr = wv; rr < SYNC_BAND; rr += 4) {
+    for (int rr = wv; rr < SYNC_BAND; rr += SYNC2D_NT / 64) {
         const int bin = i0 + rr;
         if (bin > ib) break;                            // wave-uniform
         // 7-tone sums of this bin for every symbol step (sequential k, as the restatement)
