@@ -257,8 +257,11 @@ int build_pending_phasors(cwslg_ctx *c)
     std::memcpy(w->h, jobs.data(), jobs.size() * sizeof(PhasorJob));
     HIPCHK(c, hipMemcpyAsync(w->d, w->h, jobs.size() * sizeof(PhasorJob), hipMemcpyHostToDevice, c->stream));
     const int n = (int)jobs.size();
-    hipLaunchKernelGGL(phasor_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream,
-                       (const PhasorJob *)w->d, n);
+    unsigned max_ckpt = 0;
+    for (const PhasorJob &j : jobs) max_ckpt = std::max(max_ckpt, j.n_ckpt);
+    hipLaunchKernelGGL(phasor_coarse_kernel, dim3((n + 63) / 64), dim3(64), 0, c->stream, (const PhasorJob *)w->d, n);
+    const unsigned segs = (max_ckpt + kCoarse - 1) / kCoarse;
+    hipLaunchKernelGGL(phasor_fine_kernel, dim3((segs + 63) / 64, (unsigned)n), dim3(64), 0, c->stream, (const PhasorJob *)w->d);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(w->done, c->stream));
     w->in_flight = true;

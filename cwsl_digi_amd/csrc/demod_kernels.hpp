@@ -110,17 +110,36 @@ __device__ __forceinline__ float2 cmul_exact(float2 a, float2 b)
     return make_float2(ac - bd, ad + bc);
 }
 
-// Phasor checkpoint table: one thread walks the whole recurrence of one channel once, at open time.
-__global__ void phasor_kernel(const PhasorJob *__restrict__ jobs, int n_jobs)
+// Phasor checkpoint table, built once per distinct tuning at channel-open time.  The recurrence is serial, so
+// pass 1 walks it with one lane per channel, keeping only every kCoarse-th checkpoint; pass 2 fills the checkpoints in
+// between with one lane per (channel, coarse segment), restarting from the coarse value -- the same multiplies in
+// the same order, so the table is bit-identical to a single serial walk (tests/test_gpu_demod.py).
+constexpr int kCoarse = 256;            // fine checkpoints per coarse segment (= 1024 blocks)
+
+__global__ void phasor_coarse_kernel(const PhasorJob *__restrict__ jobs, int n_jobs)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_jobs) return;
     const PhasorJob job = jobs[j];
     float2 p = make_float2(1.0f, 0.0f);                 // SSBD.hpp:121
-    for (unsigned c = 0; c < job.n_ckpt; ++c) {
+    for (unsigned c = 0; c < job.n_ckpt; c += kCoarse) {
         job.ckpt[c] = p;
+        for (int s = 0; s < kCoarse * kCk; ++s) p = cmul_exact(p, job.inc);
+    }
+}
+
+// grid (ceil(max segments / 64), n_jobs), 64 threads: lane = coarse segment
+__global__ void phasor_fine_kernel(const PhasorJob *__restrict__ jobs)
+{
+    const PhasorJob job = jobs[blockIdx.y];
+    const unsigned seg = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned c0 = seg * kCoarse;
+    if (c0 >= job.n_ckpt) return;
+    float2 p = job.ckpt[c0];
+    for (unsigned c = c0 + 1; c < c0 + kCoarse && c < job.n_ckpt; ++c) {
 #pragma unroll
         for (int s = 0; s < kCk; ++s) p = cmul_exact(p, job.inc);
+        job.ckpt[c] = p;
     }
 }
 
