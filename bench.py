@@ -78,6 +78,7 @@ def main():
     import torch.distributed as dist
     import numpy as np
     import cwsl_digi_amd as P
+    from cwsl_digi_amd import shard
 
     if args.same_device:
         local_rank = 0
@@ -99,8 +100,10 @@ def main():
     cap = ring_blocks * IQ_LEN
     chans, rxs, freqs = [], [], []
     t_setup = time.time()
+    my_slots = list(shard.slots_of_rank(S * world, rank, world))     # contiguous block partition, no data-path collective
+    assert len(my_slots) == S and my_slots[0] == rank * S
     for s in range(S):
-        gs = rank * S + s
+        gs = my_slots[s]
         f = slot_freq(gs)
         rx = ctx.receiver_open(FS, IQ_LEN, 0, ring_blocks=ring_blocks)
         tones = [f + 600.0 + 37.0 * (gs % 11), f + 1500.0, f + 2450.0 - 13.0 * (gs % 7)]
@@ -113,7 +116,6 @@ def main():
     ctx.synchronize()
     t_setup = time.time() - t_setup
 
-    flag = torch.zeros(1, dtype=torch.int32, device=dev)
 
     def step(k):
         ctx.ring_commit_all(SLOT_SAMPLES, IQ_LEN)     # the slot's IQ is already in HBM: bookkeeping only
@@ -121,9 +123,8 @@ def main():
         ctx.slot_boundary("FT8", 15 * (k + 2))         # batched peak-normalise + int16 (+ sync) ; frames swap
         if world > 1:
             ctx.synchronize()                          # frames of this epoch are final on this GPU ...
-            flag.fill_(S)
-            dist.all_reduce(flag)                      # ... and on every other GPU: 4-byte RCCL all-reduce (frames finalised)
-            assert int(flag.item()) == S * world
+            total = shard.slot_boundary_rendezvous(S, dev)   # ... and on every other GPU: 4-byte RCCL all-reduce (frames finalised)
+            assert total == S * world
     def barrier():
         ctx.synchronize()
         torch.cuda.synchronize()
@@ -186,15 +187,22 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
         cores = host_cores()
-        t1 = O.bench_cpu(1, 2)                         # single-thread rate (reported)
-        tc = O.bench_cpu(cores, 1)                     # calibrate the aggregate rate on `cores` threads
+        n_eff = SLOT_SAMPLES // IQ_LEN * IQ_LEN       # the CPU drivers push whole blocks only
+        if O.have_ref():
+            # kind "reference": the reference's own SSBD<float>/LowPass code (oracle/_ref, compiled from its headers)
+            fn, kind = O.bench_cpu_reference, "reference"
+            what = "reference SSBD.hpp/LowPass.hpp compiled -O2 -ffp-contract=off (Iterate loop + per-slot SSBD construction; " \
+                   "prepareAudio/int16, <2% of the path, not included)"
+        else:
+            fn, kind = O.bench_cpu, "port"
+            what = "oracle/cwsl_oracle.c -O2 -ffp-contract=off (whole path incl. prepareAudio + int16)"
+        t1 = fn(1, 2)                                  # single-thread rate (reported)
+        tc = fn(cores, 1)                              # calibrate the aggregate rate on `cores` threads
         slots_each = max(1, min(400, int(args.cpu_seconds / max(tc, 1e-3))))
-        tN = O.bench_cpu(cores, slots_each) if slots_each > 1 else tc
-        n_eff = SLOT_SAMPLES // IQ_LEN * IQ_LEN       # the CPU driver pushes whole blocks only
-        cpu = {"value": cores * slots_each * n_eff / tN / 1e6, "unit": "Msamples/s", "cores": cores,
-               "kind": "port",
-               "sample": f"{cores} channels x {slots_each} FT8 slots (2.88 M IQ samples each) on {cores} threads, "
-                         f"oracle/cwsl_oracle.c -O2 -ffp-contract=off; single thread: {2 * SLOT_SAMPLES / t1 / 1e6:.1f} Msamples/s"}
+        tN = fn(cores, slots_each) if slots_each > 1 else tc
+        cpu = {"value": cores * slots_each * n_eff / tN / 1e6, "unit": "Msamples/s", "cores": cores, "kind": kind,
+               "sample": f"{cores} channels x {slots_each} FT8 slots (2.88 M IQ samples each) on {cores} threads, {what}; "
+                         f"single thread: {2 * n_eff / t1 / 1e6:.1f} Msamples/s"}
 
     if rank == 0:
         launches = max(1, st["demod_launches"])

@@ -112,6 +112,8 @@ def ref():
         R.ref_ssbd_run.argtypes = [C.c_void_p, _f32p, C.c_uint64, _f32p, C.c_void_p]
         R.ref_ssbd_run.restype = C.c_int
         R.ref_build_lowpass.argtypes = [C.c_uint64, C.c_double, _f32p]
+        R.ref_bench_cpu.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint64]
+        R.ref_bench_cpu.restype = C.c_double
         _ref = R
     return _ref
 
@@ -383,3 +385,8 @@ def ft4_candidates(frame_i16, fa_hz=200.0, fb_hz=4000.0, syncmin=1.2, maxcand=20
     assert n >= 0
     cands = [(buf[k].freq_bin, buf[k].time_step, buf[k].sync, buf[k].freq_hz, buf[k].dt_s) for k in range(n)]
     return (cands, dict(savsm=sm, sbase=sb)) if want_arrays else cands
+
+
+def bench_cpu_reference(threads, slots, fs=192000, iq_len=2048, n_per_slot=2880000):
+    """Wall seconds of the REFERENCE's own SSBD<float> loop (oracle/_ref) for `threads` channels x `slots` slots."""
+    return float(ref().ref_bench_cpu(threads, slots, fs, iq_len, n_per_slot))

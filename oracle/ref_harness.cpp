@@ -21,6 +21,8 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cmath>
+#include <thread>
+#include <chrono>
 
 #define private public
 #include "SSBD.hpp"
@@ -104,6 +106,45 @@ void ref_build_lowpass(uint64_t order, double bandwidth, float* taps)
     float* f = BuildLowPass<float>(order, bandwidth);
     for (size_t n = 0; n < order; ++n) taps[n] = f[n];
     delete[] f;
+}
+
+// CPU baseline of kind "reference": the reference's own SSBD<float>::Iterate loop, driven exactly like
+// Instance::sampleManager does (one thread per channel, iq_len-sample blocks, a new SSBD per slot; Instance.cpp:251,273-275).
+// Returns wall seconds for `threads` channels x `slots` slots of n_per_slot samples, or <0 on error.
+double ref_bench_cpu(int threads, int slots, uint64_t Fs, uint32_t iq_len, uint64_t n_per_slot)
+{
+    if (threads < 1 || threads > 4096 || slots < 1) return -1.0;
+    std::vector<std::vector<float>> iq(threads), out(threads);
+    for (int t = 0; t < threads; ++t) {
+        iq[t].resize(2 * n_per_slot);
+        out[t].resize(n_per_slot / (Fs / 12000) + 16);
+        uint64_t z = 0x9E3779B97F4A7C15ull * (uint64_t)(t + 1);
+        for (size_t k = 0; k < iq[t].size(); ++k) {           // cheap deterministic noise; values do not matter for timing
+            z ^= z << 13; z ^= z >> 7; z ^= z << 17;
+            iq[t][k] = (float)((int)(z & 0xFFFF) - 32768) * 0.05f;
+        }
+    }
+    std::vector<std::thread> th;
+    std::vector<int> rc(threads, 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < threads; ++t) {
+        th.emplace_back([&, t]() {
+            try {
+                const std::complex<float>* xc = reinterpret_cast<const std::complex<float>*>(iq[t].data());
+                for (int s = 0; s < slots; ++s) {
+                    SSBD<float> ssbd(Fs, 6000, (float)(-26000 + 137 * t), true);
+                    const size_t in_size = ssbd.GetInSize(), dec = in_size / 4;
+                    for (uint64_t b = 0; b + iq_len <= n_per_slot; b += iq_len)
+                        for (size_t n = 0; n < iq_len; n += in_size)
+                            ssbd.Iterate(xc + b + n, out[t].data() + (b + n) / dec);
+                }
+            } catch (...) { rc[t] = -1; }
+        });
+    }
+    for (auto& x : th) x.join();
+    const auto t1 = std::chrono::steady_clock::now();
+    for (int r : rc) if (r) return -1.0;
+    return std::chrono::duration<double>(t1 - t0).count();
 }
 
 } // extern "C"
