@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--slots", type=int, default=512, help="FT8 slots per GPU")
     ap.add_argument("--sync", type=int, default=1, help="run the FT8 sync stage (symbol spectra + Costas search) at every boundary")
+    ap.add_argument("--channels-per-rx", type=int, default=1,
+                    help="1 = private IQ stream per slot (BASELINE configs); C>1 = the reference's topology, C decoders share one receiver's IQ (<=8)")
     ap.add_argument("--exact", action="store_true", help="reference-order arithmetic (cwslg_set_exact): bit-exact, slower")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU tensors; for checking the N>1 path on a 1-GPU box)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses GPU 0")
@@ -102,16 +104,24 @@ def main():
     t_setup = time.time()
     my_slots = list(shard.slots_of_rank(S * world, rank, world))     # contiguous block partition, no data-path collective
     assert len(my_slots) == S and my_slots[0] == rank * S
-    for s in range(S):
-        gs = my_slots[s]
-        f = slot_freq(gs)
+    C = max(1, min(8, args.channels_per_rx))
+    assert S % C == 0
+    rx_meta = []
+    for r in range(S // C):
+        group = my_slots[r * C:(r + 1) * C]
+        fl = [slot_freq(gs) for gs in group]
+        gs0 = group[0]
+        if C == 1:
+            tones = [fl[0] + 600.0 + 37.0 * (gs0 % 11), fl[0] + 1500.0, fl[0] + 2450.0 - 13.0 * (gs0 % 7)]
+        else:
+            tones = [f + 1500.0 for f in fl]
         rx = ctx.receiver_open(FS, IQ_LEN, 0, ring_blocks=ring_blocks)
-        tones = [f + 600.0 + 37.0 * (gs % 11), f + 1500.0, f + 2450.0 - 13.0 * (gs % 7)]
         half = cap // 2
-        ctx.push_synth(rx, 0xC0FFEE ^ gs, half, IQ_LEN, tones_hz=tones, amp=2.0e4)   # fill the ring (no channel yet)
-        ctx.push_synth(rx, 0xC0FFEE ^ gs, cap - half, IQ_LEN, tones_hz=tones, amp=2.0e4)
-        ch = ctx.channel_open(rx, f, "FT8")
-        rxs.append(rx); chans.append(ch); freqs.append((f, tones))
+        ctx.push_synth(rx, 0xC0FFEE ^ gs0, half, IQ_LEN, tones_hz=tones, amp=2.0e4)   # fill the ring (no channel yet)
+        ctx.push_synth(rx, 0xC0FFEE ^ gs0, cap - half, IQ_LEN, tones_hz=tones, amp=2.0e4)
+        for f in fl:
+            ch = ctx.channel_open(rx, f, "FT8")
+            rxs.append(rx); chans.append(ch); freqs.append((f, tones, 0xC0FFEE ^ gs0))
     ctx.slot_boundary("FT8", 1)           # the reference's discarded first (partial) frame
     ctx.synchronize()
     t_setup = time.time() - t_setup
@@ -161,9 +171,8 @@ def main():
         mism = 0
         laps = args.warmup + args.steps
         for s in range(min(args.verify, S)):
-            gs = rank * S + s
-            f, tones = freqs[s]
-            ring = O.synth_iq(0xC0FFEE ^ gs, cap, FS, tones_hz=tones, amp=2.0e4)    # ring content (sample index = ring index)
+            f, tones, seed = freqs[s]
+            ring = O.synth_iq(seed, cap, FS, tones_hz=tones, amp=2.0e4)    # ring content (sample index = ring index)
             start = ((laps - 1) * SLOT_SAMPLES) % cap
             idx = (start + np.arange(SLOT_SAMPLES)) % cap
             iq = ring[idx]
@@ -208,13 +217,14 @@ def main():
         launches = max(1, st["demod_launches"])
         avg_ms = st["demod_ms"] / launches
         samples_per_launch = S * SLOT_SAMPLES
-        achieved = BYTES_PER_SAMPLE_DEMOD * samples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        bps = 8.0 / C + 4.0 / 16                      # IQ is fetched once per receiver, audio written per channel
+        achieved = bps * samples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
         if os.path.isfile(tp):
             try:
                 tj = json.load(open(tp))
-                if tj.get("slots") == S:
+                if tj.get("slots") == S and C == 1 and not args.exact:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -223,14 +233,15 @@ def main():
             "value": msps, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{S} FT8 slots/GPU x 15 s (2.88 M IQ samples) at 192 kHz, private IQ stream per slot "
+            "config": {"workload": f"{S} FT8 slots/GPU x 15 s (2.88 M IQ samples) at 192 kHz, " + ("private IQ stream per slot " if C == 1 else f"{C} slots share each receiver's IQ (reference topology) ") +
                                    f"(BASELINE configs[3] share 4096/8=512 per GPU; same kernel as configs[1]'s 64 slots)",
-                       "slots_per_gpu": S, "fs_hz": FS, "iq_block": IQ_LEN, "stages": "nco-mix+polyphase-decimate, peak-normalise+int16" + (", ft8 symbol-spectra+costas-sync+candidates" if args.sync else ""),
+                       "slots_per_gpu": S, "channels_per_receiver": C, "fs_hz": FS, "iq_block": IQ_LEN, "stages": "nco-mix+polyphase-decimate, peak-normalise+int16" + (", ft8 symbol-spectra+costas-sync+candidates" if args.sync else ""),
                        "sharding": f"slots x{world}, RCCL 4-byte all-reduce per slot boundary" if world > 1 else "single GPU"},
             "realtime_ft8_slots": msps / 0.192,
             "roofline": {"bound": "hbm", "kernel": "demod_exact_kernel<16,256,256>" if args.exact else "demod_kernel<16,256,256,false>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_sample": BYTES_PER_SAMPLE_DEMOD, "samples_per_launch": samples_per_launch,
+                         "bytes_per_sample": bps, "samples_per_launch": samples_per_launch,
+                         "valu_tflops": 80.0 * samples_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
                          "avg_launch_ms": avg_ms, "launches": st["demod_launches"],
                          "finalize_avg_ms": st["finalize_ms"] / max(1, st["finalize_launches"]),
                          "sync_avg_ms": st["sync_ms"] / max(1, st["sync_launches"]),

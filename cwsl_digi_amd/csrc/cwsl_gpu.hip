@@ -114,6 +114,7 @@ struct cwslg_ctx {
     std::mutex mu;
     int device = 0;
     int cu_count = 256;
+    int order_override = 0;            // CWSLG_ITEM_ORDER=1 channel-major, 2 tile-major (A/B); 0 = by topology
     bool exact = false;                // cwslg_set_exact: reference-order arithmetic (bit-exact, slower)
     int demod_variant = 0;             // 0 = one workgroup per tile (default), 1 = persistent + prefetch (CWSLG_DEMOD_VARIANT=1)
     hipStream_t stream = nullptr;
@@ -269,15 +270,16 @@ int build_pending_phasors(cwslg_ctx *c)
 }
 
 template <int D>
-int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_blocks, uint32_t fs)
+int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_blocks, uint32_t fs, bool tile_major)
 {
     if (works.empty()) return CWSLG_OK;
     WorkBuf *w = acquire_workbuf(c, works.size() * sizeof(ChanWork));
     if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
     std::memcpy(w->h, works.data(), works.size() * sizeof(ChanWork));
     HIPCHK(c, hipMemcpyAsync(w->d, w->h, works.size() * sizeof(ChanWork), hipMemcpyHostToDevice, c->stream));
-    const int tiles_x = (int)((max_blocks + kTile - 1) / kTile);
-    const long long total = (long long)tiles_x * (long long)works.size();
+    const int tiles_n = (int)((max_blocks + kTile - 1) / kTile);
+    const int tiles_x = tile_major ? -tiles_n : tiles_n;        // sign selects the work-item order (demod_kernels.hpp)
+    const long long total = (long long)tiles_n * (long long)works.size();
     const long long per_xcd = (total + 7) / 8;
     hipEvent_t ea, eb;
     span_begin(c, 0, &ea, &eb);
@@ -310,39 +312,49 @@ int process_locked(cwslg_ctx *c)
 {
     int rc = build_pending_phasors(c);
     if (rc) return rc;
-    // one launch per distinct sample rate
+    // one launch per distinct sample rate; channels grouped by receiver so that a receiver's channels are neighbours
     std::map<uint32_t, std::vector<ChanWork>> by_fs;
     std::map<uint32_t, unsigned> max_blocks;
-    for (Channel &ch : c->chans) {
-        if (!ch.open || ch.pend_n == 0) continue;
-        Receiver &rx = c->rxs[ch.rx];
-        ChanWork w{};
-        w.ring = rx.d_ring;
-        w.out = ch.d_frame[ch.wr] + ch.pend_fill0;
-        w.peak = ch.d_peak + ch.wr;
-        w.ckpt = c->phasors[ch.phasor_key].d_ckpt;
-        w.tone = ch.d_tone;
-        w.lo_abs = ch.pend_lo;
-        w.origin_abs = ch.origin_abs;
-        w.ring_cap = rx.cap;
-        w.n_blocks = ch.pend_n / rx.D;
-        w.inc = make_float2(ch.k.inc.real(), ch.k.inc.imag());
-        w.sign = ch.k.sign;
-        w.lo_mod = (unsigned)((uint64_t)ch.pend_lo % rx.cap);
-        w.q_first = (ch.pend_lo - ch.origin_abs) / (int64_t)rx.D;
-        by_fs[rx.fs].push_back(w);
-        max_blocks[rx.fs] = std::max(max_blocks[rx.fs], w.n_blocks);
-        c->stats.demod_samples += ch.pend_n;
-        ch.pend_lo += ch.pend_n;
-        ch.pend_fill0 += ch.pend_n / rx.D;
-        ch.pend_n = 0;
+    std::map<uint32_t, unsigned> max_share;            // most channels with pending work on one receiver
+    for (size_t r = 0; r < c->rxs.size(); ++r) {
+        Receiver &rx = c->rxs[r];
+        if (!rx.open) continue;
+        unsigned share = 0;
+        for (int id : rx.channels) {
+            Channel &ch = c->chans[id];
+            if (!ch.open || ch.pend_n == 0) continue;
+            ++share;
+            ChanWork w{};
+            w.ring = rx.d_ring;
+            w.out = ch.d_frame[ch.wr] + ch.pend_fill0;
+            w.peak = ch.d_peak + ch.wr;
+            w.ckpt = c->phasors[ch.phasor_key].d_ckpt;
+            w.tone = ch.d_tone;
+            w.lo_abs = ch.pend_lo;
+            w.origin_abs = ch.origin_abs;
+            w.ring_cap = rx.cap;
+            w.n_blocks = ch.pend_n / rx.D;
+            w.inc = make_float2(ch.k.inc.real(), ch.k.inc.imag());
+            w.sign = ch.k.sign;
+            w.lo_mod = (unsigned)((uint64_t)ch.pend_lo % rx.cap);
+            w.q_first = (ch.pend_lo - ch.origin_abs) / (int64_t)rx.D;
+            by_fs[rx.fs].push_back(w);
+            max_blocks[rx.fs] = std::max(max_blocks[rx.fs], w.n_blocks);
+            c->stats.demod_samples += ch.pend_n;
+            ch.pend_lo += ch.pend_n;
+            ch.pend_fill0 += ch.pend_n / rx.D;
+            ch.pend_n = 0;
+        }
+        max_share[rx.fs] = std::max(max_share[rx.fs], share);
     }
     for (auto &kv : by_fs) {
         const uint32_t fs = kv.first;
         const uint32_t D = fs / kWaveSR;
-        if (D == 16) rc = launch_demod<16>(c, kv.second, max_blocks[fs], fs);
-        else if (D == 8) rc = launch_demod<8>(c, kv.second, max_blocks[fs], fs);
-        else if (D == 4) rc = launch_demod<4>(c, kv.second, max_blocks[fs], fs);
+        // receivers shared by several channels: tile-major order (the IQ tile is fetched once, then served from L2)
+        const bool tile_major = c->order_override ? (c->order_override == 2) : (max_share[fs] >= 2);
+        if (D == 16) rc = launch_demod<16>(c, kv.second, max_blocks[fs], fs, tile_major);
+        else if (D == 8) rc = launch_demod<8>(c, kv.second, max_blocks[fs], fs, tile_major);
+        else if (D == 4) rc = launch_demod<4>(c, kv.second, max_blocks[fs], fs, tile_major);
         else rc = fail(c, CWSLG_ERR_UNSUPPORTED, "sample rate %u unsupported", fs);
         if (rc) return rc;
     }
@@ -531,6 +543,7 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
     c->device = device_ordinal;
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *v = std::getenv("CWSLG_DEMOD_VARIANT")) c->demod_variant = std::atoi(v);
+    if (const char *v = std::getenv("CWSLG_ITEM_ORDER")) c->order_override = std::atoi(v);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
     if (hipHostMalloc((void **)&c->h_stage, 2 * kStageHalf, hipHostMallocDefault) != hipSuccess) return CWSLG_ERR_NOMEM;
     hipEventCreateWithFlags(&c->stage_ev[0], hipEventDisableTiming);

@@ -260,6 +260,17 @@ __device__ __forceinline__ void lds_barrier()
 
 constexpr int kDescWords = sizeof(ChanWork) / 4;
 
+// Work-item order.  tiles_x > 0: channel-major (item = ch*tiles_x + tile): neighbouring items are neighbouring tiles of
+// one channel, whose 31-block halo then hits the XCD's L2 -- right for private IQ streams.  tiles_x < 0: tile-major
+// (item = tile*n_ch + ch): neighbouring items are the channels of one receiver at the same tile, so the receiver's IQ
+// is fetched from HBM once and served from L2 to its other channels -- right for the reference's real topology
+// (many decoders per band).
+__device__ __forceinline__ void item_to_ch_tile(int item, int tiles_x, int n_ch, int &ch, int &tile)
+{
+    if (tiles_x > 0) { ch = item / tiles_x; tile = item - ch * tiles_x; }
+    else { tile = item / n_ch; ch = item - tile * n_ch; }
+}
+
 template <int D, int T>
 struct TileCtx {                 // wave-uniform description of one work item (held in SGPRs)
     const float2 *ring, *ckpt, *tone;
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(NT, 4) void demod_kernel(const ChanWork *__restrict
 
     // XCD-aware persistent schedule: XCD x owns items [x*per_xcd, (x+1)*per_xcd); its workgroups walk them with
     // stride n_slots, so neighbouring tiles (which share 31 blocks of halo) run on the same XCD at about the same time.
-    const int total = tiles_x * n_ch;
+    const int total = (tiles_x < 0 ? -tiles_x : tiles_x) * n_ch;
     const int per_xcd = (total + 7) >> 3;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, n_slots = gridDim.x >> 3;
     const int hi_item = min((xcd + 1) * per_xcd, total);
@@ -378,7 +389,9 @@ __global__ __launch_bounds__(NT, 4) void demod_kernel(const ChanWork *__restrict
     const CWSLG_GLOBAL unsigned *wwords = as_global(reinterpret_cast<const unsigned *>(works));
     int cb = 0;
     TileCtx<D, T> cur;
-    decode_item<D, T>(works + item / tiles_x, item % tiles_x, cur);
+    int ich, itile;
+    item_to_ch_tile(item, tiles_x, n_ch, ich, itile);
+    decode_item<D, T>(works + ich, itile, cur);
     v4f xs[NIT];
     float2 ck;
     v4f tn;
@@ -399,9 +412,9 @@ __global__ __launch_bounds__(NT, 4) void demod_kernel(const ChanWork *__restrict
     const bool desc_lane = PERSIST && tid >= 64 && tid < 64 + kDescWords;
     if (PERSIST) {
         const int i1 = item + n_slots;
-        if (desc_lane && i1 < hi_item) s_desc[1][tid - 64] = wwords[(size_t)(i1 / tiles_x) * kDescWords + (tid - 64)];
+        if (desc_lane && i1 < hi_item) { item_to_ch_tile(i1, tiles_x, n_ch, ich, itile); s_desc[1][tid - 64] = wwords[(size_t)ich * kDescWords + (tid - 64)]; }
         const int i2 = item + 2 * n_slots;
-        if (desc_lane && i2 < hi_item) dword = wwords[(size_t)(i2 / tiles_x) * kDescWords + (tid - 64)];
+        if (desc_lane && i2 < hi_item) { item_to_ch_tile(i2, tiles_x, n_ch, ich, itile); dword = wwords[(size_t)ich * kDescWords + (tid - 64)]; }
     }
 
     for (;;) {
@@ -434,13 +447,15 @@ __global__ __launch_bounds__(NT, 4) void demod_kernel(const ChanWork *__restrict
         if (PERSIST && desc_lane) {
             if (nitem + n_slots < hi_item) s_desc[cb][tid - 64] = dword;
             const int i3 = item + 3 * n_slots;
-            if (i3 < hi_item) dword = wwords[(size_t)(i3 / tiles_x) * kDescWords + (tid - 64)];
+            if (i3 < hi_item) { int c3, t3; item_to_ch_tile(i3, tiles_x, n_ch, c3, t3); dword = wwords[(size_t)c3 * kDescWords + (tid - 64)]; }
         }
         // ---- the NEXT item: decode now, its loads are issued in place as phase 1 frees the registers
         TileCtx<D, T> nxt = cur;
         const CWSLG_GLOBAL v4f *nring4 = nullptr;
         if (has_next) {
-            decode_item<D, T>(reinterpret_cast<const ChanWork *>(s_desc[cb ^ 1]), nitem % tiles_x, nxt);
+            int nch, ntile;
+            item_to_ch_tile(nitem, tiles_x, n_ch, nch, ntile);
+            decode_item<D, T>(reinterpret_cast<const ChanWork *>(s_desc[cb ^ 1]), ntile, nxt);
             nring4 = as_global(reinterpret_cast<const v4f *>(nxt.ring));
             int cidx = nxt.ck_first + ((tid < Geo::NCK) ? tid : 0);
             if (cidx < 0) cidx = 0;
@@ -584,13 +599,15 @@ __global__ __launch_bounds__(NT) void demod_exact_kernel(const ChanWork *__restr
     __shared__ float2 s_t[Geo::NBLK * (D + 1)];
     __shared__ float2 s_phase[Geo::NBLK + 1];
 
-    const int total = tiles_x * n_ch;
+    const int total = (tiles_x < 0 ? -tiles_x : tiles_x) * n_ch;
     const int per_xcd = (total + 7) >> 3;
     const int wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (wid >= total) return;
     const int tid = threadIdx.x;
     TileCtx<D, T> cur;
-    decode_item<D, T>(works + wid / tiles_x, wid % tiles_x, cur);
+    int ich, itile;
+    item_to_ch_tile(wid, tiles_x, n_ch, ich, itile);
+    decode_item<D, T>(works + ich, itile, cur);
     if (cur.n_out == 0) return;
     v4f xs[NIT];
     float2 ck;
