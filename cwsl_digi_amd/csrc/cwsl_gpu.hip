@@ -330,8 +330,6 @@ int process_locked(cwslg_ctx *c)
             w.peak = ch.d_peak + ch.wr;
             w.ckpt = c->phasors[ch.phasor_key].d_ckpt;
             w.tone = ch.d_tone;
-            w.lo_abs = ch.pend_lo;
-            w.origin_abs = ch.origin_abs;
             w.ring_cap = rx.cap;
             w.n_blocks = ch.pend_n / rx.D;
             w.inc = make_float2(ch.k.inc.real(), ch.k.inc.imag());

@@ -68,15 +68,14 @@ struct alignas(16) ChanWork {
     unsigned     *peak;       // max|audio| of the frame, as float bits (atomicMax)
     const float2 *ckpt;       // phasor checkpoints: ckpt[c] = phase_{16c}
     const float2 *tone;       // tone[D]
-    long long     lo_abs;     // absolute sample index of the first pending sample
-    long long     origin_abs; // absolute sample index at which the demodulator was (re)created
     unsigned      ring_cap;   // ring capacity in complex samples
     unsigned      n_blocks;   // pending outputs (= pending samples / D)
     float2        inc;        // phase_inc
     float         sign;       // +1 USB, -1 LSB
-    unsigned      lo_mod;     // lo_abs mod ring_cap (host-computed: no 64-bit division on the device)
-    long long     q_first;    // (lo_abs - origin_abs) / D : block index of the first pending output
+    unsigned      lo_mod;     // ring index of the first pending sample (host-computed: no 64-bit division on the device)
+    long long     q_first;    // block index of the first pending output, counted from the demodulator's (re)creation
 };
+static_assert(sizeof(ChanWork) == 80, "descriptor layout (kDescWords lanes stage it through LDS)");
 
 // One entry per channel per finalize launch.
 struct alignas(16) FinWork {

@@ -1,0 +1,47 @@
+// End-to-end run of the C++ shim (include/cwsl_gpu_shim.hpp) the way a CWSL_DIGI maintainer would use it:
+// Receiver::readIQ -> port.push(block); slot clock -> ctx.slotBoundary(); Instance -> chan.fetch() -> ItemToDecode.
+// Built and executed by tests/test_gpu_shim.py; prints "<status> <n_valid-ish> <crc32 of the int16 frame>".
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+#include "../include/cwsl_gpu_shim.hpp"
+
+static uint32_t crc32(const void *data, size_t n)
+{
+    const uint8_t *p = static_cast<const uint8_t *>(data);
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t k = 0; k < n; ++k) { c ^= p[k]; for (int b = 0; b < 8; ++b) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u))); }
+    return c ^ 0xFFFFFFFFu;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) return 2;
+    FILE *f = std::fopen(argv[1], "rb");            // complex64 IQ, 2048-sample blocks, written by the test
+    if (!f) return 3;
+    try {
+        cwslgpu::Context ctx(0);
+        cwslgpu::ReceiverPort rx(ctx, 192000, 2048, 28100000);
+        cwslgpu::SsbChannel chan(rx, 28074000.0 - 28100000.0, true, "FT8");
+        bool threw = false;
+        try { cwslgpu::SsbChannel bad(rx, 97000.0, true, "FT8"); } catch (const std::invalid_argument &e) {
+            threw = std::string(e.what()) == "Signal outside of band (low)";      // SSBD.hpp:101
+        }
+        if (!threw) return 4;
+        std::vector<std::complex<float>> blk(2048);
+        std::vector<std::int16_t> audio;
+        std::uint64_t t0 = 0;
+        ctx.slotBoundary(CWSLG_GROUP_FT8, 1000);
+        if (chan.fetch(audio, t0)) return 5;          // first (partial) slot: nothing to decode (Instance.cpp:224-227)
+        while (std::fread(blk.data(), sizeof(blk[0]), blk.size(), f) == blk.size()) rx.push(blk.data(), 2048);
+        ctx.slotBoundary(CWSLG_GROUP_FT8, 1015);
+        if (!chan.fetch(audio, t0)) return 6;
+        std::printf("OK %llu %zu %08x %zu %zu\n", (unsigned long long)t0, audio.size(), crc32(audio.data(), audio.size() * 2),
+                    chan.GetInSize(), chan.GetOutRate());
+    } catch (const std::exception &e) {
+        std::printf("EXC %s\n", e.what());
+        return 7;
+    }
+    std::fclose(f);
+    return 0;
+}
