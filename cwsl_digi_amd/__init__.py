@@ -5,6 +5,8 @@ This package is only the loader plus a thin Python mirror of that ABI for tests 
 There is no CPU fallback anywhere in this package.
 """
 from .api import (Context, CwslGpuError, GROUPS, group_of, frame_len, load_library,  # noqa: F401
-                  STATUS_NAMES, parse_decoder_line)
+                  STATUS_NAMES, parse_decoder_line, decoder_block_bytes, decoder_block_field,
+                  decoder_route, decoder_command)
 
-__all__ = ["Context", "CwslGpuError", "GROUPS", "group_of", "frame_len", "load_library", "STATUS_NAMES", "parse_decoder_line"]
+__all__ = ["Context", "CwslGpuError", "GROUPS", "group_of", "frame_len", "load_library", "STATUS_NAMES", "parse_decoder_line",
+           "decoder_block_bytes", "decoder_block_field", "decoder_route", "decoder_command"]

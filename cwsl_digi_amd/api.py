@@ -94,6 +94,7 @@ ABI_SYMBOLS = [
     "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_write_wav", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
     "cwslg_enable_sync", "cwslg_fetch_candidates", "cwslg_set_ft4_syncmin", "cwslg_sync_debug_fetch", "cwslg_get_stats", "cwslg_reset_stats",
     "cwslg_set_timing", "cwslg_stream", "cwslg_channel_constants", "cwslg_phasor_checkpoint_stride", "cwslg_channel_phasor_checkpoints",
+    "cwslg_decoder_block_bytes", "cwslg_decoder_block_field", "cwslg_fill_decoder_block", "cwslg_decoder_route", "cwslg_decoder_command",
 ]
 
 
@@ -152,8 +153,46 @@ def load_library(build_if_missing=True):
     L.cwslg_stream.argtypes = [vp]; L.cwslg_stream.restype = vp
     L.cwslg_channel_constants.argtypes = [vp, i32, vp, vp, vp]
     L.cwslg_channel_phasor_checkpoints.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.cwslg_decoder_block_bytes.argtypes = [i32]; L.cwslg_decoder_block_bytes.restype = C.c_size_t
+    L.cwslg_decoder_block_field.argtypes = [i32, C.c_char_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.cwslg_fill_decoder_block.argtypes = [vp, i32, vp, C.c_size_t, i32, i32, i32, C.POINTER(u64)]
+    L.cwslg_decoder_route.argtypes = [C.c_char_p, i32]
+    L.cwslg_decoder_command.argtypes = [C.c_char_p, i32, i32, i32, i32, i32, f32, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
     _lib = L
     return L
+
+
+def decoder_block_bytes(js8=False):
+    """sizeof(dec_data_t) / sizeof(dec_data_js8_t) (DecoderPool.hpp:58-108 / :110-171)."""
+    return load_library().cwslg_decoder_block_bytes(int(js8))
+
+
+def decoder_block_field(name, js8=False):
+    """(offset, bytes) of a member of the decoder block: ipc/ss/savg/sred/d2/params or a params field name."""
+    off, n = C.c_size_t(), C.c_size_t()
+    rc = load_library().cwslg_decoder_block_field(int(js8), name.encode(), C.byref(off), C.byref(n))
+    if rc != 0:
+        raise CwslGpuError(rc, f"no member {name!r} in the decoder block")
+    return off.value, n.value
+
+
+def decoder_route(mode, transfer_shmem=True):
+    """'shmem' or 'wavefile' -- DecoderPool.hpp:379-395."""
+    rc = load_library().cwslg_decoder_route(mode.encode(), int(transfer_shmem))
+    if rc < 0:
+        raise CwslGpuError(rc, f"Unhandled mode: {mode}")
+    return "shmem" if rc == 1 else "wavefile"
+
+
+def decoder_command(mode, target, shmem_route, numjt9threads=3, decodedepth=3, highest_decode_hz=3000, wspr_cycles=3000,
+                    trperiod=0.0):
+    """(program, argument string) exactly as DecoderPool.hpp:634-659 / :1007-1046 concatenate them."""
+    app, opts = C.create_string_buffer(64), C.create_string_buffer(1024)
+    rc = load_library().cwslg_decoder_command(mode.encode(), int(shmem_route), numjt9threads, decodedepth, highest_decode_hz,
+                                              wspr_cycles, float(trperiod), str(target).encode(), app, 64, opts, 1024)
+    if rc != 0:
+        raise CwslGpuError(rc, f"Mode {mode} not handled")
+    return app.value.decode(), opts.value.decode()
 
 
 class Context:
@@ -251,7 +290,10 @@ class Context:
         self._chk(self.L.cwslg_process(self.h))
 
     def slot_boundary(self, group, epoch_s):
-        g = GROUPS[group] if isinstance(group, str) else int(group)
+        if isinstance(group, str):                       # a group name ("S120") or a mode name ("WSPR" -> its group)
+            g = GROUPS[group] if group in GROUPS else _MODE_GROUP[group]
+        else:
+            g = int(group)
         self._chk(self.L.cwslg_slot_boundary(self.h, g, int(epoch_s)))
 
     def slot_boundary_channel(self, ch, epoch_s):
@@ -274,6 +316,21 @@ class Context:
     def write_wav(self, ch, path):
         """The reference's 46-byte-header 12 kHz mono int16 .wav of the last finalised frame (WaveFile.hpp:87-135)."""
         self._chk(self.L.cwslg_write_wav(self.h, ch, str(path).encode()))
+
+    def fill_decoder_block(self, ch, block=None, js8=False, decodedepth=3, highest_decode_hz=3000):
+        """The jt9/js8 shared-memory block for the last finalised frame (DecoderPool.hpp:451-590).  `block` is a
+        writable uint8 array of decoder_block_bytes(js8) (e.g. a mapped shared-memory segment) or None to allocate.
+        Returns (block, t_start) or None before the first frame."""
+        n = decoder_block_bytes(js8)
+        if block is None:
+            block = np.empty(n, np.uint8)
+        t0 = C.c_uint64()
+        rc = self.L.cwslg_fill_decoder_block(self.h, ch, block.ctypes.data, block.nbytes, int(js8), decodedepth,
+                                             highest_decode_hz, C.byref(t0))
+        if rc == ERR_NO_FRAME:
+            return None
+        self._chk(rc)
+        return block, t0.value
 
     def fetch_audio_f32(self, ch):
         n = frame_len(self._modes[ch])

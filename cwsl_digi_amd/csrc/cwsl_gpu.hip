@@ -24,6 +24,7 @@
 #include "../../include/cwsl_gpu.h"
 #include "demod_kernels.hpp"
 #include "host_dsp.hpp"
+#include "handoff.hpp"
 #include "sync_kernels.hpp"
 
 namespace cwslg {
@@ -1092,6 +1093,75 @@ int cwslg_write_wav(cwslg_ctx *c, int ch_id, const char *path)
     const bool ok = std::fwrite(h, 1, sizeof(h), f) == sizeof(h) && std::fwrite(pcm.data(), sizeof(int16_t), n, f) == n;
     std::fclose(f);
     return ok ? CWSLG_OK : fail(c, CWSLG_ERR_ARG, "short write to %s", path);
+}
+
+// ---- downstream hand-off formats (layouts and rules in handoff.hpp) ----
+size_t cwslg_decoder_block_bytes(int js8) { return cwslg::handoff::block_layout(js8 != 0).total; }
+
+int cwslg_decoder_block_field(int js8, const char *name, size_t *offset, size_t *bytes)
+{
+    if (!name) return CWSLG_ERR_ARG;
+    const cwslg::handoff::BlockLayout L = cwslg::handoff::block_layout(js8 != 0);
+    const struct { const char *n; size_t off, len; } arrays[] = {
+        {"ipc", L.ipc, js8 ? (size_t)0 : (size_t)12}, {"ss", L.ss, 184 * cwslg::handoff::kNsMax * 4},
+        {"savg", L.savg, cwslg::handoff::kNsMax * 4}, {"sred", L.sred, 5760 * 4},
+        {"d2", L.d2, cwslg::handoff::kD2Samples * 2}, {"params", L.params, L.total - L.params},
+    };
+    for (const auto &a : arrays)
+        if (std::strcmp(a.n, name) == 0) {
+            if (js8 && std::strcmp(name, "ipc") == 0) return CWSLG_ERR_ARG;
+            if (offset) *offset = a.off;
+            if (bytes) *bytes = a.len;
+            return CWSLG_OK;
+        }
+    return cwslg::handoff::field_offset(L, name, offset, bytes) ? CWSLG_OK : CWSLG_ERR_ARG;
+}
+
+int cwslg_fill_decoder_block(cwslg_ctx *c, int ch_id, void *block, size_t block_bytes, int js8, int decodedepth,
+                             int highest_decode_hz, uint64_t *start_epoch)
+{
+    if (!c || !block) return CWSLG_ERR_ARG;
+    const cwslg::handoff::BlockLayout L = cwslg::handoff::block_layout(js8 != 0);
+    std::lock_guard<std::mutex> g(c->mu);
+    if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
+    Channel &ch = c->chans[ch_id];
+    if (block_bytes < L.total) return fail(c, CWSLG_ERR_ARG, "decoder block holds %zu bytes, layout needs %zu", block_bytes, L.total);
+    if (!ch.have_frame) return CWSLG_ERR_NO_FRAME;
+    uint8_t *blk = static_cast<uint8_t *>(block);
+    if (js8) {
+        if (ch.mode != "JS8") return fail(c, CWSLG_ERR_MODE, "js8 block asked for a %s channel", ch.mode.c_str());
+        cwslg::handoff::fill_js8_params(L, blk, decodedepth, highest_decode_hz);
+    } else if (!cwslg::handoff::fill_jt9_params(L, blk, ch.mode.c_str(), decodedepth, highest_decode_hz)) {
+        return fail(c, CWSLG_ERR_MODE, "Unknown mode : %s", ch.mode.c_str());           // DecoderPool.hpp:566-570
+    }
+    const size_t nel = ch.frame_len < cwslg::handoff::kD2Samples ? ch.frame_len : cwslg::handoff::kD2Samples;   // :576-579
+    hipSetDevice(c->device);
+    HIPCHK(c, hipMemcpyAsync(blk + L.d2, ch.d_i16, nel * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));   // :588
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drain_spans(c);
+    if (start_epoch) *start_epoch = ch.frame_t0;
+    return CWSLG_OK;
+}
+
+int cwslg_decoder_route(const char *mode, int transfer_shmem)
+{
+    if (!mode || !cwslg::find_mode(mode)) return CWSLG_ERR_MODE;
+    return cwslg::handoff::uses_shared_memory(mode, transfer_shmem != 0);
+}
+
+int cwslg_decoder_command(const char *mode, int shmem_route, int numjt9threads, int decodedepth, int highest_decode_hz,
+                          int wspr_cycles, float trperiod, const char *target, char *app, size_t app_cap, char *opts,
+                          size_t opts_cap)
+{
+    if (!mode || !target || !app || !opts) return CWSLG_ERR_ARG;
+    std::string a, o;
+    if (!cwslg::handoff::decoder_command(mode, shmem_route != 0, numjt9threads, decodedepth, highest_decode_hz, wspr_cycles,
+                                         trperiod, target, a, o))
+        return CWSLG_ERR_MODE;                                                           // "Mode ... not handled"
+    if (a.size() + 1 > app_cap || o.size() + 1 > opts_cap) return CWSLG_ERR_ARG;
+    std::memcpy(app, a.c_str(), a.size() + 1);
+    std::memcpy(opts, o.c_str(), o.size() + 1);
+    return CWSLG_OK;
 }
 
 int cwslg_fetch_audio_f32(cwslg_ctx *c, int ch_id, float *dst, size_t cap, size_t *n_valid)

@@ -160,6 +160,26 @@ int cwslg_fetch_frame(cwslg_ctx *ctx, int ch_id, int16_t *dst, size_t cap,
  * transfermethod=wavefile mode (DecoderPool.hpp:966-1046).  For the shared-memory mode pass &dec_data->d2[0]
  * to cwslg_fetch_frame instead (DecoderPool.hpp:588). */
 int cwslg_write_wav(cwslg_ctx *ctx, int ch_id, const char *path);
+/* ---- decoder hand-off formats -------------------------------------------------------------
+ * The block a stock jt9 (js8 = 0: dec_data_t, DecoderPool.hpp:58-108, "in sync with lib/jt9com.f90") or js8
+ * (js8 = 1: dec_data_js8_t, :110-171) maps as shared memory.  cwslg_fill_decoder_block() does what
+ * decodeUsingShMem() does between lock and unlock (:451-590): zero the block, set params and ipc for the channel's
+ * mode, copy min(frame, 30*60*12000) int16 samples into d2 -- here straight from HBM, no intermediate vector.
+ * Returns CWSLG_ERR_MODE for a mode that route rejects ("Unknown mode", :566-570), CWSLG_ERR_NO_FRAME before the
+ * first finalised frame.  cwslg_decoder_block_field() gives offset/size of "ipc","ss","savg","sred","d2","params"
+ * or of any params member by name (e.g. "nzhsym"). */
+size_t cwslg_decoder_block_bytes(int js8);
+int cwslg_decoder_block_field(int js8, const char *name, size_t *offset, size_t *bytes);
+int cwslg_fill_decoder_block(cwslg_ctx *ctx, int ch_id, void *block, size_t block_bytes, int js8, int decodedepth,
+                             int highest_decode_hz, uint64_t *start_epoch);
+/* 1 = shared memory, 0 = wave file: the route DecoderPool gives an item of this mode (:379-395; WSPR, JS8 and the
+ * FST4 family always go through a file). */
+int cwslg_decoder_route(const char *mode, int transfer_shmem);
+/* Program name ("jt9.exe" / "wsprd.exe" / "js8.exe") and argument string, character for character as
+ * DecoderPool.hpp:634-659 (shared memory; target = key) and :1007-1046 (wave file; target = file name) build them. */
+int cwslg_decoder_command(const char *mode, int shmem_route, int numjt9threads, int decodedepth, int highest_decode_hz,
+                          int wspr_cycles, float trperiod, const char *target, char *app, size_t app_cap, char *opts,
+                          size_t opts_cap);
 /* The same frame as 12 kHz float audio BEFORE prepareAudio's scaling (for the 1e-5 check). */
 int cwslg_fetch_audio_f32(cwslg_ctx *ctx, int ch_id, float *dst, size_t cap, size_t *n_valid);
 /* Device pointers of the last finalised frame (valid until the next boundary of that channel). */

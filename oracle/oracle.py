@@ -86,6 +86,15 @@ def lib():
         L.orc_bench_cpu.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint64]
         L.orc_bench_cpu.restype = C.c_double
         L.orc_crc32.argtypes = [C.c_void_p, C.c_size_t]; L.orc_crc32.restype = C.c_uint32
+        L.orc_jt9_block_bytes.restype = C.c_size_t
+        L.orc_js8_block_bytes.restype = C.c_size_t
+        L.orc_jt9_offset.argtypes = [C.c_char_p]; L.orc_jt9_offset.restype = C.c_long
+        L.orc_js8_offset.argtypes = [C.c_char_p]; L.orc_js8_offset.restype = C.c_long
+        L.orc_jt9_fill.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, _i16p, C.c_size_t]
+        L.orc_js8_fill.argtypes = [C.c_void_p, C.c_int, C.c_int, _i16p, C.c_size_t]
+        L.orc_decoder_route.argtypes = [C.c_char_p, C.c_int]
+        L.orc_decoder_command.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_char_p,
+                                          C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -329,6 +338,39 @@ def checksum(x):
 def crc32(a):
     a = np.ascontiguousarray(a)
     return int(lib().orc_crc32(a.ctypes.data, a.nbytes))
+
+
+# ---- decoder hand-off formats (handoff_oracle.c; DecoderPool.hpp:58-171, 379-395, 451-590, 634-659, 1007-1046) ----
+def decoder_block_bytes(js8=False):
+    return int(lib().orc_js8_block_bytes() if js8 else lib().orc_jt9_block_bytes())
+
+
+def decoder_block_offset(name, js8=False):
+    """Byte offset of a member of the jt9/js8 shared-memory block, or -1."""
+    return int((lib().orc_js8_offset if js8 else lib().orc_jt9_offset)(name.encode()))
+
+
+def decoder_block(mode, audio_i16, decodedepth=3, highest_hz=3000, js8=False):
+    """The filled shared-memory block as uint8[...]; None for a mode the jt9 route rejects."""
+    audio = np.ascontiguousarray(audio_i16, dtype=np.int16)
+    blk = np.empty(decoder_block_bytes(js8), np.uint8)
+    if js8:
+        rc = lib().orc_js8_fill(blk.ctypes.data, decodedepth, highest_hz, audio, audio.shape[0])
+    else:
+        rc = lib().orc_jt9_fill(blk.ctypes.data, mode.encode(), decodedepth, highest_hz, audio, audio.shape[0])
+    return blk if rc == 0 else None
+
+
+def decoder_route(mode, transfer_shmem=True):
+    return "shmem" if lib().orc_decoder_route(mode.encode(), int(transfer_shmem)) else "wavefile"
+
+
+def decoder_command(mode, target, shmem_route, numjt9threads=3, decodedepth=3, highest_decode_hz=3000, wspr_cycles=3000,
+                    trperiod=0.0):
+    app, opts = C.create_string_buffer(64), C.create_string_buffer(1024)
+    rc = lib().orc_decoder_command(mode.encode(), int(shmem_route), numjt9threads, decodedepth, highest_decode_hz,
+                                   wspr_cycles, float(trperiod), str(target).encode(), app, 64, opts, 1024)
+    return (app.value.decode(), opts.value.decode()) if rc == 0 else None
 
 
 def bench_cpu(threads, slots, fs=192000, iq_len=2048, n_per_slot=2880000):
