@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Full-size runs of BASELINE.json configs[2] ("1024 mixed FT8/FT4 slots") and configs[4] ("WSPR + FST4W-120, 2 min
+frames, 256 slots") on one MI355X.  Not the bench line (bench.py is) -- these are the parity-at-full-size cases:
+a few slots are checked against the oracle on exactly the input the last step consumed, and the FT8/FT4 candidate
+lists of those slots must be identical to the oracle's.  One JSON line per run.
+
+    python scripts/run_configs.py --config 3 [--steps 3]
+    python scripts/run_configs.py --config 5 [--steps 2]
+"""
+import argparse, json, os, sys, time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+FS, IQ_LEN = 192000, 2048
+
+
+def slot_freq(gs):
+    return -90000 + (gs * 4373) % 176000
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, required=True, choices=(3, 5))
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--verify", type=int, default=2, help="slots of each mode checked against the oracle")
+    ap.add_argument("--scale", type=float, default=1.0, help="fraction of the config's slot count (testing)")
+    args = ap.parse_args()
+    import torch  # noqa: F401  (its HIP runtime first)
+    import numpy as np
+    import cwsl_digi_amd as P
+    from oracle import oracle as O
+
+    if args.config == 3:
+        plan = [("FT8", int(768 * args.scale)), ("FT4", int(256 * args.scale))]
+        window = 2880000                    # 15 s: one FT8 slot, two FT4 slots
+        sub = 2                             # commits per step (FT4 boundary after each)
+    else:
+        plan = [("WSPR", int(128 * args.scale)), ("FST4W-120", int(128 * args.scale))]
+        window = 23040000                   # 120 s
+        sub = 1
+    part = window // sub
+    ring_blocks = window // IQ_LEN + 2 + (window % IQ_LEN != 0)
+    cap = ring_blocks * IQ_LEN
+    ctx = P.Context(0)
+    ctx.enable_sync(True, 1.5, 200, 200, 3000)
+    chans = []
+    t0 = time.time()
+    gs = 0
+    for mode, count in plan:
+        for _ in range(count):
+            f = slot_freq(gs)
+            tones = [f + 700.0 + 31.0 * (gs % 13), f + 1500.0, f + 2300.0 - 17.0 * (gs % 5)]
+            rx = ctx.receiver_open(FS, IQ_LEN, 0, ring_blocks=ring_blocks)
+            done = 0
+            while done < cap:               # fill the ring in pieces (push_synth's count is 32 bit)
+                n = min(cap - done, 4096 * IQ_LEN, (ring_blocks // 2) * IQ_LEN)
+                ctx.push_synth(rx, 0xBEEF00 ^ gs, n, IQ_LEN, tones_hz=tones, amp=2.0e4)
+                done += n
+            ch = ctx.channel_open(rx, f, mode)
+            chans.append((mode, rx, ch, f, tones, 0xBEEF00 ^ gs))
+            gs += 1
+    groups = sorted({P.group_of(m) for m, _ in plan})
+    for g in groups:
+        ctx.slot_boundary(g, 1)
+    ctx.synchronize()
+    setup_s = time.time() - t0
+
+    def step(k):
+        for j in range(sub):
+            ctx.ring_commit_all(part, IQ_LEN)
+            ctx.process()
+            if args.config == 3:
+                ctx.slot_boundary("FT4", 100 + 15 * k + 7 * j)
+                if j == sub - 1:
+                    ctx.slot_boundary("FT8", 100 + 15 * k)
+            else:
+                ctx.slot_boundary("S120", 1000 + 120 * k)
+
+    for k in range(args.warmup):
+        step(k)
+    ctx.synchronize()
+    ctx.reset_stats(); ctx.set_timing(True)
+    t1 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    ctx.synchronize()
+    dt = time.perf_counter() - t1
+    ctx.set_timing(False)
+    st = ctx.stats()
+    n_slots = len(chans)
+    msps = n_slots * window * args.steps / dt / 1e6
+
+    # ---- verification on the input the LAST (sub)step consumed
+    laps = (args.warmup + args.steps) * sub          # commits of `part` samples since the ring was filled
+    worst, mism, cand_checked, cand_equal = 0.0, 0, 0, 0
+    seen = {}
+    for mode, rx, ch, f, tones, seed in chans:
+        if seen.get(mode, 0) >= args.verify:
+            continue
+        seen[mode] = seen.get(mode, 0) + 1
+        ring = O.synth_iq(seed, cap, FS, tones_hz=tones, amp=2.0e4)
+        nslot = part if mode == "FT4" else window     # the samples of this mode's last complete slot
+        start = (laps * part - nslot) % cap
+        iq = ring[(start + np.arange(nslot)) % cap]
+        oc = O.Channel(mode, FS, IQ_LEN, f)
+        oc.boundary(1); oc.boundary(2)
+        oc.push_stream(iq)
+        ref = oc.boundary(3, want_f32=True)
+        a, nv = ctx.fetch_audio_f32(ch)
+        g = ctx.fetch_frame(ch)
+        peak = float(np.abs(ref["f32"]).max())
+        worst = max(worst, float(np.abs(a.astype(np.float64) - ref["f32"]).max()) / peak)
+        mism += int((g["i16"] != ref["i16"]).sum())
+        if mode in ("FT8", "FT4"):
+            got = ctx.fetch_candidates(ch)
+            if mode == "FT8":
+                want = O.ft8_sync(g["i16"], 200, 3000, 1.5, 200)
+            else:
+                want = O.ft4_candidates(g["i16"], 200.0, 3000.0, 1.2, 200)
+            cand_checked += 1
+            cand_equal += int(list(got) == list(want) and len(want) > 0)
+    out = {
+        "config": args.config, "workload": ", ".join(f"{c} {m}" for m, c in plan) + f" slots, {window} IQ samples per step each, private streams, one MI355X",
+        "value": msps, "unit": "Msamples/s", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps,
+        "realtime_factor": (window / FS) / (dt / args.steps),
+        "demod_ms_per_launch": st["demod_ms"] / max(1, st["demod_launches"]), "demod_launches": st["demod_launches"],
+        "demod_gbs": 8.25 * n_slots * part / (st["demod_ms"] / max(1, st["demod_launches"]) * 1e-3) / 1e9,
+        "finalize_ms": st["finalize_ms"] / max(1, st["finalize_launches"]),
+        "sync_ms_per_boundary": st["sync_ms"] / max(1, st["sync_launches"]), "sync_launches": st["sync_launches"],
+        "verify": {"slots_checked": sum(seen.values()), "max_rel_err": worst, "tolerance": 1e-5, "int16_mismatches_1lsb_ties": mism,
+                   "candidate_lists_checked": cand_checked, "candidate_lists_identical": cand_equal},
+        "hbm_resident_gb": n_slots * cap * 8 / 1e9, "setup_s": setup_s,
+    }
+    print(json.dumps(out))
+    ok = worst <= 1e-5 and cand_equal == cand_checked
+    ctx.close()
+    sys.exit(0 if ok else 2)
+
+
+if __name__ == "__main__":
+    main()
