@@ -42,13 +42,15 @@ struct SyncConfig {
     int ia = 64, ib = 960, nbins = 976;   // derived: bin range and stored row length (ib+13 rounded up to 16)
 };
 
-struct SyncTables {                       // device pointers: W_NA, W_NZ, W_128, W_2NZ twiddles, optional window
-    const float2 *w15, *w1920, *w128, *w3840;
+struct SyncTables {                       // device pointers: W_NZ, W_128, W_2NZ twiddles, optional window
+    const float2 *w1920, *w128, *w3840;
     const float *win;
+    float war[8], wai[8];                 // W_NA^k for k <= NA/2, by value (kernel argument -> scalar registers);
+                                          // the other half is its bitwise conjugate (spec v2, oracle/sync_oracle.c)
 };
 
 struct SyncShared {
-    float2 *d_tables = nullptr;           // FT8: w15[15] | w1920[1920] | w128[64] | w3840[1921] ; FT4: w9[9] | w1152[1152] | w2304[1153]
+    float2 *d_tables = nullptr;           // FT8: w1920[1920] | w128[64] | w3840[1921] ; FT4: w1152[1152] | w2304[1153]
     float *d_win = nullptr;               // Nuttall window, 2304 floats
     SyncTables t{};                       // FT8 set
     SyncTables t4{};                      // FT4 set (w15 -> W_9, w1920 -> W_1152, w3840 -> W_2304)
@@ -91,62 +93,94 @@ __device__ __forceinline__ float2 cmul_u(float2 a, float2 b)          // un-fuse
     const float ac = a.x * b.x, bd = a.y * b.y, ad = a.x * b.y, bc = a.y * b.x;
     return make_float2(ac - bd, ad + bc);
 }
+// the transform's complex product (spec v2): one rounding fewer per component, same bits as the oracle's CMUL
+__device__ __forceinline__ float2 cmul_f(float2 v, float2 w)
+{
+    return make_float2(__builtin_fmaf(v.x, w.x, -(v.y * w.y)), __builtin_fmaf(v.x, w.y, v.y * w.x));
+}
 
 // ---------------------------------------------------------------------------------------------
 // Symbol spectra.  grid (NHSYM, n_channels), 256 threads.
 //
-// The transform is DEFINED as: pack z[m] = x[2m] + i x[2m+1] (m < 960, zero above), 1920 = 15 x 128:
-// 15-point DFTs over a (m = 128a + b) -> twiddle W1920^(bc) -> 15 radix-2 DIT FFTs of 128 points (bit-reversed
-// input) -> real-input unpack with W3840^k.  Any schedule that evaluates the same butterflies gives the same
-// bits; here each lane does 8-point groups (three radix-2 stages) in registers per LDS pass.
-// LDS image of the 15 x 128 work array: row pitch 129 (rows start 2 banks apart) and, after pass A, logical
+// The transform is DEFINED (oracle/sync_oracle.c, "spec v2") as: pack z[m] = x[2m] + i x[2m+1] (m < NPACK, zero
+// above), NZ = NA x 128: NA-point DFTs over a (m = 128a + b) evaluated in conjugate pairs with fmaf chains ->
+// twiddle W_NZ^(bc) -> NA radix-2 DIT FFTs of 128 points (bit-reversed input) -> real-input unpack with W_2NZ^k.
+// Any schedule that evaluates the same operations gives the same bits; here each lane does 8-point groups (three
+// radix-2 stages) in registers per LDS pass, and products by the exact table entries W^0 = (1,0) and
+// W128^32 = (0,-1) are not multiplied out (identical up to the sign of zeros, which |X|^2 cannot see).
+// LDS image of the NA x 128 work array: row pitch 129 (rows start 2 banks apart) and, after pass A, logical
 // column i stored at i ^ ((i >> 3) & 7) -- together they keep every pass at <= 2-way bank conflicts
 // (the plain [15][128] image ran the LDS at 94 % busy, two thirds of it conflict cycles).
 constexpr int SY_PITCH = 129;
 __device__ __forceinline__ int sy_col(int i) { return i ^ ((i >> 3) & 7); }
 
-// NA = 15 (FT8: 1920 = 15 x 128, only the first NPACK = 960 packed inputs are non-zero) or 9 (FT4: 1152 = 9 x 128)
-template <int CH, int NA, int NPACK>
-__device__ __forceinline__ void spectra_stage1(const float *s_x, float2 (*s_y)[SY_PITCH], const float2 *s_wa,
+// NA = 15 (FT8: 1920 = 15 x 128, only the first NPACK = 960 packed inputs are non-zero) or 9 (FT4: 1152 = 9 x 128).
+// HALF 0 (waves 0-1): output 0 and the pairs c = 1..SPLIT;  HALF 1 (waves 2-3): the pairs c = SPLIT+1..NA/2.
+template <int HALF, int NA, int NPACK>
+__device__ __forceinline__ void spectra_stage1(const float *s_x, float2 (*s_y)[SY_PITCH], const SyncTables &tb,
                                                const float2 *__restrict__ wn, int b)
 {
     constexpr int AMAX = (NPACK + 127) / 128;            // 8 (FT8), 9 (FT4)
-    constexpr int NC = (NA - CH + 1) / 2;                // outputs c = CH, CH+2, ... handled by this half
+    constexpr int NPAIR = NA / 2, SPLIT = NPAIR / 2;
+    constexpr int C0 = HALF ? SPLIT + 1 : 1, C1 = HALF ? NPAIR : SPLIT;
     float2 z[AMAX];
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) {
-        const int m = 128 * a + b;
+        const int m = 128 * a + b;                       // a zero input adds exactly nothing to an fmaf chain
         z[a] = (m < NPACK) ? make_float2(s_x[2 * m], s_x[2 * m + 1]) : make_float2(0.f, 0.f);
     }
-    const bool last_ok = (128 * (AMAX - 1) + b) < NPACK;
-    float2 tw[NC];
+    float2 tw[2 * (C1 - C0 + 1)];
 #pragma unroll
-    for (int i = 0; i < NC; ++i) tw[i] = wn[b * (CH + 2 * i)];
+    for (int c = C0; c <= C1; ++c) {
+        tw[2 * (c - C0)] = wn[b * c];
+        tw[2 * (c - C0) + 1] = wn[b * (NA - c)];
+    }
+    if (HALF == 0) {
+        float2 s0 = z[0];
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
-        const int c = CH + 2 * i;
-        float2 acc = z[0];
+        for (int a = 1; a < AMAX; ++a) { s0.x = s0.x + z[a].x; s0.y = s0.y + z[a].y; }
+        s_y[0][b] = s0;                                  // W_NZ^0 = 1: no multiply
+    }
 #pragma unroll
-        for (int a = 1; a < AMAX - 1; ++a) {
-            const float2 p = cmul_u(z[a], s_wa[(a * c) % NA]);
-            acc.x = acc.x + p.x;
-            acc.y = acc.y + p.y;
+    for (int c = C0; c <= C1; ++c) {
+        float P = 0.f, Q = 0.f, R = 0.f, S = 0.f;
+#pragma unroll
+        for (int a = 1; a < AMAX; ++a) {
+            const int idx = (a * c) % NA;
+            const float wr = (idx <= NA / 2) ? tb.war[idx] : tb.war[NA - idx];
+            const float wi = (idx <= NA / 2) ? tb.wai[idx] : -tb.wai[NA - idx];
+            P = __builtin_fmaf(z[a].x, wr, P);
+            Q = __builtin_fmaf(z[a].y, wi, Q);
+            R = __builtin_fmaf(z[a].x, wi, R);
+            S = __builtin_fmaf(z[a].y, wr, S);
         }
-        if (last_ok) {
-            const float2 p = cmul_u(z[AMAX - 1], s_wa[((AMAX - 1) * c) % NA]);
-            acc.x = acc.x + p.x;
-            acc.y = acc.y + p.y;
-        }
-        s_y[c][b] = cmul_u(acc, tw[i]);        // natural order; pass A gathers the bit-reversed inputs
+        const float2 yc = make_float2(z[0].x + (P - Q), z[0].y + (R + S));
+        const float2 yn = make_float2(z[0].x + (P + Q), z[0].y + (S - R));
+        s_y[c][b] = cmul_f(yc, tw[2 * (c - C0)]);        // natural order; pass A gathers the bit-reversed inputs
+        s_y[NA - c][b] = cmul_f(yn, tw[2 * (c - C0) + 1]);
     }
 }
 
-// radix-2 DIT butterfly on two registers: (u, v) -> (u + w v, u - w v), un-fused
+// radix-2 DIT butterfly on two registers: (u, v) -> (u + w v, u - w v)
 __device__ __forceinline__ void bfly(float2 &u, float2 &v, float2 w)
 {
-    const float2 t = cmul_u(v, w);
+    const float2 t = cmul_f(v, w);
     const float2 a = make_float2(u.x + t.x, u.y + t.y);
     const float2 d = make_float2(u.x - t.x, u.y - t.y);
+    u = a;
+    v = d;
+}
+__device__ __forceinline__ void bfly_one(float2 &u, float2 &v)        // w = W^0 = (1, 0)
+{
+    const float2 a = make_float2(u.x + v.x, u.y + v.y);
+    const float2 d = make_float2(u.x - v.x, u.y - v.y);
+    u = a;
+    v = d;
+}
+__device__ __forceinline__ void bfly_mj(float2 &u, float2 &v)         // w = W128^32 = (0, -1): w v = (v.y, -v.x)
+{
+    const float2 a = make_float2(u.x + v.y, u.y - v.x);
+    const float2 d = make_float2(u.x - v.y, u.y + v.x);
     u = a;
     v = d;
 }
@@ -161,7 +195,6 @@ __global__ __launch_bounds__(256) void symbol_spectra_kernel(const SyncWork *__r
     static_assert(NGRP <= 256 && NIN % 8 == 0, "geometry");
     __shared__ float s_x[NIN];
     __shared__ float2 s_y[NA][SY_PITCH];
-    __shared__ float2 s_wa[16];
     __shared__ float2 s_w128[64];
     const SyncWork *w = works + blockIdx.y;
     const int j = blockIdx.x;
@@ -180,13 +213,12 @@ __global__ __launch_bounds__(256) void symbol_spectra_kernel(const SyncWork *__r
             s_x[8 * t + 2 * k + 1] = hi;
         }
     }
-    if (tid < NA) s_wa[tid] = tb.w15[tid];
     if (tid >= 64 && tid < 128) s_w128[tid - 64] = tb.w128[tid - 64];
     __syncthreads();
 
-    // stage 1 (wave-uniform split of the NA outputs c: even c on waves 0-1, odd c on waves 2-3)
-    if (tid < 128) spectra_stage1<0, NA, NPACK>(s_x, s_y, s_wa, tb.w1920, tid & 127);
-    else spectra_stage1<1, NA, NPACK>(s_x, s_y, s_wa, tb.w1920, tid & 127);
+    // stage 1 (wave-uniform split of the conjugate pairs of outputs between waves 0-1 and waves 2-3)
+    if (tid < 128) spectra_stage1<0, NA, NPACK>(s_x, s_y, tb, tb.w1920, tid & 127);
+    else spectra_stage1<1, NA, NPACK>(s_x, s_y, tb, tb.w1920, tid & 127);
     __syncthreads();
 
     // stage 2, pass A: DIT stages len = 2,4,8 on logical points 8g..8g+7 of row c; the DIT input order is
@@ -204,9 +236,9 @@ __global__ __launch_bounds__(256) void symbol_spectra_kernel(const SyncWork *__r
         }
         __syncthreads();                     // everyone has gathered: the image may now be rewritten
         if (tid < NGRP) {
-            bfly(e[0], e[1], s_w128[0]); bfly(e[2], e[3], s_w128[0]); bfly(e[4], e[5], s_w128[0]); bfly(e[6], e[7], s_w128[0]);
-            bfly(e[0], e[2], s_w128[0]); bfly(e[1], e[3], s_w128[32]); bfly(e[4], e[6], s_w128[0]); bfly(e[5], e[7], s_w128[32]);
-            bfly(e[0], e[4], s_w128[0]); bfly(e[1], e[5], s_w128[16]); bfly(e[2], e[6], s_w128[32]); bfly(e[3], e[7], s_w128[48]);
+            bfly_one(e[0], e[1]); bfly_one(e[2], e[3]); bfly_one(e[4], e[5]); bfly_one(e[6], e[7]);
+            bfly_one(e[0], e[2]); bfly_mj(e[1], e[3]); bfly_one(e[4], e[6]); bfly_mj(e[5], e[7]);
+            bfly_one(e[0], e[4]); bfly(e[1], e[5], s_w128[16]); bfly_mj(e[2], e[6]); bfly(e[3], e[7], s_w128[48]);
 #pragma unroll
             for (int k = 0; k < 8; ++k) s_y[c][sy_col(8 * g + k)] = e[k];
         }
@@ -256,9 +288,9 @@ __global__ __launch_bounds__(256) void symbol_spectra_kernel(const SyncWork *__r
             B.y = -B.y;
             const float er = (A.x + B.x) * 0.5f, ei = (A.y + B.y) * 0.5f;
             const float2 o = make_float2((A.x - B.x) * 0.5f, (A.y - B.y) * 0.5f);
-            const float2 t = cmul_u(o, tb.w3840[k]);
+            const float2 t = cmul_f(o, tb.w3840[k]);
             const float xr = er + t.y, xi = ei - t.x;
-            pw = xr * xr + xi * xi;
+            pw = __builtin_fmaf(xr, xr, xi * xi);
         }
         out[k] = pw;
     }

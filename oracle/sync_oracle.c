@@ -5,89 +5,119 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define NZ   1920              /* complex FFT length after real packing */
-#define NA   15
-#define NB   128
+#define NB   128               /* radix-2 part of both transforms */
 
-static float w15r[NA], w15i[NA];           /* exp(-2 pi i k/15)   */
-static float w1920r[NZ], w1920i[NZ];       /* exp(-2 pi i k/1920) */
+/*
+ * Transform of record ("spec v2"), shared by FT8 (2*NZ = 3840, NA = 15) and FT4 (2*NZ = 2304, NA = 9):
+ *   pack     z[m] = x[2m] + i x[2m+1]  (m < NZ; FT8: zero for m >= 960), m = 128 a + b
+ *   stage 1  for each column b an NA-point DFT over a, evaluated in conjugate pairs (c, NA-c):
+ *              P = sum_a zr_a wr, Q = sum_a zi_a wi, R = sum_a zr_a wi, S = sum_a zi_a wr   (a = 1.., fmaf chains from 0)
+ *              y_c = (z0r + (P - Q), z0i + (R + S)),  y_{NA-c} = (z0r + (P + Q), z0i + (S - R)),  w = WA[(a c) mod NA]
+ *              y_0 = z_0 + z_1 + ... (sequential)
+ *            then y_c *= WN[b c] for c >= 1 (cmul below)
+ *   stage 2  NA radix-2 DIT FFTs of 128 points (input bit-reversed): t = v*w, (u, v) <- (u + t, u - t)
+ *   stage 3  real-input unpack with W2N[k], pw = fmaf(xr, xr, xi*xi)
+ *   cmul     (vr + i vi)(wr + i wi) = ( fmaf(vr, wr, -(vi*wi)),  fmaf(vr, wi, vi*wr) )
+ * Twiddle tables: float(cos), float(-sin) of the double angle, EXCEPT that the cardinal points are exact
+ * (W^0 = (1, 0), W128^32 = (0, -1)) and WA is conjugate-symmetric bit for bit (WA[NA-k] = conj(WA[k])).
+ * fmaf is the correctly-rounded fused multiply-add (C99); everything else is plain float + - *.
+ */
+typedef struct {
+    int na, nz, npack;
+    float war[16], wai[16];
+    float *wnr, *wni;          /* exp(-2 pi i k/NZ),  k < NZ   */
+    float *w2r, *w2i;          /* exp(-2 pi i k/2NZ), k <= NZ  */
+} fft_plan;
+
 static float w128r[NB / 2], w128i[NB / 2]; /* exp(-2 pi i k/128)  */
-static float w3840r[NZ + 1], w3840i[NZ + 1]; /* exp(-2 pi i k/3840), k = 0..1920 */
 static unsigned char rev7[NB];
+static fft_plan plan8, plan4;
 static int tables_ready = 0;
+
+static void make_plan(fft_plan *P, int na, int npack)
+{
+    const double pi = 3.14159265358979323846;
+    P->na = na; P->nz = na * NB; P->npack = npack;
+    for (int k = 0; k <= na / 2; ++k) { P->war[k] = (float)cos(2.0 * pi * k / na); P->wai[k] = (float)(-sin(2.0 * pi * k / na)); }
+    P->war[0] = 1.0f; P->wai[0] = 0.0f;
+    for (int k = na / 2 + 1; k < na; ++k) { P->war[k] = P->war[na - k]; P->wai[k] = -P->wai[na - k]; }
+    P->wnr = (float *)malloc(sizeof(float) * P->nz); P->wni = (float *)malloc(sizeof(float) * P->nz);
+    P->w2r = (float *)malloc(sizeof(float) * (P->nz + 1)); P->w2i = (float *)malloc(sizeof(float) * (P->nz + 1));
+    for (int k = 0; k < P->nz; ++k) { P->wnr[k] = (float)cos(2.0 * pi * k / P->nz); P->wni[k] = (float)(-sin(2.0 * pi * k / P->nz)); }
+    for (int k = 0; k <= P->nz; ++k) { P->w2r[k] = (float)cos(pi * k / P->nz); P->w2i[k] = (float)(-sin(pi * k / P->nz)); }
+    P->wnr[0] = 1.0f; P->wni[0] = 0.0f; P->w2r[0] = 1.0f; P->w2i[0] = 0.0f;
+}
 
 static void make_tables(void)
 {
     const double pi = 3.14159265358979323846;
-    for (int k = 0; k < NA; ++k) { w15r[k] = (float)cos(2.0 * pi * k / 15.0); w15i[k] = (float)(-sin(2.0 * pi * k / 15.0)); }
-    for (int k = 0; k < NZ; ++k) { w1920r[k] = (float)cos(2.0 * pi * k / 1920.0); w1920i[k] = (float)(-sin(2.0 * pi * k / 1920.0)); }
     for (int k = 0; k < NB / 2; ++k) { w128r[k] = (float)cos(2.0 * pi * k / 128.0); w128i[k] = (float)(-sin(2.0 * pi * k / 128.0)); }
-    for (int k = 0; k <= NZ; ++k) { w3840r[k] = (float)cos(2.0 * pi * k / 3840.0); w3840i[k] = (float)(-sin(2.0 * pi * k / 3840.0)); }
+    w128r[0] = 1.0f; w128i[0] = 0.0f; w128r[32] = 0.0f; w128i[32] = -1.0f;
     for (int b = 0; b < NB; ++b) {
         int r = 0;
         for (int t = 0; t < 7; ++t) if (b & (1 << t)) r |= 1 << (6 - t);
         rev7[b] = (unsigned char)r;
     }
+    make_plan(&plan8, 15, 960);
+    make_plan(&plan4, 9, 1152);
     tables_ready = 1;
 }
 
-/* One symbol spectrum: x[0..1920) real, zero padded to 3840; pw[k] = |X[k]|^2 for k in [0,nbins). */
-static void spectrum_3840(const float *x, float *pw, int nbins)
+#define CMUL(vr, vi, wr, wi, tr, ti) do { (tr) = fmaf((vr), (wr), -((vi) * (wi))); (ti) = fmaf((vr), (wi), (vi) * (wr)); } while (0)
+
+/* x[0 .. 2*npack) real (implicitly zero padded to 2*NZ); pw[k] = |X[k]|^2 for k in [0, nbins), nbins <= NZ + 1 */
+static void spectrum_packed(const fft_plan *P, const float *x, float *pw, int nbins)
 {
-    static float yr[NA][NB], yi[NA][NB];
-    /* pack: z[m] = x[2m] + i x[2m+1], m < 960 (zero above); m = 128 a + b */
-    /* stage 1: 15-point DFT over a (only a <= 7 can be non-zero), then twiddle W1920^(b*c), stored bit-reversed in b */
+    static float yr[16][NB], yi[16][NB];
+    const int na = P->na, nz = P->nz;
     for (int b = 0; b < NB; ++b) {
-        for (int c = 0; c < NA; ++c) {
-            float ar = x[2 * b], ai = x[2 * b + 1];                    /* a = 0 term, W^0 */
-            for (int a = 1; a < 8; ++a) {
-                const int m = NB * a + b;
-                if (m >= 960) break;
-                const float zr = x[2 * m], zi = x[2 * m + 1];
-                const float wr = w15r[(a * c) % NA], wi = w15i[(a * c) % NA];
-                const float pr = zr * wr - zi * wi;
-                const float pi_ = zr * wi + zi * wr;
-                ar = ar + pr;
-                ai = ai + pi_;
+        int amax = 0;
+        while (amax < na && NB * amax + b < P->npack) ++amax;              /* inputs a < amax are live */
+        const float z0r = x[2 * b], z0i = x[2 * b + 1];
+        float s0r = z0r, s0i = z0i;
+        for (int a = 1; a < amax; ++a) { s0r = s0r + x[2 * (NB * a + b)]; s0i = s0i + x[2 * (NB * a + b) + 1]; }
+        yr[0][rev7[b]] = s0r; yi[0][rev7[b]] = s0i;                         /* c = 0: WN^0 = 1, no multiply */
+        for (int c = 1; c <= na / 2; ++c) {
+            float Ps = 0.0f, Qs = 0.0f, Rs = 0.0f, Ss = 0.0f;
+            for (int a = 1; a < amax; ++a) {
+                const float zr = x[2 * (NB * a + b)], zi = x[2 * (NB * a + b) + 1];
+                const float wr = P->war[(a * c) % na], wi = P->wai[(a * c) % na];
+                Ps = fmaf(zr, wr, Ps); Qs = fmaf(zi, wi, Qs); Rs = fmaf(zr, wi, Rs); Ss = fmaf(zi, wr, Ss);
             }
-            const float tr = w1920r[b * c], ti = w1920i[b * c];
-            const float qr = ar * tr - ai * ti;
-            const float qi = ar * ti + ai * tr;
-            yr[c][rev7[b]] = qr;
-            yi[c][rev7[b]] = qi;
+            const float ar = z0r + (Ps - Qs), ai = z0i + (Rs + Ss);         /* output c      */
+            const float br = z0r + (Ps + Qs), bi = z0i + (Ss - Rs);         /* output na - c */
+            float qr, qi;
+            CMUL(ar, ai, P->wnr[b * c], P->wni[b * c], qr, qi);
+            yr[c][rev7[b]] = qr; yi[c][rev7[b]] = qi;
+            CMUL(br, bi, P->wnr[b * (na - c)], P->wni[b * (na - c)], qr, qi);
+            yr[na - c][rev7[b]] = qr; yi[na - c][rev7[b]] = qi;
         }
     }
-    /* stage 2: 15 radix-2 DIT FFTs of 128 points (input bit-reversed, output natural): Z[c + 15 d] = y[c][d] */
-    for (int c = 0; c < NA; ++c) {
+    for (int c = 0; c < na; ++c) {
         for (int len = 2; len <= NB; len <<= 1) {
             const int half = len >> 1, step = NB / len;
             for (int base = 0; base < NB; base += len) {
                 for (int k = 0; k < half; ++k) {
-                    const float wr = w128r[k * step], wi = w128i[k * step];
                     const float ur = yr[c][base + k], ui = yi[c][base + k];
-                    const float vr = yr[c][base + k + half], vi = yi[c][base + k + half];
-                    const float tr = vr * wr - vi * wi;
-                    const float ti = vr * wi + vi * wr;
+                    float tr, ti;
+                    CMUL(yr[c][base + k + half], yi[c][base + k + half], w128r[k * step], w128i[k * step], tr, ti);
                     yr[c][base + k] = ur + tr;        yi[c][base + k] = ui + ti;
                     yr[c][base + k + half] = ur - tr; yi[c][base + k + half] = ui - ti;
                 }
             }
         }
     }
-    /* stage 3: unpack the real-input transform: X[k], k = 0..1920 */
-    for (int k = 0; k < nbins; ++k) {
-        const int k2 = (NZ - k) % NZ;
-        const int kk = k % NZ;
-        const float ar = yr[kk % NA][kk / NA], ai = yi[kk % NA][kk / NA];
-        const float br = yr[k2 % NA][k2 / NA], bi = -yi[k2 % NA][k2 / NA];   /* conj(Z[N-k]) */
+    for (int k = 0; k < nbins; ++k) {                                      /* Z[c + na d] = y[c][d] */
+        const int k2 = (nz - k) % nz, kk = k % nz;
+        const float ar = yr[kk % na][kk / na], ai = yi[kk % na][kk / na];
+        const float br = yr[k2 % na][k2 / na], bi = -yi[k2 % na][k2 / na];  /* conj(Z[N-k]) */
         const float er = (ar + br) * 0.5f, ei = (ai + bi) * 0.5f;
         const float orr = (ar - br) * 0.5f, oi = (ai - bi) * 0.5f;
-        const float wr = w3840r[k], wi = w3840i[k];
-        const float tr = orr * wr - oi * wi;
-        const float ti = orr * wi + oi * wr;
+        float tr, ti;
+        CMUL(orr, oi, P->w2r[k], P->w2i[k], tr, ti);
         const float xr = er + ti;            /* E + (-i) T */
         const float xi = ei - tr;
-        pw[k] = xr * xr + xi * xi;
+        pw[k] = fmaf(xr, xr, xi * xi);
     }
 }
 
@@ -100,7 +130,7 @@ int orc_ft8_spectra(const int16_t *frame, float *s_out, int nbins)
     for (int j = 0; j < FT8_NHSYM; ++j) {
         const int16_t *d = frame + (size_t)FT8_NSTEP * j;
         for (int n = 0; n < FT8_NSPS; ++n) x[n] = fac * (float)d[n];
-        spectrum_3840(x, s_out + (size_t)j * nbins, nbins);
+        spectrum_packed(&plan8, x, s_out + (size_t)j * nbins, nbins);
     }
     return 0;
 }
@@ -259,9 +289,6 @@ int orc_ft8_sync(const int16_t *frame, int nfa_hz, int nfb_hz, float syncmin, in
 #define F4_NHSYM  122
 #define F4_NA     9
 
-static float f4_w9r[F4_NA], f4_w9i[F4_NA];
-static float f4_wNr[F4_NH1], f4_wNi[F4_NH1];          /* exp(-2 pi i k/1152) */
-static float f4_w2Nr[F4_NH1 + 1], f4_w2Ni[F4_NH1 + 1]; /* exp(-2 pi i k/2304), k = 0..1152 */
 static float f4_win[F4_NFFT];
 static int f4_ready = 0;
 
@@ -269,64 +296,10 @@ static void f4_tables(void)
 {
     const double pi = 3.14159265358979323846;
     if (!tables_ready) make_tables();
-    for (int k = 0; k < F4_NA; ++k) { f4_w9r[k] = (float)cos(2.0 * pi * k / 9.0); f4_w9i[k] = (float)(-sin(2.0 * pi * k / 9.0)); }
-    for (int k = 0; k < F4_NH1; ++k) { f4_wNr[k] = (float)cos(2.0 * pi * k / 1152.0); f4_wNi[k] = (float)(-sin(2.0 * pi * k / 1152.0)); }
-    for (int k = 0; k <= F4_NH1; ++k) { f4_w2Nr[k] = (float)cos(2.0 * pi * k / 2304.0); f4_w2Ni[k] = (float)(-sin(2.0 * pi * k / 2304.0)); }
     for (int i = 0; i < F4_NFFT; ++i)                   /* nuttal_window */
         f4_win[i] = (float)(0.3635819 - 0.4891775 * cos(2.0 * pi * i / 2304.0) + 0.1365995 * cos(4.0 * pi * i / 2304.0)
                             - 0.0106411 * cos(6.0 * pi * i / 2304.0));
     f4_ready = 1;
-}
-
-/* 2304 real -> |X[k]|^2, k = 0..1152: pack to 1152 complex = 9 x 128, same structure as spectrum_3840 */
-static void spectrum_2304(const float *x, float *pw)
-{
-    static float yr[F4_NA][NB], yi[F4_NA][NB];
-    for (int b = 0; b < NB; ++b) {
-        for (int c = 0; c < F4_NA; ++c) {
-            float ar = x[2 * b], ai = x[2 * b + 1];
-            for (int a = 1; a < F4_NA; ++a) {
-                const int m = NB * a + b;
-                const float zr = x[2 * m], zi = x[2 * m + 1];
-                const float wr = f4_w9r[(a * c) % F4_NA], wi = f4_w9i[(a * c) % F4_NA];
-                const float pr = zr * wr - zi * wi;
-                const float pi_ = zr * wi + zi * wr;
-                ar = ar + pr;
-                ai = ai + pi_;
-            }
-            const float tr = f4_wNr[b * c], ti = f4_wNi[b * c];
-            yr[c][rev7[b]] = ar * tr - ai * ti;
-            yi[c][rev7[b]] = ar * ti + ai * tr;
-        }
-    }
-    for (int c = 0; c < F4_NA; ++c) {
-        for (int len = 2; len <= NB; len <<= 1) {
-            const int half = len >> 1, step = NB / len;
-            for (int base = 0; base < NB; base += len) {
-                for (int k = 0; k < half; ++k) {
-                    const float wr = w128r[k * step], wi = w128i[k * step];
-                    const float ur = yr[c][base + k], ui = yi[c][base + k];
-                    const float vr = yr[c][base + k + half], vi = yi[c][base + k + half];
-                    const float tr = vr * wr - vi * wi;
-                    const float ti = vr * wi + vi * wr;
-                    yr[c][base + k] = ur + tr;        yi[c][base + k] = ui + ti;
-                    yr[c][base + k + half] = ur - tr; yi[c][base + k + half] = ui - ti;
-                }
-            }
-        }
-    }
-    for (int k = 0; k <= F4_NH1; ++k) {
-        const int k2 = (F4_NH1 - k) % F4_NH1, kk = k % F4_NH1;
-        const float ar = yr[kk % F4_NA][kk / F4_NA], ai = yi[kk % F4_NA][kk / F4_NA];
-        const float br = yr[k2 % F4_NA][k2 / F4_NA], bi = -yi[k2 % F4_NA][k2 / F4_NA];
-        const float er = (ar + br) * 0.5f, ei = (ai + bi) * 0.5f;
-        const float orr = (ar - br) * 0.5f, oi = (ai - bi) * 0.5f;
-        const float wr = f4_w2Nr[k], wi = f4_w2Ni[k];
-        const float tr = orr * wr - oi * wi;
-        const float ti = orr * wi + oi * wr;
-        const float xr = er + ti, xi = ei - tr;
-        pw[k] = xr * xr + xi * xi;
-    }
 }
 
 /* s_out: NHSYM rows of 1153 floats (bins 0..1152) */
@@ -338,7 +311,7 @@ int orc_ft4_spectra(const int16_t *frame, float *s_out)
     for (int j = 0; j < F4_NHSYM; ++j) {
         const int16_t *d = frame + (size_t)F4_NSTEP * j;
         for (int n = 0; n < F4_NFFT; ++n) x[n] = (fac * (float)d[n]) * f4_win[n];
-        spectrum_2304(x, s_out + (size_t)j * (F4_NH1 + 1));
+        spectrum_packed(&plan4, x, s_out + (size_t)j * (F4_NH1 + 1), F4_NH1 + 1);
     }
     return 0;
 }

@@ -16,9 +16,12 @@
  *                 different lag, the +-62 peak of each bin), threshold syncmin, near-dupe suppression
  *                 (4 Hz, 0.04 s), sorted by sync, first maxcand kept.
  *
- * Because no external implementation can arbitrate, the ARITHMETIC is fully specified here (un-fused float32
- * operations in a fixed order, a fixed FFT factorisation 3840 -> real-pack 1920 = 15 x 128 radix-2 DIT, host
- * twiddles from double cos/sin) so that the GPU kernels reproduce it BIT FOR BIT and "bit-identical candidate
+ * Because no external implementation can arbitrate, the ARITHMETIC is fully specified here (float32 operations
+ * in a fixed order; the transform -- "spec v2" at the top of sync_oracle.c -- is a fixed factorisation
+ * 3840 -> real-pack 1920 = 15 x 128 [FT4: 2304 -> 1152 = 9 x 128], NA-point DFTs in conjugate pairs with
+ * correctly-rounded fmaf chains, radix-2 DIT butterflies whose complex product is (fmaf, fmaf), host twiddles
+ * from double cos/sin with exact cardinal points; everything after the spectra is un-fused + - * /)
+ * so that the GPU kernels reproduce it BIT FOR BIT and "bit-identical candidate
  * lists" is a testable statement.  Ordering of the final list: descending sync, ties by ascending bin, then lag.
  */
 #ifndef SYNC_ORACLE_H
