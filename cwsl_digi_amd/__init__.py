@@ -6,7 +6,8 @@ There is no CPU fallback anywhere in this package.
 """
 from .api import (Context, CwslGpuError, GROUPS, group_of, frame_len, load_library,  # noqa: F401
                   STATUS_NAMES, parse_decoder_line, decoder_block_bytes, decoder_block_field,
-                  decoder_route, decoder_command)
+                  decoder_route, decoder_command, slot_clock_next, pool_sizing, find_band)
 
 __all__ = ["Context", "CwslGpuError", "GROUPS", "group_of", "frame_len", "load_library", "STATUS_NAMES", "parse_decoder_line",
-           "decoder_block_bytes", "decoder_block_field", "decoder_route", "decoder_command"]
+           "decoder_block_bytes", "decoder_block_field", "decoder_route", "decoder_command",
+           "slot_clock_next", "pool_sizing", "find_band"]

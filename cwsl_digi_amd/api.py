@@ -94,6 +94,7 @@ ABI_SYMBOLS = [
     "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_write_wav", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
     "cwslg_enable_sync", "cwslg_fetch_candidates", "cwslg_set_ft4_syncmin", "cwslg_sync_debug_fetch", "cwslg_get_stats", "cwslg_reset_stats",
     "cwslg_set_timing", "cwslg_stream", "cwslg_channel_constants", "cwslg_phasor_checkpoint_stride", "cwslg_channel_phasor_checkpoints",
+    "cwslg_slot_clock_next", "cwslg_pool_sizing", "cwslg_find_band",
     "cwslg_decoder_block_bytes", "cwslg_decoder_block_field", "cwslg_fill_decoder_block", "cwslg_decoder_route", "cwslg_decoder_command",
 ]
 
@@ -158,8 +159,38 @@ def load_library(build_if_missing=True):
     L.cwslg_fill_decoder_block.argtypes = [vp, i32, vp, C.c_size_t, i32, i32, i32, C.POINTER(u64)]
     L.cwslg_decoder_route.argtypes = [C.c_char_p, i32]
     L.cwslg_decoder_command.argtypes = [C.c_char_p, i32, i32, i32, i32, i32, f32, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.cwslg_slot_clock_next.argtypes = [i32, u64]; L.cwslg_slot_clock_next.restype = u64
+    L.cwslg_pool_sizing.argtypes = [C.POINTER(i32), f32, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.cwslg_find_band.argtypes = [C.POINTER(C.c_int64), C.POINTER(u32), i32, C.c_int64]
     _lib = L
     return L
+
+
+def slot_clock_next(group, after_ms):
+    """UTC ms of the group's (or mode's) next slot boundary strictly after after_ms (CWSL_DIGI.cpp:174-451)."""
+    g = (GROUPS[group] if group in GROUPS else _MODE_GROUP[group]) if isinstance(group, str) else int(group)
+    return int(load_library().cwslg_slot_clock_next(g, int(after_ms)))
+
+
+POOL_ORDER = ("FT4", "FT8", "Q65-30", "JS8", "WSPR", "JT65", "FST4W", "FST4")
+
+
+def pool_sizing(counts, decoderburden=1.0, n_decoders=None):
+    """(numjt9instances, maxwsprdinstances) from decoder counts in POOL_ORDER (CWSL_DIGI.cpp:857-887)."""
+    arr = (C.c_int * 8)(*[int(x) for x in counts])
+    nj, nw = C.c_int(), C.c_int()
+    rc = load_library().cwslg_pool_sizing(arr, float(decoderburden), int(sum(counts) if n_decoders is None else n_decoders),
+                                          C.byref(nj), C.byref(nw))
+    if rc != 0:
+        raise CwslGpuError(rc, "pool_sizing")
+    return nj.value, nw.value
+
+
+def find_band(bands, f_hz):
+    """bands = [(lo_hz, fs_hz), ...]; index of the first band covering f_hz or -1 (CWSL_Utils.hpp:28-55)."""
+    lo = (C.c_int64 * len(bands))(*[int(b[0]) for b in bands])
+    fs = (C.c_uint32 * len(bands))(*[int(b[1]) for b in bands])
+    return int(load_library().cwslg_find_band(lo, fs, len(bands), int(f_hz)))
 
 
 def decoder_block_bytes(js8=False):

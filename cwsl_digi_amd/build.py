@@ -11,6 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcwslgpu.so")
+BINDIR = os.path.join(HERE, "bin")
+SKIMMER = os.path.join(BINDIR, "cwsl_gpu_skimmer")
 
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit __builtin_fmaf and every
 # bit-exact sequence (the float32 phasor recurrence, prepareAudio, the synthetic source) is plain * and +.
@@ -29,7 +31,8 @@ def _stale():
     if not os.path.isfile(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f))]
+    deps += [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host"))]
     deps.append(os.path.join(HERE, "..", "include", "cwsl_gpu.h"))
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -46,7 +49,23 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    build_skimmer(force=True, verbose=verbose)
     return LIB
+
+
+def build_skimmer(force=False, verbose=False):
+    """Compile the Linux host program (csrc/host/skimmer_main.cpp, plain C++17 over the C ABI) -> bin/cwsl_gpu_skimmer."""
+    src = os.path.join(CSRC, "host", "skimmer_main.cpp")
+    if not force and os.path.isfile(SKIMMER) and os.path.getmtime(SKIMMER) >= max(
+            os.path.getmtime(os.path.join(CSRC, "host", f)) for f in os.listdir(os.path.join(CSRC, "host"))):
+        return SKIMMER
+    os.makedirs(BINDIR, exist_ok=True)
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", src, "-o", SKIMMER, "-L" + LIBDIR, "-lcwslgpu",
+           "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SKIMMER
 
 
 if __name__ == "__main__":

@@ -25,6 +25,8 @@
 #include "demod_kernels.hpp"
 #include "host_dsp.hpp"
 #include "handoff.hpp"
+#include "host/slot_clock.hpp"
+#include "host/skimmer_config.hpp"
 #include "sync_kernels.hpp"
 
 namespace cwslg {
@@ -1093,6 +1095,22 @@ int cwslg_write_wav(cwslg_ctx *c, int ch_id, const char *path)
     const bool ok = std::fwrite(h, 1, sizeof(h), f) == sizeof(h) && std::fwrite(pcm.data(), sizeof(int16_t), n, f) == n;
     std::fclose(f);
     return ok ? CWSLG_OK : fail(c, CWSLG_ERR_ARG, "short write to %s", path);
+}
+
+// ---- host service pieces: pure functions, no device work ----
+uint64_t cwslg_slot_clock_next(int group, uint64_t after_ms) { return cwslg::host::slot_clock_next(group, after_ms); }
+
+int cwslg_pool_sizing(const int *counts, float decoderburden, int n_decoders, int *numjt9instances, int *maxwsprdinstances)
+{
+    if (!counts || n_decoders < 0) return CWSLG_ERR_ARG;
+    cwslg::host::pool_sizing(counts, decoderburden, n_decoders, numjt9instances, maxwsprdinstances);
+    return CWSLG_OK;
+}
+
+int cwslg_find_band(const int64_t *lo_hz, const uint32_t *fs_hz, int n_bands, int64_t f_hz)
+{
+    if (!lo_hz || !fs_hz || n_bands < 0) return CWSLG_ERR_ARG;
+    return cwslg::host::find_band(lo_hz, fs_hz, n_bands, f_hz);
 }
 
 // ---- downstream hand-off formats (layouts and rules in handoff.hpp) ----

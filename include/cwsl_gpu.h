@@ -160,6 +160,19 @@ int cwslg_fetch_frame(cwslg_ctx *ctx, int ch_id, int16_t *dst, size_t cap,
  * transfermethod=wavefile mode (DecoderPool.hpp:966-1046).  For the shared-memory mode pass &dec_data->d2[0]
  * to cwslg_fetch_frame instead (DecoderPool.hpp:588). */
 int cwslg_write_wav(cwslg_ctx *ctx, int ch_id, const char *path);
+/* ---- host service pieces: pure functions, usable without a context -----------------------
+ * Slot clock: the first boundary instant (UTC milliseconds) of a mode group strictly after `after_ms` -- what the
+ * reference's waitForTime* polling threads (CWSL_DIGI.cpp:174-451) converge on within one 25 ms poll: FT8 :00/:15/
+ * :30/:45; FT4 the same plus 7.4 s later (the thread sleeps to 400 ms into seconds 7/22/37/52, :427-437); Q65-30
+ * :00/:30; 60 s; 120/300/900/1800 s at second 0 of minutes divisible by 2/5/15/30.  Returns 0 for a bad group.
+ * The epoch to hand to cwslg_slot_boundary() is edge_ms / 1000 (Instance.cpp:214 stamps whole seconds). */
+uint64_t cwslg_slot_clock_next(int group, uint64_t after_ms);
+/* Decoder-pool sizing (CWSL_DIGI.cpp:857-887).  counts[8] = decoders of FT4, FT8, Q65-30, JS8, WSPR, JT65, FST4W-*,
+ * FST4-* in that order. */
+int cwslg_pool_sizing(const int *counts, float decoderburden, int n_decoders, int *numjt9instances, int *maxwsprdinstances);
+/* findBand (CWSL_Utils.hpp:28-55): index of the first band with |f - L0| <= Fs/2, or -1. */
+int cwslg_find_band(const int64_t *lo_hz, const uint32_t *fs_hz, int n_bands, int64_t f_hz);
+
 /* ---- decoder hand-off formats -------------------------------------------------------------
  * The block a stock jt9 (js8 = 0: dec_data_t, DecoderPool.hpp:58-108, "in sync with lib/jt9com.f90") or js8
  * (js8 = 1: dec_data_js8_t, :110-171) maps as shared memory.  cwslg_fill_decoder_block() does what

@@ -95,6 +95,9 @@ def lib():
         L.orc_decoder_route.argtypes = [C.c_char_p, C.c_int]
         L.orc_decoder_command.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_char_p,
                                           C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.orc_clock_sim.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
+        L.orc_pool_sizing.argtypes = [C.POINTER(C.c_int), C.c_float, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_find_band.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.c_int, C.c_int64]
         _lib = L
     return _lib
 
@@ -371,6 +374,27 @@ def decoder_command(mode, target, shmem_route, numjt9threads=3, decodedepth=3, h
     rc = lib().orc_decoder_command(mode.encode(), int(shmem_route), numjt9threads, decodedepth, highest_decode_hz,
                                    wspr_cycles, float(trperiod), str(target).encode(), app, 64, opts, 1024)
     return (app.value.decode(), opts.value.decode()) if rc == 0 else None
+
+
+# ---- host-service rules (host_oracle.c; CWSL_DIGI.cpp:174-451, 857-887; CWSL_Utils.hpp:28-55) ----
+def clock_sim(group, start_ms, end_ms, max_fires=4096):
+    """Fire times (UTC ms) of the reference's polling thread of `group`, run in virtual time over [start, end)."""
+    buf = np.zeros(max_fires, np.uint64)
+    n = lib().orc_clock_sim(int(group), int(start_ms), int(end_ms), buf.ctypes.data, max_fires)
+    return [int(x) for x in buf[:min(n, max_fires)]]
+
+
+def pool_sizing(counts, decoderburden=1.0, n_decoders=None):
+    arr = (C.c_int * 8)(*[int(x) for x in counts])
+    nj, nw = C.c_int(), C.c_int()
+    lib().orc_pool_sizing(arr, float(decoderburden), int(sum(counts) if n_decoders is None else n_decoders), C.byref(nj), C.byref(nw))
+    return nj.value, nw.value
+
+
+def find_band(bands, f_hz):
+    lo = (C.c_int64 * len(bands))(*[int(b[0]) for b in bands])
+    fs = (C.c_uint32 * len(bands))(*[int(b[1]) for b in bands])
+    return int(lib().orc_find_band(lo, fs, len(bands), int(f_hz)))
 
 
 def bench_cpu(threads, slots, fs=192000, iq_len=2048, n_per_slot=2880000):
