@@ -289,17 +289,24 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     if (c->exact) {
         hipLaunchKernelGGL((demod_exact_kernel<D, kTile, kDemodThreads>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
                            c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
-    } else if (c->demod_variant == 1) {
-        // persistent variant (measured alternative): as many workgroups as are resident at once
+    } else if (c->demod_variant == 1 || c->demod_variant == 2) {
+        // persistent variants (measured alternatives): as many workgroups as are resident at once
         int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, demod_kernel<D, kTile, kDemodThreads, true>, kDemodThreads, 0) != hipSuccess || occ < 1) occ = 3;
+        const bool loop = c->demod_variant == 2;
+        hipError_t oe = loop ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, demod_kernel<D, kTile, kDemodThreads, 2>, kDemodThreads, 0)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, demod_kernel<D, kTile, kDemodThreads, 1>, kDemodThreads, 0);
+        if (oe != hipSuccess || occ < 1) occ = 3;
         if (const char *v = std::getenv("CWSLG_PERSIST_WGS_PER_CU")) occ = std::max(1, std::atoi(v));
         long long wgs = std::min<long long>((long long)c->cu_count * occ, per_xcd * 8);
         wgs = (wgs + 7) / 8 * 8;
-        hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, true>), dim3((unsigned)wgs), dim3(kDemodThreads), 0,
-                           c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
+        if (loop)
+            hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, 2>), dim3((unsigned)wgs), dim3(kDemodThreads), 0,
+                               c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
+        else
+            hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, 1>), dim3((unsigned)wgs), dim3(kDemodThreads), 0,
+                               c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
     } else {
-        hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, false>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
+        hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, 0>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
                            c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
     }
     span_end(c, eb);

@@ -226,8 +226,10 @@ struct DemodGeom {
 
 
 // ---------------------------------------------------------------------------------------------
-// demod_kernel<D, T, NT, PERSIST>: one tile = T outputs of one channel (see the file header for the phases).
-//   PERSIST = false  one workgroup per (channel, tile) work item; 4 workgroups per CU hide each other's HBM latency.
+// demod_kernel<D, T, NT, MODE>: one tile = T outputs of one channel (see the file header for the phases).
+//   MODE 2           persistent workgroups walking a run of work items like MODE 1 but WITHOUT the prefetch (loads issued
+//                    at the top of each item): saves the per-workgroup launch, descriptor and tap loads.
+//   MODE 0 (PERSIST = false)  one workgroup per (channel, tile) work item; 4 workgroups per CU hide each other's HBM latency.
 //                    This is the default: measured 3.05 ms per 512-slot launch.
 //   PERSIST = true   a persistent workgroup walks a run of work items and keeps the NEXT item's HBM loads in
 //                    flight (registers) while it computes the current one.  Kept as a measured alternative
@@ -343,12 +345,14 @@ __device__ __forceinline__ void issue_tile_loads(const TileCtx<D, T> &c, int tid
     tn = as_global(reinterpret_cast<const v4f *>(c.tone))[((2 * tid) % D) >> 1];   // tone[m0], tone[m0+1]
 }
 
-template <int D, int T, int NT, bool PERSIST>
+template <int D, int T, int NT, int MODE>
 __global__ __launch_bounds__(NT, 4) void demod_kernel(const ChanWork *__restrict__ works,
                                                                      const float *__restrict__ taps,
                                                                      int tiles_x, int n_ch)
 {
     using Geo = DemodGeom<D, T>;
+    constexpr bool PERSIST = (MODE == 1);       // in-place prefetch of the next item
+    constexpr bool LOOP = (MODE == 2);          // persistent workgroup, loads issued at the top of every item
     constexpr int G = Geo::G;
     constexpr int GL = Geo::GL;
     constexpr int PR = Geo::PR;
@@ -563,6 +567,15 @@ __global__ __launch_bounds__(NT, 4) void demod_kernel(const ChanWork *__restrict
         }
         STAMP(6);
         }   // work in this iteration
+        if (LOOP) {
+            item = nitem;
+            if (item >= hi_item) break;
+            lds_barrier();                                       // s_aux (= s_phase) is rewritten by the next phase 0
+            item_to_ch_tile(item, tiles_x, n_ch, ich, itile);
+            decode_item<D, T>(works + ich, itile, cur);
+            issue_tile_loads<D, T, NT>(cur, tid, xs, ck, tn);
+            continue;
+        }
         if (!has_next) break;
         lds_barrier();                                           // s_aux (= s_phase) is rewritten by the next phase 0
         cur = nxt;
