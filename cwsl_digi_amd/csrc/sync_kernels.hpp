@@ -108,17 +108,37 @@ __device__ __forceinline__ float2 cmul_f(float2 v, float2 w)
 // Any schedule that evaluates the same operations gives the same bits; here each lane does 8-point groups (three
 // radix-2 stages) in registers per LDS pass, and products by the exact table entries W^0 = (1,0) and
 // W128^32 = (0,-1) are not multiplied out (identical up to the sign of zeros, which |X|^2 cannot see).
-// LDS image of the NA x 128 work array: row pitch 129 (rows start 2 banks apart) and, after pass A, logical
-// column i stored at i ^ ((i >> 3) & 7) -- together they keep every pass at <= 2-way bank conflicts
-// (the plain [15][128] image ran the LDS at 94 % busy, two thirds of it conflict cycles).
-constexpr int SY_PITCH = 129;
-__device__ __forceinline__ int sy_col(int i) { return i ^ ((i >> 3) & 7); }
+// LDS image of the NA x 128 work array: row pitch 144 complex (consecutive rows start 32 banks apart: the two rows of a
+// 32-lane ds_read_b64 group fall into different halves of the 64 banks) and, after pass A, logical column i stored at
+// i ^ ((i >> 3) & 15) (a 16-lane ds_write_b64 group -- one row, 16 eight-point groups -- hits 16 distinct bank pairs).
+// Every pass is then conflict-free; stage 3 walks the bins residue by residue (k = NA q + r, lane = q) so that its two
+// reads per bin run along rows, and stages the power row through LDS for a coalesced store.
+// (History: the plain [15][128] image ran the LDS at 94 % busy, two thirds of it conflict cycles; pitch 129 with a
+// 3-bit swizzle left every pass 2-way conflicted, 37 % of the LDS cycles.)
+constexpr int SY_PITCH = 144;
+__device__ __forceinline__ int sy_col(int i) { return i ^ ((i >> 3) & 15); }
 
 // NA = 15 (FT8: 1920 = 15 x 128, only the first NPACK = 960 packed inputs are non-zero) or 9 (FT4: 1152 = 9 x 128).
 // HALF 0 (waves 0-1): output 0 and the pairs c = 1..SPLIT;  HALF 1 (waves 2-3): the pairs c = SPLIT+1..NA/2.
+// the W_NZ^(bc) twiddles of one thread's outputs, fetched at the top of the kernel so that their L2 latency runs under
+// the frame load instead of after the first barrier
+template <int NA>
+struct Stage1Tw { float2 v[2 * (NA / 2 - (NA / 2) / 2)]; };
+template <int HALF, int NA>
+__device__ __forceinline__ void stage1_load_tw(const float2 *__restrict__ wn, int b, Stage1Tw<NA> &tw)
+{
+    constexpr int NPAIR = NA / 2, SPLIT = NPAIR / 2;
+    constexpr int C0 = HALF ? SPLIT + 1 : 1, C1 = HALF ? NPAIR : SPLIT;
+#pragma unroll
+    for (int c = C0; c <= C1; ++c) {
+        tw.v[2 * (c - C0)] = wn[b * c];
+        tw.v[2 * (c - C0) + 1] = wn[b * (NA - c)];
+    }
+}
+
 template <int HALF, int NA, int NPACK>
 __device__ __forceinline__ void spectra_stage1(const float *s_x, float2 (*s_y)[SY_PITCH], const SyncTables &tb,
-                                               const float2 *__restrict__ wn, int b)
+                                               const Stage1Tw<NA> &twp, int b)
 {
     constexpr int AMAX = (NPACK + 127) / 128;            // 8 (FT8), 9 (FT4)
     constexpr int NPAIR = NA / 2, SPLIT = NPAIR / 2;
@@ -129,12 +149,7 @@ __device__ __forceinline__ void spectra_stage1(const float *s_x, float2 (*s_y)[S
         const int m = 128 * a + b;                       // a zero input adds exactly nothing to an fmaf chain
         z[a] = (m < NPACK) ? make_float2(s_x[2 * m], s_x[2 * m + 1]) : make_float2(0.f, 0.f);
     }
-    float2 tw[2 * (C1 - C0 + 1)];
-#pragma unroll
-    for (int c = C0; c <= C1; ++c) {
-        tw[2 * (c - C0)] = wn[b * c];
-        tw[2 * (c - C0) + 1] = wn[b * (NA - c)];
-    }
+    const float2 *tw = twp.v;
     if (HALF == 0) {
         float2 s0 = z[0];
 #pragma unroll
@@ -201,6 +216,20 @@ __global__ __launch_bounds__(256) void symbol_spectra_kernel(const SyncWork *__r
     const int tid = threadIdx.x;
     const int16_t *d = w->frame + (size_t)STEP * j;
     const float fac = 1.0f / 300.0f;
+    // twiddles first (tables live in L2): stage 1's W_NZ^(bc) and the W_2NZ^k of this thread's first stage-3 bins
+    Stage1Tw<NA> tw1;
+    if (tid < 128) stage1_load_tw<0, NA>(tb.w1920, tid & 127, tw1);
+    else stage1_load_tw<1, NA>(tb.w1920, tid & 127, tw1);
+    constexpr int W3PRE = 4;
+    float2 w3[W3PRE];
+    const bool staged = nbins <= NIN;
+    const int nfull = min(nbins, NZ) / (NA * 64);         // whole 64-column chunks of bins below nbins (stage 3)
+#pragma unroll
+    for (int i = 0; i < W3PRE; ++i) {
+        const int it = (tid >> 6) + 4 * i;
+        const int k = NA * (64 * (it / NA) + (tid & 63)) + it % NA;
+        w3[i] = (staged && it < NA * nfull) ? tb.w3840[k] : make_float2(0.f, 0.f);
+    }
     for (int t = tid; t < NIN / 8; t += 256) {            // 16 B = 8 samples per lane
         const uint4 q = reinterpret_cast<const uint4 *>(d)[t];
         const unsigned v[4] = {q.x, q.y, q.z, q.w};
@@ -217,8 +246,8 @@ __global__ __launch_bounds__(256) void symbol_spectra_kernel(const SyncWork *__r
     __syncthreads();
 
     // stage 1 (wave-uniform split of the conjugate pairs of outputs between waves 0-1 and waves 2-3)
-    if (tid < 128) spectra_stage1<0, NA, NPACK>(s_x, s_y, tb, tb.w1920, tid & 127);
-    else spectra_stage1<1, NA, NPACK>(s_x, s_y, tb, tb.w1920, tid & 127);
+    if (tid < 128) spectra_stage1<0, NA, NPACK>(s_x, s_y, tb, tw1, tid & 127);
+    else spectra_stage1<1, NA, NPACK>(s_x, s_y, tb, tw1, tid & 127);
     __syncthreads();
 
     // stage 2, pass A: DIT stages len = 2,4,8 on logical points 8g..8g+7 of row c; the DIT input order is
@@ -277,22 +306,54 @@ __global__ __launch_bounds__(256) void symbol_spectra_kernel(const SyncWork *__r
     }
     __syncthreads();
 
-    // stage 3: unpack the real-input transform, power spectrum
+    // stage 3: unpack the real-input transform, power spectrum.  X[k] needs Z[k] and Z[NZ-k], Z[c + NA d] = y[c][d].
     float *out = w->spectra + (size_t)j * nbins;
-    for (int k = tid; k < nbins; k += 256) {
-        float pw = 0.0f;
-        if (k <= NZ) {
-            const int k2 = (NZ - k) % NZ, kk = k % NZ;
-            const float2 A = s_y[kk % NA][sy_col(kk / NA)];
-            float2 B = s_y[k2 % NA][sy_col(k2 / NA)];
+    auto power_at = [&](int k) -> float {                  // generic indexing (any k <= NZ)
+        const int k2 = (NZ - k) % NZ, kk = k % NZ;
+        const float2 A = s_y[kk % NA][sy_col(kk / NA)];
+        float2 B = s_y[k2 % NA][sy_col(k2 / NA)];
+        B.y = -B.y;
+        const float er = (A.x + B.x) * 0.5f, ei = (A.y + B.y) * 0.5f;
+        const float2 o = make_float2((A.x - B.x) * 0.5f, (A.y - B.y) * 0.5f);
+        const float2 t = cmul_f(o, tb.w3840[k]);
+        const float xr = er + t.y, xi = ei - t.x;
+        return __builtin_fmaf(xr, xr, xi * xi);
+    };
+    if (staged) {
+        // residue-major walk: item (r, chunk) = bins k = NA (64 chunk + lane) + r.  Row k % NA = r and row (NZ-k) % NA
+        // are wave-uniform, the columns run with the lane: both reads are conflict-free.  The row of powers is
+        // collected in s_x (free since stage 1; stride NA between lanes = odd: conflict-free) and stored coalesced.
+        float *s_pw = s_x;
+        const int lane = tid & 63, wv = tid >> 6;
+        int pre = 0;
+        for (int it = wv; it < NA * nfull; it += 4, ++pre) {
+            const int r = it % NA, q = 64 * (it / NA) + lane;
+            const int k = NA * q + r;
+            const float2 A = s_y[r][sy_col(q)];
+            const int r2 = (r == 0) ? 0 : NA - r;
+            const int q2 = (r == 0) ? ((q == 0) ? 0 : 128 - q) : 127 - q;     // (NZ - k) / NA ; k = 0 pairs with itself
+            float2 B = s_y[r2][sy_col(q2)];
             B.y = -B.y;
             const float er = (A.x + B.x) * 0.5f, ei = (A.y + B.y) * 0.5f;
             const float2 o = make_float2((A.x - B.x) * 0.5f, (A.y - B.y) * 0.5f);
-            const float2 t = cmul_f(o, tb.w3840[k]);
+            float2 wk;
+            switch (pre) {                                   // the first W3PRE twiddles were fetched at the top
+            case 0: wk = w3[0]; break;
+            case 1: wk = w3[1]; break;
+            case 2: wk = w3[2]; break;
+            case 3: wk = w3[3]; break;
+            default: wk = tb.w3840[k]; break;
+            }
+            const float2 t = cmul_f(o, wk);
             const float xr = er + t.y, xi = ei - t.x;
-            pw = __builtin_fmaf(xr, xr, xi * xi);
+            s_pw[k] = __builtin_fmaf(xr, xr, xi * xi);
         }
-        out[k] = pw;
+        for (int k = NA * 64 * nfull + tid; k < nbins; k += 256)              // ragged tail (FT8: 16 bins, FT4: bin 1152 + pad)
+            s_pw[k] = (k <= NZ) ? power_at(k) : 0.0f;
+        __syncthreads();
+        for (int k = tid; k < nbins; k += 256) out[k] = s_pw[k];
+    } else {
+        for (int k = tid; k < nbins; k += 256) out[k] = (k <= NZ) ? power_at(k) : 0.0f;
     }
 }
 
