@@ -95,6 +95,10 @@ def lib():
         L.orc_decoder_route.argtypes = [C.c_char_p, C.c_int]
         L.orc_decoder_command.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_char_p,
                                           C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.orc_ft4_bigspec.argtypes = [_i16p, _f32p]
+        L.orc_ft4_downsample.argtypes = [_f32p, C.c_float, _f32p]
+        L.orc_ft4_sync4d.argtypes = [_f32p, C.c_int, C.c_int]; L.orc_ft4_sync4d.restype = C.c_float
+        L.orc_ft4_search.argtypes = [_f32p, C.c_float, C.c_int, C.c_void_p, C.c_int]
         L.orc_clock_sim.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
         L.orc_pool_sizing.argtypes = [C.POINTER(C.c_int), C.c_float, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_find_band.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.c_int, C.c_int64]
@@ -374,6 +378,51 @@ def decoder_command(mode, target, shmem_route, numjt9threads=3, decodedepth=3, h
     rc = lib().orc_decoder_command(mode.encode(), int(shmem_route), numjt9threads, decodedepth, highest_decode_hz,
                                    wspr_cycles, float(trperiod), str(target).encode(), app, 64, opts, 1024)
     return (app.value.decode(), opts.value.decode()) if rc == 0 else None
+
+
+# ---- FT4 coherent sync (ft4sync_oracle.c; PARITY UNPINNED: ft4_downsample / sync4d / ft4_decode search restated) ----
+class _Ft4Sync(C.Structure):
+    _fields_ = [("f0_hz", C.c_float), ("f1_hz", C.c_float), ("dt_s", C.c_float), ("sync", C.c_float),
+                ("ibest", C.c_int32), ("idf", C.c_int32), ("seg", C.c_int32), ("cand", C.c_int32)]
+
+
+def ft4_bigspec(frame_i16):
+    """complex64[36289]: spectrum of the frame's first 72576 samples."""
+    fr = np.ascontiguousarray(frame_i16, dtype=np.int16)
+    assert fr.shape[0] >= 72576
+    out = np.empty(2 * 36289, np.float32)
+    lib().orc_ft4_bigspec(fr, out)
+    return out.view(np.complex64)
+
+
+def ft4_downsample(cx, f0_hz):
+    """(complex64[4032] normalised baseband at 666.7 Hz, i0)."""
+    cxf = np.ascontiguousarray(cx).view(np.float32)
+    out = np.empty(2 * 4032, np.float32)
+    i0 = lib().orc_ft4_downsample(cxf, float(f0_hz), out)
+    return out.view(np.complex64), int(i0)
+
+
+def ft4_sync4d(cd, i0, idf=0):
+    return float(lib().orc_ft4_sync4d(np.ascontiguousarray(cd).view(np.float32), int(i0), int(idf)))
+
+
+def ft4_search(cd, f0_hz, cand=0):
+    """The three-segment coarse+fine search of ft4_decode: list of dicts (f0_hz, f1_hz, dt_s, sync, ibest, idf, seg, cand)."""
+    buf = (_Ft4Sync * 3)()
+    n = lib().orc_ft4_search(np.ascontiguousarray(cd).view(np.float32), float(f0_hz), int(cand), buf, 3)
+    return [dict(f0_hz=b.f0_hz, f1_hz=b.f1_hz, dt_s=b.dt_s, sync=b.sync, ibest=b.ibest, idf=b.idf, seg=b.seg, cand=b.cand)
+            for b in buf[:n]]
+
+
+def ft4_sync_all(frame_i16, cands):
+    """Refine every getcandidates4 candidate (tuples with freq_hz at index 3) of a frame."""
+    cx = ft4_bigspec(frame_i16)
+    out = []
+    for k, c in enumerate(cands):
+        cd, _ = ft4_downsample(cx, np.float32(c[3]))
+        out += ft4_search(cd, np.float32(c[3]), k)
+    return out
 
 
 # ---- host-service rules (host_oracle.c; CWSL_DIGI.cpp:174-451, 857-887; CWSL_Utils.hpp:28-55) ----

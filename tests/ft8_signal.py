@@ -39,3 +39,28 @@ def ft4_iq(fs, n, rf_hz, audio_hz, t0_s, amp, rng):
     m = min(len(sig), n - i0)
     out[i0:i0 + m] = sig[:m]
     return out
+
+
+ICOS4 = [[0, 1, 3, 2], [1, 0, 2, 3], [2, 3, 1, 0], [3, 2, 0, 1]]
+
+
+def ft4_frame_tones(rng):
+    """103 FT4 channel symbols: Costas blocks at symbols 0, 33, 66, 99, random data elsewhere."""
+    t = list(rng.integers(0, 4, 103))
+    for b, base in enumerate((0, 33, 66, 99)):
+        t[base:base + 4] = ICOS4[b]
+    return np.array(t)
+
+
+def ft4_audio(n, f0_hz, t_start_s, amp, rng, fs=12000):
+    """Real 12 kHz audio of one FT4 transmission whose first Costas symbol starts t_start_s into the buffer
+    (tone 0 at f0_hz, 20.833 Hz spacing, 48 ms symbols, continuous phase, no pulse shaping)."""
+    tones = ft4_frame_tones(rng)
+    sps = 576 * fs // 12000
+    f = f0_hz + (12000.0 / 576.0) * np.repeat(tones, sps)
+    ph = 2 * np.pi * np.cumsum(f) / fs
+    out = np.zeros(n)
+    i0 = int(round(t_start_s * fs))
+    m = min(len(ph), n - i0)
+    out[i0:i0 + m] = amp * np.cos(ph[:m])
+    return out
