@@ -75,6 +75,11 @@ class Candidate(C.Structure):
                 ("freq_hz", C.c_float), ("dt_s", C.c_float)]
 
 
+class Ft4Sync(C.Structure):
+    _fields_ = [("f0_hz", C.c_float), ("f1_hz", C.c_float), ("dt_s", C.c_float), ("sync", C.c_float),
+                ("ibest", C.c_int32), ("idf", C.c_int32), ("seg", C.c_int32), ("cand", C.c_int32)]
+
+
 class Stats(C.Structure):
     _fields_ = [("demod_launches", C.c_uint64), ("demod_samples", C.c_uint64),
                 ("finalize_launches", C.c_uint64), ("sync_launches", C.c_uint64), ("frames_emitted", C.c_uint64),
@@ -92,7 +97,7 @@ ABI_SYMBOLS = [
     "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_parse_decoder_line", "cwslg_channel_open_line", "cwslg_channel_open", "cwslg_channel_close",
     "cwslg_channel_info", "cwslg_process", "cwslg_slot_boundary", "cwslg_slot_boundary_channel",
     "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_write_wav", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
-    "cwslg_enable_sync", "cwslg_fetch_candidates", "cwslg_set_ft4_syncmin", "cwslg_sync_debug_fetch", "cwslg_get_stats", "cwslg_reset_stats",
+    "cwslg_enable_sync", "cwslg_fetch_candidates", "cwslg_set_ft4_syncmin", "cwslg_enable_ft4_coherent", "cwslg_fetch_ft4_sync", "cwslg_sync_debug_fetch", "cwslg_get_stats", "cwslg_reset_stats",
     "cwslg_set_timing", "cwslg_stream", "cwslg_channel_constants", "cwslg_phasor_checkpoint_stride", "cwslg_channel_phasor_checkpoints",
     "cwslg_slot_clock_next", "cwslg_pool_sizing", "cwslg_find_band",
     "cwslg_decoder_block_bytes", "cwslg_decoder_block_field", "cwslg_fill_decoder_block", "cwslg_decoder_route", "cwslg_decoder_command",
@@ -147,6 +152,8 @@ def load_library(build_if_missing=True):
     L.cwslg_enable_sync.argtypes = [vp, i32, f32, i32, i32, i32]
     L.cwslg_fetch_candidates.argtypes = [vp, i32, C.POINTER(Candidate), i32, C.POINTER(i32)]
     L.cwslg_set_ft4_syncmin.argtypes = [vp, f32]
+    L.cwslg_enable_ft4_coherent.argtypes = [vp, i32]
+    L.cwslg_fetch_ft4_sync.argtypes = [vp, i32, C.POINTER(Ft4Sync), i32, C.POINTER(i32)]
     L.cwslg_sync_debug_fetch.argtypes = [vp, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i32)]
     L.cwslg_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.cwslg_reset_stats.argtypes = [vp]
@@ -387,13 +394,32 @@ class Context:
         self._chk(self.L.cwslg_fetch_candidates(self.h, ch, buf, max_cand, C.byref(n)))
         return [(buf[k].freq_bin, buf[k].time_step, buf[k].sync, buf[k].freq_hz, buf[k].dt_s) for k in range(n.value)]
 
+    def enable_ft4_coherent(self, enable=True):
+        self._chk(self.L.cwslg_enable_ft4_coherent(self.h, int(enable)))
+
+    def fetch_ft4_sync(self, ch, max_rec=1800):
+        """Refined FT4 candidates (ft4_downsample + sync4d search): list of dicts, candidate order then segment order."""
+        buf = (Ft4Sync * max_rec)()
+        n = C.c_int()
+        rc = self.L.cwslg_fetch_ft4_sync(self.h, ch, buf, max_rec, C.byref(n))
+        if rc == ERR_NO_FRAME:
+            return None
+        self._chk(rc)
+        return [dict(f0_hz=b.f0_hz, f1_hz=b.f1_hz, dt_s=b.dt_s, sync=b.sync, ibest=b.ibest, idf=b.idf, seg=b.seg, cand=b.cand)
+                for b in buf[:n.value]]
+
     def set_ft4_syncmin(self, syncmin=1.2):
         self._chk(self.L.cwslg_set_ft4_syncmin(self.h, syncmin))
 
     def sync_debug(self, ch, what):
         """what: 'spectra' -> float32[steps, row]; 'red'/'red2' -> float32[1921]; 'jpeak'/'jpeak2' -> int32[1921].
         FT4 channels: 'red' = savsm/sbase, 'red2' = sbase (first 1153 entries meaningful)."""
-        sel = {"spectra": 0, "red": 1, "red2": 2, "jpeak": 3, "jpeak2": 4}[what]
+        sel = {"spectra": 0, "red": 1, "red2": 2, "jpeak": 3, "jpeak2": 4, "ft4_cx": 5, "ft4_cd0": 6}[what]
+        if sel >= 5:                                    # FT4 coherent stage: complex64[36289] / complex64[4032]
+            buf = np.empty(2 * (36289 if sel == 5 else 4032), np.float32)
+            n, row = C.c_size_t(), C.c_int()
+            self._chk(self.L.cwslg_sync_debug_fetch(self.h, ch, sel, buf.ctypes.data, buf.nbytes, C.byref(n), C.byref(row)))
+            return buf.view(np.complex64)
         buf = np.empty(372 * 1936 if sel == 0 else 1921, np.float32 if sel < 3 else np.int32)
         n, row = C.c_size_t(), C.c_int()
         self._chk(self.L.cwslg_sync_debug_fetch(self.h, ch, sel, buf.ctypes.data, buf.nbytes, C.byref(n), C.byref(row)))

@@ -28,6 +28,7 @@
 #include "host/slot_clock.hpp"
 #include "host/skimmer_config.hpp"
 #include "sync_kernels.hpp"
+#include "ft4sync_kernels.hpp"
 
 namespace cwslg {
 
@@ -146,6 +147,7 @@ struct cwslg_ctx {
     // sync stage
     SyncConfig sync_cfg;
     SyncShared sync_shared;
+    Ft4Tables ft4_tables{};
 };
 
 namespace {

@@ -37,6 +37,7 @@ struct SyncConfig {
     bool enabled = false;
     float syncmin = 1.5f;
     float syncmin_ft4 = 1.2f;             // ft4_decode's threshold for getcandidates4
+    bool ft4_coherent = true;             // run ft4_downsample + sync4d on every FT4 candidate (ft4sync_kernels.hpp)
     int max_cand = 200;
     int f_lo_hz = 200, f_hi_hz = 3000;
     int ia = 64, ib = 960, nbins = 976;   // derived: bin range and stored row length (ib+13 rounded up to 16)
@@ -54,6 +55,8 @@ struct SyncShared {
     float *d_win = nullptr;               // Nuttall window, 2304 floats
     SyncTables t{};                       // FT8 set
     SyncTables t4{};                      // FT4 set (w15 -> W_9, w1920 -> W_1152, w3840 -> W_2304)
+    float2 *d_ft4c = nullptr;             // FT4 coherent-sync tables (ft4sync_kernels.hpp), one allocation
+    float *d_ft4c_win = nullptr;
 };
 
 struct SyncChannelBuffers {
@@ -65,6 +68,11 @@ struct SyncChannelBuffers {
     int *d_ncand = nullptr;
     int nbins = 0, max_cand = 0;
     bool ft4 = false;                     // FT4 layout: spectra [122][FT4_ROW]; red = normalised savsm, red2 = sbase
+    // FT4 coherent sync (ft4sync_kernels.hpp): frame spectrum, its stage-A scratch, refined records
+    char *d_ft4c = nullptr;
+    float2 *d_y = nullptr, *d_cx = nullptr, *d_cd_dbg = nullptr;
+    void *d_rec = nullptr;                // Ft4Rec [max_cand][3]
+    int *d_nrec = nullptr;                // [max_cand]
 };
 
 struct alignas(16) SyncWork {
@@ -79,12 +87,15 @@ struct alignas(16) SyncWork {
 inline void sync_free_channel(SyncChannelBuffers &b)
 {
     if (b.d_block) (void)hipFree(b.d_block);
+    if (b.d_ft4c) (void)hipFree(b.d_ft4c);
     b = SyncChannelBuffers();
 }
 inline void sync_free_shared(SyncShared &s)
 {
     if (s.d_tables) (void)hipFree(s.d_tables);
     if (s.d_win) (void)hipFree(s.d_win);
+    if (s.d_ft4c) (void)hipFree(s.d_ft4c);
+    if (s.d_ft4c_win) (void)hipFree(s.d_ft4c_win);
     s = SyncShared();
 }
 

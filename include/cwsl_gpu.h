@@ -202,11 +202,29 @@ int cwslg_enable_sync(cwslg_ctx *ctx, int enable, float syncmin, int max_cand, i
 int cwslg_fetch_candidates(cwslg_ctx *ctx, int ch_id, cwslg_candidate *dst, int max, int *n);
 /* FT4 channels run getcandidates4's spectral-peak search instead (freq_hz = interpolated peak - 1.5 tone spacings,
  * sync = normalised peak height, time_step/dt_s = 0); its threshold defaults to upstream's 1.2. */
+/* FT4 coherent sync (row a13; PARITY UNPINNED, restated from upstream ft4_decode / ft4_downsample / sync4d): every
+ * getcandidates4 candidate of an FT4 channel is band-limited to a 666.7 Hz complex baseband around its frequency and
+ * correlated with the four 4x4 Costas blocks over ft4_decode's three start-time segments (coarse then fine grid in start
+ * sample and frequency tweak).  One record per candidate and segment that passes (sync >= 1.2, not weaker than segment 1,
+ * 10 < f1 < 4990), in candidate order then segment order.  Enabled by default whenever sync is enabled. */
+typedef struct {
+    float   f0_hz;        /* the getcandidates4 candidate                                            */
+    float   f1_hz;        /* f0 + best frequency tweak (Hz)                                          */
+    float   dt_s;         /* ibest / 666.67 - 0.5                                                    */
+    float   sync;         /* sum of the four block correlation magnitudes / 64                       */
+    int32_t ibest;        /* start sample of the first Costas block at 666.7 Hz                      */
+    int32_t idf;          /* frequency tweak, Hz                                                     */
+    int32_t seg;          /* 1..3: ft4_decode's start-time segment                                   */
+    int32_t cand;         /* index into the cwslg_fetch_candidates list                              */
+} cwslg_ft4_sync;
+int cwslg_enable_ft4_coherent(cwslg_ctx *ctx, int enable);
+int cwslg_fetch_ft4_sync(cwslg_ctx *ctx, int ch_id, cwslg_ft4_sync *dst, int max, int *n);
 int cwslg_set_ft4_syncmin(cwslg_ctx *ctx, float syncmin);
 
 /* Intermediate products of the sync stage for parity tests: what = 0 symbol spectra [372][nbins] float,
  * 1 red, 2 red2 (float[1921], before normalisation), 3 jpeak, 4 jpeak2 (int32[1921]).  *n_items = items available.
- * FT4 channels: 0 = [122][1168] windowed spectra, 1 = savsm/sbase (first 1153 entries), 2 = sbase. */
+ * FT4 channels: 0 = [122][1168] windowed spectra, 1 = savsm/sbase (first 1153 entries), 2 = sbase,
+ * 5 = frame spectrum (complex float[36289]), 6 = unit-power baseband of candidate 0 (complex float[4032]). */
 int cwslg_sync_debug_fetch(cwslg_ctx *ctx, int ch_id, int what, void *dst, size_t cap_bytes, size_t *n_items, int *row_len);
 
 /* ---- introspection for bench / tests ---- */

@@ -94,6 +94,7 @@ def main():
     # ---- verification on the input the LAST (sub)step consumed
     laps = (args.warmup + args.steps) * sub          # commits of `part` samples since the ring was filled
     worst, mism, cand_checked, cand_equal = 0.0, 0, 0, 0
+    ft4_checked = ft4_equal = ft4_records = 0
     seen = {}
     for mode, rx, ch, f, tones, seed in chans:
         if seen.get(mode, 0) >= args.verify:
@@ -120,6 +121,12 @@ def main():
                 want = O.ft4_candidates(g["i16"], 200.0, 3000.0, 1.2, 200)
             cand_checked += 1
             cand_equal += int(list(got) == list(want) and len(want) > 0)
+            if mode == "FT4":                              # coherent stage: refined records of every candidate
+                ref4 = O.ft4_sync_all(g["i16"], want)
+                got4 = ctx.fetch_ft4_sync(ch)
+                ft4_checked += 1
+                ft4_equal += int(got4 == ref4)
+                ft4_records += len(ref4)
     out = {
         "config": args.config, "workload": ", ".join(f"{c} {m}" for m, c in plan) + f" slots, {window} IQ samples per step each, private streams, one MI355X",
         "value": msps, "unit": "Msamples/s", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps,
@@ -129,11 +136,12 @@ def main():
         "finalize_ms": st["finalize_ms"] / max(1, st["finalize_launches"]),
         "sync_ms_per_boundary": st["sync_ms"] / max(1, st["sync_launches"]), "sync_launches": st["sync_launches"],
         "verify": {"slots_checked": sum(seen.values()), "max_rel_err": worst, "tolerance": 1e-5, "int16_mismatches_1lsb_ties": mism,
-                   "candidate_lists_checked": cand_checked, "candidate_lists_identical": cand_equal},
+                   "candidate_lists_checked": cand_checked, "candidate_lists_identical": cand_equal,
+                   "ft4_refined_lists_checked": ft4_checked, "ft4_refined_lists_identical": ft4_equal, "ft4_refined_records": ft4_records},
         "hbm_resident_gb": n_slots * cap * 8 / 1e9, "setup_s": setup_s,
     }
     print(json.dumps(out))
-    ok = worst <= 1e-5 and cand_equal == cand_checked
+    ok = worst <= 1e-5 and cand_equal == cand_checked and ft4_equal == ft4_checked
     ctx.close()
     sys.exit(0 if ok else 2)
 
