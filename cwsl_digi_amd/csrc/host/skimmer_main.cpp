@@ -178,6 +178,7 @@ int main(int argc, char **argv)
     for (int g : groups) next_edge.emplace_back(g, cwslg_slot_clock_next(g, start_ms));
     std::vector<int16_t> pcm;
     std::vector<cwslg_candidate> cand(600);
+    std::vector<cwslg_ft4_sync> ref4(1800);
     uint64_t frames_total = 0, boundaries = 0;
 
     auto publish = [&](int group, uint64_t edge_ms) {
@@ -206,13 +207,26 @@ int main(int argc, char **argv)
                     std::fclose(cf);
                 }
             }
+            int nref = -1;
+            if (sync && !std::strcmp(c.spec.mode, "FT4")) {              // FT4: coherent refinement of every candidate
+                rc = cwslg_fetch_ft4_sync(ctx, c.id, ref4.data(), (int)ref4.size(), &nref);
+                if (rc == CWSLG_OK) {
+                    FILE *rf = std::fopen((std::string(stem) + ".sync4").c_str(), "w");
+                    if (rf) {
+                        for (int q = 0; q < nref; ++q)
+                            std::fprintf(rf, "%.9g %.9g %.9g %.9g %d %d %d %d\n", ref4[q].f0_hz, ref4[q].f1_hz, ref4[q].dt_s, ref4[q].sync,
+                                         ref4[q].ibest, ref4[q].idf, ref4[q].seg, ref4[q].cand);
+                        std::fclose(rf);
+                    }
+                } else if (rc != CWSLG_ERR_NO_FRAME) die("fetch_ft4_sync", rc);
+            }
             char app[64], opts[1024];
             const std::string target = route == 1 ? std::string("<shmem-key>") : wav;
             cwslg_decoder_command(c.spec.mode, route, cfg.numjt9threads, cfg.decodedepth, cfg.highest_decode_hz, cfg.wspr_cycles,
                                   c.spec.period_s, target.c_str(), app, sizeof app, opts, sizeof opts);
-            std::fprintf(log, "{\"t_start\": %" PRIu64 ", \"freq_hz\": %u, \"mode\": \"%s\", \"n_valid\": %zu, \"factor\": %.9g, \"candidates\": %d, "
+            std::fprintf(log, "{\"t_start\": %" PRIu64 ", \"freq_hz\": %u, \"mode\": \"%s\", \"n_valid\": %zu, \"factor\": %.9g, \"candidates\": %d, \"ft4_refined\": %d, "
                               "\"route\": \"%s\", \"wav\": \"%s\", \"app\": \"%s\", \"opts\": \"%s\"}\n",
-                         t0, c.spec.freq_hz, c.spec.mode, nv, factor, ncand, route == 1 ? "shmem" : "wavefile",
+                         t0, c.spec.freq_hz, c.spec.mode, nv, factor, ncand, nref, route == 1 ? "shmem" : "wavefile",
                          write_wav ? json_escape(wav).c_str() : "", app, json_escape(opts).c_str());
             ++c.frames; ++frames_total;
         }

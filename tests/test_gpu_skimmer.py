@@ -118,6 +118,13 @@ def test_skimmer_files_match_oracle(tmp_path, oracle):
             for g_, w_ in zip(got, want):
                 assert tuple(np.float32(x) for x in g_) == (np.float32(w_[3]), np.float32(w_[4]), np.float32(w_[2]))      # %.9g round-trips float32
             seen_cands += len(want)
+            if m == "FT4":                                                    # coherent refinement records
+                ref4 = oracle.ft4_sync_all(fr["i16"], want)
+                got4 = [l.split() for l in open(out_dir / f"{t0}_{f}_{m}.sync4")]
+                assert len(got4) == len(ref4) == rec["ft4_refined"]
+                for g_, w_ in zip(got4, ref4):
+                    assert tuple(np.float32(x) for x in g_[:4]) == tuple(np.float32(w_[k]) for k in ("f0_hz", "f1_hz", "dt_s", "sync"))
+                    assert [int(x) for x in g_[4:]] == [w_["ibest"], w_["idf"], w_["seg"], w_["cand"]]
     assert seen_cands > 0
 
 
