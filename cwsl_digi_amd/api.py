@@ -75,6 +75,11 @@ class Candidate(C.Structure):
                 ("freq_hz", C.c_float), ("dt_s", C.c_float)]
 
 
+class Spot(C.Structure):
+    _fields_ = [("snr_db", C.c_int32), ("dt_s", C.c_float), ("freq_hz", C.c_uint32), ("has_locator", C.c_int32),
+                ("call", C.c_char * 16), ("locator", C.c_char * 8), ("message", C.c_char * 64)]
+
+
 class Ft4Sync(C.Structure):
     _fields_ = [("f0_hz", C.c_float), ("f1_hz", C.c_float), ("dt_s", C.c_float), ("sync", C.c_float),
                 ("ibest", C.c_int32), ("idf", C.c_int32), ("seg", C.c_int32), ("cand", C.c_int32)]
@@ -99,7 +104,7 @@ ABI_SYMBOLS = [
     "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_write_wav", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
     "cwslg_enable_sync", "cwslg_fetch_candidates", "cwslg_set_ft4_syncmin", "cwslg_enable_ft4_coherent", "cwslg_fetch_ft4_sync", "cwslg_sync_debug_fetch", "cwslg_get_stats", "cwslg_reset_stats",
     "cwslg_set_timing", "cwslg_stream", "cwslg_channel_constants", "cwslg_phasor_checkpoint_stride", "cwslg_channel_phasor_checkpoints",
-    "cwslg_slot_clock_next", "cwslg_pool_sizing", "cwslg_find_band",
+    "cwslg_slot_clock_next", "cwslg_pool_sizing", "cwslg_find_band", "cwslg_parse_decode_line",
     "cwslg_decoder_block_bytes", "cwslg_decoder_block_field", "cwslg_fill_decoder_block", "cwslg_decoder_route", "cwslg_decoder_command",
 ]
 
@@ -166,11 +171,23 @@ def load_library(build_if_missing=True):
     L.cwslg_fill_decoder_block.argtypes = [vp, i32, vp, C.c_size_t, i32, i32, i32, C.POINTER(u64)]
     L.cwslg_decoder_route.argtypes = [C.c_char_p, i32]
     L.cwslg_decoder_command.argtypes = [C.c_char_p, i32, i32, i32, i32, i32, f32, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+    L.cwslg_parse_decode_line.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.POINTER(Spot)]
     L.cwslg_slot_clock_next.argtypes = [i32, u64]; L.cwslg_slot_clock_next.restype = u64
     L.cwslg_pool_sizing.argtypes = [C.POINTER(i32), f32, i32, C.POINTER(i32), C.POINTER(i32)]
     L.cwslg_find_band.argtypes = [C.POINTER(C.c_int64), C.POINTER(u32), i32, C.c_int64]
     _lib = L
     return L
+
+
+def parse_decode_line(mode, line, base_freq_hz):
+    """One jt9 stdout line -> dict(status 'ok'|'unhandled'|'skip', snr_db, dt_s, freq_hz, call, locator, message)
+    (OutputHandler.cpp:505-621, 924-1128)."""
+    sp = Spot()
+    rc = load_library().cwslg_parse_decode_line(mode.encode(), line.encode(), int(base_freq_hz), C.byref(sp))
+    if rc < 0:
+        raise CwslGpuError(rc, f"parse_decode_line({mode})")
+    return dict(status=("ok", "unhandled", "skip")[rc], snr_db=sp.snr_db, dt_s=sp.dt_s, freq_hz=sp.freq_hz,
+                call=sp.call.decode(), locator=sp.locator.decode() if sp.has_locator else None, message=sp.message.decode())
 
 
 def slot_clock_next(group, after_ms):

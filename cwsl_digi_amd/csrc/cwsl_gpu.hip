@@ -27,6 +27,7 @@
 #include "handoff.hpp"
 #include "host/slot_clock.hpp"
 #include "host/skimmer_config.hpp"
+#include "host/spot_parse.hpp"
 #include "sync_kernels.hpp"
 #include "ft4sync_kernels.hpp"
 
@@ -1120,6 +1121,13 @@ int cwslg_find_band(const int64_t *lo_hz, const uint32_t *fs_hz, int n_bands, in
 {
     if (!lo_hz || !fs_hz || n_bands < 0) return CWSLG_ERR_ARG;
     return cwslg::host::find_band(lo_hz, fs_hz, n_bands, f_hz);
+}
+
+int cwslg_parse_decode_line(const char *mode, const char *line, int64_t base_freq_hz, cwslg_spot *out)
+{
+    if (!mode || !line || !out) return CWSLG_ERR_ARG;
+    if (std::strcmp(mode, "FT8") != 0 && std::strcmp(mode, "FT4") != 0) return CWSLG_ERR_MODE;
+    return cwslg::host::parse_decode_line(mode, line, base_freq_hz, out);
 }
 
 // ---- downstream hand-off formats (layouts and rules in handoff.hpp) ----

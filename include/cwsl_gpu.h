@@ -173,6 +173,26 @@ int cwslg_pool_sizing(const int *counts, float decoderburden, int n_decoders, in
 /* findBand (CWSL_Utils.hpp:28-55): index of the first band with |f - L0| <= Fs/2, or -1. */
 int cwslg_find_band(const int64_t *lo_hz, const uint32_t *fs_hz, int n_bands, int64_t f_hz);
 
+/* ---- decoder stdout -> spot record, FT8/FT4 -----------------------------------------------
+ * One line of jt9's stdout ("HHMMSS snr  dt freq ~  message", fixed columns: OutputHandler.cpp:505-621) -> the
+ * arguments reporter->handle() would receive (message rules: OutputHandler.cpp:924-1128; call / locator checks
+ * :788-922, HamUtils.hpp:26-43).  base_freq_hz = the decoder's dial frequency (ItemToDecode::baseFreq).
+ * CWSLG_SPOT_OK: call (and locator if has_locator) identify the transmitting station; CWSLG_SPOT_UNHANDLED: a well
+ * formed line whose message the reference logs as "Message not handled"; CWSLG_SPOT_SKIP: not a decode line. */
+#define CWSLG_SPOT_OK         0
+#define CWSLG_SPOT_UNHANDLED  1
+#define CWSLG_SPOT_SKIP       2
+typedef struct {
+    int32_t  snr_db;
+    float    dt_s;
+    uint32_t freq_hz;          /* audio offset + base frequency, truncated like static_cast<uint32_t> */
+    int32_t  has_locator;
+    char     call[16];
+    char     locator[8];
+    char     message[64];      /* the message text, trimmed                                           */
+} cwslg_spot;
+int cwslg_parse_decode_line(const char *mode, const char *line, int64_t base_freq_hz, cwslg_spot *out);
+
 /* ---- decoder hand-off formats -------------------------------------------------------------
  * The block a stock jt9 (js8 = 0: dec_data_t, DecoderPool.hpp:58-108, "in sync with lib/jt9com.f90") or js8
  * (js8 = 1: dec_data_js8_t, :110-171) maps as shared memory.  cwslg_fill_decoder_block() does what

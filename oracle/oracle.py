@@ -99,6 +99,7 @@ def lib():
         L.orc_ft4_downsample.argtypes = [_f32p, C.c_float, _f32p]
         L.orc_ft4_sync4d.argtypes = [_f32p, C.c_int, C.c_int]; L.orc_ft4_sync4d.restype = C.c_float
         L.orc_ft4_search.argtypes = [_f32p, C.c_float, C.c_int, C.c_void_p, C.c_int]
+        L.orc_parse_decode_line.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_void_p]
         L.orc_clock_sim.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_int]
         L.orc_pool_sizing.argtypes = [C.POINTER(C.c_int), C.c_float, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_find_band.argtypes = [C.POINTER(C.c_int64), C.POINTER(C.c_uint32), C.c_int, C.c_int64]
@@ -423,6 +424,19 @@ def ft4_sync_all(frame_i16, cands):
         cd, _ = ft4_downsample(cx, np.float32(c[3]))
         out += ft4_search(cd, np.float32(c[3]), k)
     return out
+
+
+class _Spot(C.Structure):
+    _fields_ = [("snr_db", C.c_int32), ("dt_s", C.c_float), ("freq_hz", C.c_uint32), ("has_locator", C.c_int32),
+                ("call", C.c_char * 16), ("locator", C.c_char * 8), ("message", C.c_char * 64)]
+
+
+def parse_decode_line(mode, line, base_freq_hz):
+    """spot_oracle.c: one jt9 stdout line (OutputHandler.cpp:505-621, 924-1128)."""
+    sp = _Spot()
+    rc = lib().orc_parse_decode_line(mode.encode(), line.encode(), int(base_freq_hz), C.byref(sp))
+    return dict(status=("ok", "unhandled", "skip")[rc], snr_db=sp.snr_db, dt_s=sp.dt_s, freq_hz=sp.freq_hz,
+                call=sp.call.decode(), locator=sp.locator.decode() if sp.has_locator else None, message=sp.message.decode())
 
 
 # ---- host-service rules (host_oracle.c; CWSL_DIGI.cpp:174-451, 857-887; CWSL_Utils.hpp:28-55) ----
