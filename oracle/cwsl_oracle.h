@@ -17,7 +17,10 @@
  * itself: oracle/_ref/libcwsl_ref.so is the unmodified SSBD.hpp/LowPass.hpp
  * compiled in place, and tests/test_oracle_vs_ref.py + the committed
  * fixtures in tests/golden/ (made by tests/gen_golden.py from that build)
- * require bit-identical taps, tone, phasor trace and audio.
+ * require bit-identical taps, tone, phasor trace and audio.  The slot framing (orc_channel_*) is pinned the same
+ * way against Instance.cpp's call sequences replayed on the reference's own ring_buffer_t / sample_buffer_t
+ * containers (ring_buffer.h, decode_audio_buffer.h compile as they are): same drop decisions, epochs, sample
+ * counts and frames (tests/test_oracle_vs_ref.py::test_framing_matches_reference_containers).
  *
  * Build of record: gcc -std=c99 -O2 -ffp-contract=off (no -march=native,
  * no -ffast-math) -- the same floating-point contract as the reference

@@ -131,6 +131,13 @@ def ref():
         R.ref_build_lowpass.argtypes = [C.c_uint64, C.c_double, _f32p]
         R.ref_bench_cpu.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint64]
         R.ref_bench_cpu.restype = C.c_double
+        R.ref_inst_new.argtypes = [C.c_uint64, C.c_uint32, C.c_double, C.c_uint64]; R.ref_inst_new.restype = C.c_void_p
+        R.ref_inst_delete.argtypes = [C.c_void_p]
+        R.ref_inst_push.argtypes = [C.c_void_p, _f32p]
+        R.ref_inst_boundary.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        R.ref_mode_group.argtypes = [C.c_char_p]
+        R.ref_is_valid_locator.argtypes = [C.c_char_p]
+        R.ref_trim.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         _ref = R
     return _ref
 
@@ -189,6 +196,48 @@ class Demod:
         lib().orc_demod_run(C.byref(self.s), iq.view(np.float32), n, out,
                             tr.ctypes.data if trace else None)
         return (out, tr.view(np.complex64)) if trace else out
+
+
+class RefInstance:
+    """Instance's frame handling replayed on the reference's own ring_buffer_t / sample_buffer_t / SSBD (oracle/_ref)."""
+
+    def __init__(self, mode, fs, iq_len, demod_hz):
+        self.iq_len, self.frame_len = iq_len, frame_len(mode)
+        self.h = ref().ref_inst_new(fs, iq_len, float(demod_hz), self.frame_len)
+        if not self.h:
+            raise ValueError("ref_inst_new failed")
+
+    def close(self):
+        if getattr(self, "h", None):
+            ref().ref_inst_delete(self.h); self.h = None
+
+    __del__ = close
+
+    def push(self, iq_block):
+        iq_block = np.ascontiguousarray(iq_block, dtype=np.complex64)
+        assert iq_block.shape[0] == self.iq_len
+        return int(ref().ref_inst_push(self.h, iq_block.view(np.float32)))
+
+    def boundary(self, epoch_s):
+        """-> (emitted, t_start, samples_written, float32 frame before prepareAudio or None)."""
+        f32 = np.empty(self.frame_len, np.float32)
+        t0, nw = C.c_uint64(0), C.c_uint64(0)
+        got = ref().ref_inst_boundary(self.h, int(epoch_s), f32.ctypes.data, C.byref(t0), C.byref(nw))
+        return bool(got), int(t0.value), int(nw.value), (f32 if got else None)
+
+
+def ref_mode_group(mode):
+    return int(ref().ref_mode_group(mode.encode()))
+
+
+def ref_is_valid_locator(s):
+    return bool(ref().ref_is_valid_locator(s.encode()))
+
+
+def ref_trim(s):
+    out = C.create_string_buffer(len(s) + 8)
+    ref().ref_trim(s.encode(), out, len(s) + 8)
+    return out.value.decode()
 
 
 class RefDemod:

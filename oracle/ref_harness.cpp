@@ -24,9 +24,23 @@
 #include <thread>
 #include <chrono>
 
+#include <string>
+#include <memory>
+#include <atomic>
+#include <mutex>
+#include <condition_variable>
+#include <cctype>
+
 #define private public
 #include "SSBD.hpp"
 #undef private
+// further reference headers that are plain standard C++: the two-deep frame ring and its frames
+// (Instance.hpp:95 af_buffer), the slot-clock predicate groups, and the small text helpers of the output stage
+#include "ring_buffer.h"
+#include "decode_audio_buffer.h"
+#include "CWSL_DIGI_Types.hpp"
+#include "HamUtils.hpp"
+#include "StringUtils.hpp"
 
 extern "C" {
 
@@ -145,6 +159,93 @@ double ref_bench_cpu(int threads, int slots, uint64_t Fs, uint32_t iq_len, uint6
     const auto t1 = std::chrono::steady_clock::now();
     for (int r : rc) if (r) return -1.0;
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// ---- Instance framing replayed on the reference's OWN containers -------------------------------------------------
+// Instance.cpp itself needs <windows.h>; its frame handling is three short sequences of calls on ring_buffer_t /
+// sample_buffer_t / SSBD, transcribed here call for call (Instance.cpp:139-157 init, :203-227,251 boundary, :268-276
+// block).  What the containers and the demodulator DO with those calls is the compiled reference.
+struct RefInstance {
+    ring_buffer_t<sample_buffer_t<float>> af_buffer;
+    std::unique_ptr<SSBD<float>> ssbd;
+    uint64_t Fs; uint32_t iq_len; double demodFreq; size_t decRatio, ssbd_in_size;
+};
+
+void* ref_inst_new(uint64_t Fs, uint32_t iq_len, double demod_hz, uint64_t frame_len)
+{
+    try {
+        auto* I = new RefInstance();
+        I->Fs = Fs; I->iq_len = iq_len; I->demodFreq = demod_hz; I->decRatio = Fs / 12000;
+        if (!I->af_buffer.initialize(2)) { delete I; return nullptr; }                      // :143
+        for (size_t k = 0; k < I->af_buffer.size; ++k) {                                      // :152-157
+            I->af_buffer.recs[k].init(frame_len);
+            memset(I->af_buffer.recs[k].buf, 0, I->af_buffer.recs[k].byte_size());
+            I->af_buffer.recs[k].resetIndices();
+        }
+        I->ssbd = std::make_unique<SSBD<float>>(Fs, 6000, static_cast<float>(demod_hz), true);   // :187
+        I->ssbd_in_size = I->ssbd->GetInSize();
+        return I;
+    } catch (...) { return nullptr; }
+}
+void ref_inst_delete(void* h)
+{
+    auto* I = static_cast<RefInstance*>(h);
+    if (!I) return;
+    for (size_t k = 0; k < I->af_buffer.size; ++k) I->af_buffer.recs[k].deallocate();      // frames were malloc'ed by init()
+    delete I;
+}
+// one Receiver block (Instance.cpp:268-276): 1 consumed, 0 "af buffer full"
+int ref_inst_push(void* h, const float* iq_ri)
+{
+    auto* I = static_cast<RefInstance*>(h);
+    auto& af = I->af_buffer;
+    const std::complex<float>* xc = reinterpret_cast<const std::complex<float>*>(iq_ri);
+    if (af.recs[af.write_index].write_index + I->iq_len > af.recs[af.write_index].size - 1) return 0;
+    float* dest = af.recs[af.write_index].buf + af.recs[af.write_index].write_index;
+    for (size_t n = 0; n < I->iq_len; n += I->ssbd_in_size) I->ssbd->Iterate(xc + n, dest + n / I->decRatio);
+    af.recs[af.write_index].write_index += (I->iq_len / I->decRatio);
+    return 1;
+}
+// slot boundary (Instance.cpp:203-227, 251): 1 = frame handed on (copied to frame_out BEFORE prepareAudio), 0 = discarded
+int ref_inst_boundary(void* h, uint64_t epoch_s, float* frame_out, uint64_t* t_start, uint64_t* n_written)
+{
+    auto* I = static_cast<RefInstance*>(h);
+    auto& af = I->af_buffer;
+    auto idx_next = af.get_next_write_index();
+    memset(af.recs[idx_next].buf, 0, af.recs[af.write_index].byte_size());
+    af.recs[idx_next].reset();
+    af.recs[idx_next].startEpochTime = epoch_s;
+    af.inc_write_index();
+    auto& current = af.pop_ref();
+    const auto startTime = current.startEpochTime;
+    if (t_start) *t_start = startTime;
+    if (n_written) *n_written = current.write_index;
+    if (0 == startTime) return 0;                                                              // :224-227
+    if (frame_out) memcpy(frame_out, current.buf, current.byte_size());
+    I->ssbd = std::make_unique<SSBD<float>>(I->Fs, 6000, static_cast<float>(I->demodFreq), true);   // :251
+    return 1;
+}
+
+// slot-clock group of a mode through the reference's SyncPredicates::createPredicate (CWSL_DIGI_Types.hpp:83-134):
+// 0 ft8, 1 ft4, 2 q65_30, 3 s60, 4 s120, 5 s300, 6 s900, 7 s1800; -1 = "Unhandled mode"
+int ref_mode_group(const char* mode)
+{
+    try {
+        SyncPredicates P;
+        auto pred = P.createPredicate(mode);
+        const std::vector<std::shared_ptr<SyncPredicate>>* v[8] = {&P.ft8Preds, &P.ft4Preds, &P.q65_30Preds, &P.s60sPreds,
+                                                                    &P.s120sPreds, &P.s300sPreds, &P.s900sPreds, &P.s1800sPreds};
+        for (int g = 0; g < 8; ++g) if (!v[g]->empty()) return g;
+        return -2;
+    } catch (const std::exception&) { return -1; }
+}
+
+int ref_is_valid_locator(const char* s) { return isValidLocator(std::string(s)) ? 1 : 0; }   // HamUtils.hpp:26-43
+void ref_trim(const char* in, char* out, int cap)                                             // StringUtils.hpp:25-28
+{
+    std::string s(in);
+    trim(s);
+    std::strncpy(out, s.c_str(), (size_t)cap - 1); out[cap - 1] = 0;
 }
 
 } // extern "C"

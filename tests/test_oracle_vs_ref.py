@@ -46,3 +46,69 @@ def test_lowpass_design_matches(ref):
         ref.lib().orc_lowpass_design(order, bw, a)
         ref.ref().ref_build_lowpass(order, bw, b)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+# ---- slot framing: the oracle's Channel against Instance's sequences replayed on the reference's own containers ----
+@pytest.mark.parametrize("mode,fs,blk,f", [("FT4", 48000, 1024, 3000), ("FT8", 96000, 2048, -20000), ("FT4", 192000, 2048, 50000)])
+def test_framing_matches_reference_containers(ref, mode, fs, blk, f):
+    """Random schedules of blocks and boundaries, including over-full slots ("af buffer full"), empty slots and the
+    discarded first frame: same drop decisions, same epochs, same sample counts, bit-identical float frames."""
+    rng = np.random.default_rng(fs + blk)
+    oc = ref.Channel(mode, fs, blk, f)
+    ri = ref.RefInstance(mode, fs, blk, f)
+    dec = fs // 12000
+    cap_blocks = (oc.frame_len - 1) // (blk // dec)              # blocks a frame accepts before the guard trips
+    epoch = 1000
+    n_emit = n_drop = 0
+    for slot in range(6):
+        n_blocks = [cap_blocks // 3, 0, cap_blocks + 5, 1, cap_blocks, 7][slot]
+        iq = ref.synth_iq(100 + slot, max(1, n_blocks) * blk, fs, tones_hz=[f + 1500.0], amp=8000.0)
+        for k in range(n_blocks):
+            b = iq[k * blk:(k + 1) * blk]
+            took_o, took_r = oc.push(b), ri.push(b)
+            assert took_o == took_r
+            n_drop += 1 - took_r
+        epoch += int(rng.integers(1, 20))
+        fo = oc.boundary(epoch, want_f32=True)
+        emitted, t0, nw, fr = ri.boundary(epoch)
+        assert (fo is not None) == emitted
+        if emitted:
+            n_emit += 1
+            assert fo["t_start"] == t0
+            assert np.array_equal(fo["f32"].view(np.uint32), fr.view(np.uint32))
+    assert n_emit == 5 and n_drop >= 5                           # first frame discarded; the over-full slot dropped blocks
+
+
+def test_mode_groups_match_syncpredicates(ref):
+    import cwsl_digi_amd as P
+    modes = ["FT8", "JS8", "FT4", "WSPR", "Q65-30", "JT65", "FST4-60", "FST4-120", "FST4-300", "FST4-900", "FST4-1800",
+             "FST4W-120", "FST4W-300", "FST4W-900", "FST4W-1800"]
+    for m in modes:
+        g = ref.ref_mode_group(m)
+        assert g == P.group_of(m) == P.parse_decoder_line(f"14074000 {m}", 1.0)["group"], m
+    assert ref.ref_mode_group("PSK31") == -1
+    with pytest.raises(Exception):
+        P.parse_decoder_line("14074000 PSK31", 1.0)
+
+
+def test_locator_and_trim_helpers_match_reference(ref):
+    import random
+    import cwsl_digi_amd as P
+    rng = random.Random(5)
+    alphabet = "ABfn0199 -/x"
+    for _ in range(400):
+        loc = "".join(rng.choice(alphabet) for _ in range(rng.choice([3, 4, 4, 4, 5])))
+        if " " in loc:
+            continue
+        line = f"123045 -12  0.3 1234 ~  CQ K1ABC {loc}"
+        got = P.parse_decode_line("FT8", line, 0)
+        want = ref.parse_decode_line("FT8", line, 0)
+        assert got == want
+        if got["status"] == "ok" and got["call"] == "K1ABC":
+            assert (got["locator"] is not None) == ref.ref_is_valid_locator(loc), loc
+    for _ in range(200):
+        pad_l = "".join(rng.choice(" \t") for _ in range(rng.randrange(0, 4)))
+        pad_r = "".join(rng.choice(" \t\r\n") for _ in range(rng.randrange(0, 4)))
+        core = "123045 -12  0.3 1234 ~  CQ K1ABC FN42"
+        assert ref.ref_trim(pad_l + core + pad_r) == core
+        assert P.parse_decode_line("FT8", pad_l + core + pad_r, 0)["call"] == "K1ABC"
