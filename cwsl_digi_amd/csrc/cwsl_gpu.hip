@@ -149,6 +149,7 @@ struct cwslg_ctx {
     SyncConfig sync_cfg;
     SyncShared sync_shared;
     Ft4Tables ft4_tables{};
+    bool ft4_dft_valu = false;         // CWSLG_FT4_DFT=valu
 };
 
 namespace {
@@ -554,6 +555,7 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
     c->device = device_ordinal;
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *v = std::getenv("CWSLG_DEMOD_VARIANT")) c->demod_variant = std::atoi(v);
+    if (const char *v = std::getenv("CWSLG_FT4_DFT")) c->ft4_dft_valu = std::strcmp(v, "valu") == 0;
     if (const char *v = std::getenv("CWSLG_ITEM_ORDER")) c->order_override = std::atoi(v);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
     if (hipHostMalloc((void **)&c->h_stage, 2 * kStageHalf, hipHostMallocDefault) != hipSuccess) return CWSLG_ERR_NOMEM;

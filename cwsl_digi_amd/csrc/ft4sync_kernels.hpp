@@ -88,6 +88,50 @@ __global__ __launch_bounds__(256) void ft4_dft567_kernel(const Ft4Work *__restri
     }
 }
 
+// The same 567-point DFTs on the matrix cores.  Y[c][b] = sum_a W567^(ac) z[a][b] is a dense 567 x 567 by 567 x 64
+// complex product, and gfx950's f32 MFMA is bit for bit a k-ordered fmaf chain (cdna_hip_programming.md, 'FP32-input
+// MFMA'): v_mfma_f32_32x32x2_f32 with k0 = (wr, zr), k1 = (wi, -zi) performs exactly the restatement's
+//   yr = fmaf(zr, wr, yr); yr = fmaf(-zi, wi, yr)        and with k0 = (wi, zr), k1 = (wr, zi)
+//   yi = fmaf(zr, wi, yi); yi = fmaf(zi, wr, yi)
+// for a 32 (c) x 32 (b) tile per wave, two MFMAs per input row a.  Same bits as ft4_dft567_kernel at a third of the
+// time: the VALU version spends its issue slots on the twiddle lookups (one LDS read + index update per term).
+typedef float f4c_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void ft4_dft567_mfma_kernel(const Ft4Work *__restrict__ works, Ft4Tables tb)
+{
+    __shared__ float2 s_w[F4C_NA];
+    const Ft4Work *w = works + blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int k = tid; k < F4C_NA; k += 256) s_w[k] = tb.w567[k];
+    __syncthreads();
+    const int tile = (int)blockIdx.x * 4 + wv;                 // 36 tiles per channel: 18 row tiles x 2 column tiles
+    const int c0 = 32 * (tile >> 1), b0 = 32 * (tile & 1);     // (nine workgroups per channel: every SIMD gets the same load)
+    const int i = lane & 31, h = lane >> 5;
+    const int c = (c0 + i < F4C_NA) ? c0 + i : 0;             // rows past 566 compute row 0 and are not stored
+    const int b = b0 + i;
+    const CWSLG_GLOBAL int *fr = as_global(reinterpret_cast<const int *>(w->frame)) + b;   // two int16 = one packed complex input
+    f4c_f32x16 yr, yi;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { yr[v] = 0.f; yi[v] = 0.f; }
+    int idx = 0;
+#pragma unroll 4
+    for (int a = 0; a < F4C_NA; ++a) {
+        const int zv = fr[64 * a];
+        const float zr = (float)(short)(zv & 0xFFFF), zi = (float)(zv >> 16);
+        const float2 t = s_w[idx];
+        idx += c;
+        if (idx >= F4C_NA) idx -= F4C_NA;
+        // lane (i, h): A[i][k = h], B[k = h][j = i]
+        yr = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? t.y : t.x, h ? -zi : zr, yr, 0, 0, 0);
+        yi = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? t.x : t.y, h ? zi : zr, yi, 0, 0, 0);
+    }
+    // D[row][col]: col = lane & 31 (b), row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5) (c)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int cr = c0 + (v & 3) + 8 * (v >> 2) + 4 * h;
+        if (cr < F4C_NA) w->y[cr * 64 + rev6(b)] = cmul_f(make_float2(yr[v], yi[v]), tb.wn2[b * cr]);
+    }
+}
+
 // one 64-point radix-2 DIT stage on two rows held by one wave: lane -> (row lane >> 5, butterfly lane & 31)
 template <bool INVERSE>
 __device__ __forceinline__ void fft64_stage(float2 *r0, float2 *r1, const float2 *s_w64, int len, int lane)
