@@ -203,6 +203,14 @@ __device__ __forceinline__ int reduce_lanes(float (&acc)[16], int k)
     return rbase;
 }
 
+// Frame peak: max|audio| as float bits, one word per channel, one fire-and-forget atomicMax per wave.  (Measured: compiled
+// out, the tile kernel gains 0.07 ms of 2.75; guarding the atomic with a device-scope load of the word -- to skip it
+// when it cannot raise the maximum -- costs more than it saves, 2.85 ms: the load's round trip lands on the workgroup's tail.)
+__device__ __forceinline__ void publish_peak(unsigned *peak, float mx)
+{
+    if (mx > 0.0f) atomicMax(peak, __float_as_uint(mx));
+}
+
 // ---------------------------------------------------------------------------------------------
 template <int D, int T>
 struct DemodGeom {
@@ -563,7 +571,7 @@ __global__ __launch_bounds__(NT, 4) void demod_kernel(const ChanWork *__restrict
             }
 #pragma unroll
             for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-            if (lane == 0 && mx > 0.0f) atomicMax(cur.peak, __float_as_uint(mx));
+            if (lane == 0) publish_peak(cur.peak, mx);
         }
         STAMP(6);
         }   // work in this iteration
@@ -587,6 +595,236 @@ __global__ __launch_bounds__(NT, 4) void demod_kernel(const ChanWork *__restrict
         STAMP(0); STAMP(7); STAMP(1);
 #endif
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// demod_mfma1p_kernel (D = 16; measured alternative, CWSLG_DEMOD_VARIANT=4..7 = workgroups per CU the registers are capped
+// for): the tile kernel with its FIR on the matrix cores and ONE plane resident at a time.
+// Per plane the polyphase FIR  out[p] = sum_{u<32} sum_{w<16} X[u][p+w] H[u][w]  splits into a dense product over the 32
+// branches,  Dm[q][w] = sum_u X[u][q] H[u][w]   (143 columns q x 16 taps w, K = 32: v_mfma_f32_16x16x4_f32, A = 16 columns of
+// four branches straight out of the pair-row LDS image, B = four rows of the 32 x 16 tap matrix held in 8 registers), and a
+// diagonal sum  out[p] = sum_w Dm[p+w][w]  (16 conflict-free LDS reads per output).  89 % of the MFMA work is useful (143 x 16 x
+// 32 against 128 x 512 products per plane); the 544 FIR v_fma per wave, their DPP reduction and the 16-tap register file
+// leave the VALU (474 instead of ~950 VALU instructions per wave).  The tone-mixed samples stay in the load registers: the
+// Re plane is written and multiplied, then the Im plane reuses the same LDS -- 21 KB instead of 39.7 KB per workgroup, six
+// workgroups per CU instead of four.  Accumulation order differs from demod_kernel's (branches first, then taps): same
+// tolerance class (4.6e-7 of frame peak against the reference-order arithmetic).
+// Result: 2.71 ms against demod_kernel's 2.72 ms on the same box -- half the VALU work and 1.5x the occupancy buy nothing.
+// With the MFMAs compiled out (mix, LDS traffic, barriers, diagonal sums all still there) the kernel runs at the memory
+// floor of ring_probe_kernel (2.10 ms); the MFMAs add back 0.7 ms = their own pipe time (144 x 32 cycles per tile): the FIR's
+// execution time, on either pipe, is what sits on top of the HBM floor.
+template <int T, int NT, int WGS>
+__global__ __launch_bounds__(NT, WGS) void demod_mfma1p_kernel(const ChanWork *__restrict__ works,
+                                                               const float *__restrict__ taps,
+                                                               int tiles_x, int n_ch)
+{
+    constexpr int D = 16;
+    using Geo = DemodGeom<D, T>;
+    constexpr int G = Geo::G;
+    constexpr int PR = Geo::PR;
+    constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
+    constexpr int NRB = (T / 2 + 15 + 15) / 16;          // 9 row blocks of 16 columns per plane
+    constexpr int PPW = (NRB + NT / 64 - 1) / (NT / 64);     // row blocks per wave and plane: 3 (wave 0) / 2
+    constexpr int PW = T / 2 + 17;                       // pitch of the product image [w][q]
+    static_assert(T == 256 && NT == 256 && 2 * 16 * PW <= Geo::PLANE_FLOATS, "geometry");
+
+    __shared__ __attribute__((aligned(16))) float s_plane[Geo::PLANE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float s_aux[Geo::AUX_FLOATS];
+    float2 *s_phase = reinterpret_cast<float2 *>(s_aux);
+
+    const int total = (tiles_x < 0 ? -tiles_x : tiles_x) * n_ch;
+    const int per_xcd = (total + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= min(((int)(blockIdx.x & 7) + 1) * per_xcd, total)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    TileCtx<D, T> cur;
+    int ich, itile;
+    item_to_ch_tile(item, tiles_x, n_ch, ich, itile);
+    decode_item<D, T>(works + ich, itile, cur);
+    v4f xs[NIT];
+    float2 ck;
+    v4f tn;
+    issue_tile_loads<D, T, NT>(cur, tid, xs, ck, tn);
+    float hb[8];                                          // B operand: H[4 ks + (lane >> 4)][lane & 15]
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) hb[ks] = taps[G * (lane & 15) + 4 * ks + (lane >> 4)];
+
+    const int r0 = 2 * tid;
+    float *p0 = s_plane + ((r0 % G) >> 1) * PR + 2 * (r0 / G);
+    const int rel1 = r0 - D + 2 * NT;
+    float *p1 = s_plane + ((rel1 % G) >> 1) * PR + 2 * (rel1 / G - (2 * NT) / G);      // the same storage, plane-1 addressing
+    constexpr int WSTEP = (2 * NT) / G;
+
+    {   // ---- phase 0: bit-exact phasor for the tile's T+31 blocks
+        const int cidx = cur.ck_first + tid;
+        if (tid < Geo::NCK && cidx >= 0) {
+            float2 p = ck;
+            const int pbase = cur.pb0 + kCk * tid;
+#pragma unroll
+            for (int s = 0; s < kCk; ++s) {
+                const int pb = pbase + s;
+                if (pb >= 0 && pb < Geo::NBLK) s_phase[pb] = p;
+                p = cmul_exact(p, cur.inc);
+            }
+        }
+    }
+    lds_barrier();
+    if (cur.n_out == 0) return;
+    const int fv = cur.first_valid;
+    // A-operand / product addresses of this wave's row blocks (the same for both planes)
+    const float *pa[PPW];
+    float *pd[PPW];
+    bool on[PPW];
+    {
+        const int wvu = __builtin_amdgcn_readfirstlane(wv);
+        const int q = lane & 15, kk = lane >> 4;
+        const int la = (kk >> 1) * PR + (kk & 1) + 2 * q;
+        const int ld = (lane & 15) * PW + 4 * (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int rb0 = wvu + (NT / 64) * i;
+            on[i] = rb0 < NRB;
+            const int rb = on[i] ? rb0 : 0;                 // a wave without a third block repeats block 0 and drops it
+            pa[i] = s_plane + 32 * rb + la;
+            pd[i] = s_plane + 16 * rb + ld;
+        }
+    }
+    // ---- phase 1a: tone mix (kept in the load registers), Re part -> the plane
+    {
+        const float2 tn0 = make_float2(tn.x, tn.y), tn1 = make_float2(tn.z, tn.w);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = 2 * tid + it * 2 * NT;
+            int blk = (2 * tid) / D + it * (2 * NT / D);
+            if (blk > Geo::NBLK - 1) blk = Geo::NBLK - 1;
+            const float2 ph = s_phase[blk];
+            const v4f x = xs[it];
+            v4f m;
+            m.x = __builtin_fmaf(x.x, tn0.x, -(x.y * tn0.y));
+            m.y = __builtin_fmaf(x.x, tn0.y, x.y * tn0.x);
+            m.z = __builtin_fmaf(x.z, tn1.x, -(x.w * tn1.y));
+            m.w = __builtin_fmaf(x.z, tn1.y, x.w * tn1.x);
+            xs[it] = m;
+            float y0r = __builtin_fmaf(m.x, ph.x, -(m.y * ph.y));
+            float y1r = __builtin_fmaf(m.z, ph.x, -(m.w * ph.y));
+            if (fv != 0) { if (r < fv) { y0r = 0.f; y1r = 0.f; } }
+            const bool in0 = (it < NIT - 1) || (r < G * (T / 2 + 15));
+            if (in0) *reinterpret_cast<float2 *>(p0 + 2 * it * WSTEP) = make_float2(y0r, y1r);
+        }
+    }
+    lds_barrier();
+    v4f acc0[PPW], acc1[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) { acc0[i] = v4f{0.f, 0.f, 0.f, 0.f}; acc1[i] = v4f{0.f, 0.f, 0.f, 0.f}; }
+    {   // all A operands first (24 LDS reads in flight), then the MFMA stream: a read issued right before its MFMA
+        // exposes the LDS latency 24 times per plane
+        float av[8][PPW];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) av[ks][i] = pa[i][2 * PR * ks];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) acc0[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks][i], hb[ks], acc0[i], 0, 0, 0);
+    }
+    lds_barrier();                                        // the Re plane has been consumed
+    // ---- phase 1b: Im part -> the same storage (plane-1 alignment: relative sample r - D)
+    {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = 2 * tid + it * 2 * NT;
+            int blk = (2 * tid) / D + it * (2 * NT / D);
+            if (blk > Geo::NBLK - 1) blk = Geo::NBLK - 1;
+            const float2 ph = s_phase[blk];
+            const v4f m = xs[it];
+            float y0i = __builtin_fmaf(m.x, ph.y, m.y * ph.x);
+            float y1i = __builtin_fmaf(m.z, ph.y, m.w * ph.x);
+            if (fv != 0) { if (r < fv) { y0i = 0.f; y1i = 0.f; } }
+            const bool in1 = (it > 0) ? ((it < NIT - 1) || (r < Geo::NSAMP)) : (r >= D);
+            if (in1) *reinterpret_cast<float2 *>(p1 + 2 * it * WSTEP) = make_float2(y0i, y1i);
+        }
+    }
+    lds_barrier();
+    {
+        float av[8][PPW];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) av[ks][i] = pa[i][2 * PR * ks];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) acc1[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks][i], hb[ks], acc1[i], 0, 0, 0);
+    }
+    lds_barrier();                                        // the Im plane has been consumed; s_phase is no longer needed either
+    // ---- products -> LDS as [plane][w][q] over the plane storage, then the diagonal sums
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+        if (on[i]) {
+            pd[i][0] = acc0[i].x; pd[i][1] = acc0[i].y; pd[i][2] = acc0[i].z; pd[i][3] = acc0[i].w;
+            float *d1 = pd[i] + 16 * PW;
+            d1[0] = acc1[i].x; d1[1] = acc1[i].y; d1[2] = acc1[i].z; d1[3] = acc1[i].w;
+        }
+    lds_barrier();
+    {
+        const int pl = tid >> 7, p = tid & 127;
+        const float *src = s_plane + pl * 16 * PW + p;
+        float sum = 0.0f;
+#pragma unroll
+        for (int wq = 0; wq < 16; ++wq) sum = sum + src[wq * (PW + 1)];
+        const float sgn_plane = pl ? -cur.sign : 1.0f;
+        const float sg = (p & 1) ? -sgn_plane : sgn_plane;
+        s_aux[2 * p + pl] = sg * sum;
+    }
+    lds_barrier();
+    {
+        CWSLG_GLOBAL float *out = as_global_rw(cur.out) + (size_t)cur.tile * T;
+        float mx = 0.0f;
+        for (int o = tid; o < cur.n_out; o += NT) {
+            const float v = s_aux[o];
+            out[o] = v;
+            mx = fmaxf(mx, fabsf(v));
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        if (lane == 0) publish_peak(cur.peak, mx);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ring_probe_kernel (diagnostic, CWSLG_DEMOD_VARIANT=9): the tile kernel's memory traffic without its arithmetic -- same
+// work-item order, same descriptor decode, same loads (IQ tile, checkpoint, tone), same 1 KB output row per tile; the
+// loaded values are only summed.  Its time is the floor the memory system sets for this access pattern.
+template <int D, int T, int NT, int FLAVOUR>
+__global__ __launch_bounds__(NT, 4) void ring_probe_kernel(const ChanWork *__restrict__ works, const float *__restrict__ taps,
+                                                           int tiles_x, int n_ch)
+{
+    using Geo = DemodGeom<D, T>;
+    // FLAVOUR 1: + the per-wave atomicMax on the channel's peak word; 2: + the tile kernel's LDS footprint (4 workgroups per CU)
+    __shared__ float s_pad[(FLAVOUR == 2) ? 9900 : 1];
+    if (FLAVOUR == 2) s_pad[threadIdx.x] = 0.f;
+    constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
+    const int total = (tiles_x < 0 ? -tiles_x : tiles_x) * n_ch;
+    const int per_xcd = (total + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= min(((int)(blockIdx.x & 7) + 1) * per_xcd, total)) return;
+    const int tid = threadIdx.x;
+    TileCtx<D, T> cur;
+    int ich, itile;
+    item_to_ch_tile(item, tiles_x, n_ch, ich, itile);
+    decode_item<D, T>(works + ich, itile, cur);
+    if (cur.n_out == 0) return;
+    v4f xs[NIT];
+    float2 ck;
+    v4f tn;
+    issue_tile_loads<D, T, NT>(cur, tid, xs, ck, tn);
+    float s = ck.x + tn.x + taps[tid & 15];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) s += xs[it].x + xs[it].y + xs[it].z + xs[it].w;
+    if (FLAVOUR == 2) s += s_pad[(threadIdx.x * 7) % 9900];
+    if (tid < cur.n_out) as_global_rw(cur.out)[(size_t)cur.tile * T + tid] = s;
+    if (FLAVOUR == 1 && (tid & 63) == 0) publish_peak(cur.peak, fabsf(s));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -688,7 +926,7 @@ __global__ __launch_bounds__(NT) void demod_exact_kernel(const ChanWork *__restr
         float mx = fabsf(v);
 #pragma unroll
         for (int msk = 32; msk >= 1; msk >>= 1) mx = fmaxf(mx, __shfl_xor(mx, msk, 64));
-        if ((tid & 63) == 0 && mx > 0.0f) atomicMax(cur.peak, __float_as_uint(mx));
+        if ((tid & 63) == 0) publish_peak(cur.peak, mx);
     }
 }
 
