@@ -121,7 +121,8 @@ struct cwslg_ctx {
     int cu_count = 256;
     int order_override = 0;            // CWSLG_ITEM_ORDER=1 channel-major, 2 tile-major (A/B); 0 = by topology
     bool exact = false;                // cwslg_set_exact: reference-order arithmetic (bit-exact, slower)
-    int demod_variant = 0;             // 0 = one workgroup per tile (default), 1 = persistent + prefetch (CWSLG_DEMOD_VARIANT=1)
+    int demod_variant = 0;             // CWSLG_DEMOD_VARIANT: 0 = one workgroup per tile (default); measured alternatives: 1 persistent +
+                                       // prefetch, 2 persistent loop, 4..7 FIR on the matrix cores (192 kHz); 9..11 memory-traffic probe
     hipStream_t stream = nullptr;
     std::string last_error;
     float scale_ft = 0.90f, scale_wspr = 0.20f;    // CWSL_DIGI.cpp:100-101
@@ -569,7 +570,7 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return CWSLG_ERR_NO_DEVICE;
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return CWSLG_ERR_NO_DEVICE;   // code object is gfx950-only
-    std::unique_ptr<cwslg_ctx> c(new cwslg_ctx);
+    std::unique_ptr<cwslg_ctx, void (*)(cwslg_ctx *)> c(new cwslg_ctx, cwslg_destroy);   // a failed create releases what it made
     c->device = device_ordinal;
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *v = std::getenv("CWSLG_DEMOD_VARIANT")) c->demod_variant = std::atoi(v);
@@ -596,7 +597,7 @@ void cwslg_destroy(cwslg_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    if (c->stream) hipStreamSynchronize(c->stream);
     for (Channel &ch : c->chans) {
         if (ch.d_block) hipFree(ch.d_block);
         sync_free_channel(ch.syncbuf);
@@ -614,9 +615,9 @@ void cwslg_destroy(cwslg_ctx *c)
     sync_free_shared(c->sync_shared);
     if (c->d_sincos) hipFree(c->d_sincos);
     if (c->h_stage) hipHostFree(c->h_stage);
-    hipEventDestroy(c->stage_ev[0]);
-    hipEventDestroy(c->stage_ev[1]);
-    hipStreamDestroy(c->stream);
+    if (c->stage_ev[0]) hipEventDestroy(c->stage_ev[0]);
+    if (c->stage_ev[1]) hipEventDestroy(c->stage_ev[1]);
+    if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
