@@ -411,42 +411,67 @@ __device__ __forceinline__ float key_value(unsigned long long k)
     return __uint_as_float(u);
 }
 
-// sync2d(i, j) for one bin (band row rr) and one lag; s_c0 holds the bin's 7-tone sums.
-__device__ __forceinline__ float costas_sync(const float (*s_s)[376], const float *s_c0, int rr, int j)
+// sync2d(i, j) and sync2d(i, j + 1) for one bin (band row rr): two adjacent lags per lane.  The LDS images are indexed by
+// the 1-based symbol step m itself (column 0 unused), so the pair's operands (m, m + 1) with m = j + 12 + 4n (+144, +288)
+// even-aligned are ONE 8-byte read: half the LDS instructions of a lag-per-read search and ds_read_b64's 256 B/clk instead
+// of ds_read_b32's 128.  A term the restatement skips (m < 1 or m > NHSYM) is read from a clamped address and replaced by
+// +0.0: adding +0.0 to a non-negative float sum is exact, so the sums are the restatement's bit for bit.
+struct SyncPair { float a, b; };
+__device__ __forceinline__ SyncPair costas_sync2(const float (*s_s)[376], const float *s_c0, int rr, int j)
 {
     const int icos[7] = {3, 1, 4, 0, 6, 5, 2};
-    float ta = 0, tbv = 0, tc = 0, t0a = 0, t0b = 0, t0c = 0;
+    float ta0 = 0, tb0 = 0, tc0 = 0, ua0 = 0, ub0 = 0, uc0 = 0;      // lag j:     t sums, t0 sums
+    float ta1 = 0, tb1 = 0, tc1 = 0, ua1 = 0, ub1 = 0, uc1 = 0;      // lag j + 1
 #pragma unroll
     for (int n = 0; n < 7; ++n) {
-        const int m = j + 12 + 4 * n;                  // 1-based symbol-step index
-        const int row = rr + 2 * icos[n];
-        if (m >= 1 && m <= FT8_NHSYM) { ta = ta + s_s[row][m - 1]; t0a = t0a + s_c0[m - 1]; }
-        { const int mb = m + 144; tbv = tbv + s_s[row][mb - 1]; t0b = t0b + s_c0[mb - 1]; }
-        if (m + 288 <= FT8_NHSYM) { const int mc = m + 288; tc = tc + s_s[row][mc - 1]; t0c = t0c + s_c0[mc - 1]; }
+        const int m = j + 12 + 4 * n;                  // even; lag j + 1 uses m + 1
+        const float *row = s_s[rr + 2 * icos[n]];
+        {   // block a: valid iff 1 <= m <= NHSYM
+            const int mc = (m < 0) ? 0 : m;
+            const float2 v = *reinterpret_cast<const float2 *>(row + mc), c = *reinterpret_cast<const float2 *>(s_c0 + mc);
+            const bool ok0 = m >= 1, ok1 = m + 1 >= 1;                // m + 1 <= 62 + 12 + 24 + 1 < NHSYM always
+            ta0 = ta0 + (ok0 ? v.x : 0.0f); ua0 = ua0 + (ok0 ? c.x : 0.0f);
+            ta1 = ta1 + (ok1 ? v.y : 0.0f); ua1 = ua1 + (ok1 ? c.y : 0.0f);
+        }
+        {   // block b: always inside the frame
+            const float2 v = *reinterpret_cast<const float2 *>(row + m + 144), c = *reinterpret_cast<const float2 *>(s_c0 + m + 144);
+            tb0 = tb0 + v.x; ub0 = ub0 + c.x;
+            tb1 = tb1 + v.y; ub1 = ub1 + c.y;
+        }
+        {   // block c: valid iff m + 288 <= NHSYM
+            const int mm = m + 288, mc = (mm > 374) ? 374 : mm;
+            const float2 v = *reinterpret_cast<const float2 *>(row + mc), c = *reinterpret_cast<const float2 *>(s_c0 + mc);
+            const bool ok0 = mm <= FT8_NHSYM, ok1 = mm + 1 <= FT8_NHSYM;
+            tc0 = tc0 + (ok0 ? v.x : 0.0f); uc0 = uc0 + (ok0 ? c.x : 0.0f);
+            tc1 = tc1 + (ok1 ? v.y : 0.0f); uc1 = uc1 + (ok1 ? c.y : 0.0f);
+        }
     }
-    float t = ta + tbv + tc;
-    float t0 = t0a + t0b + t0c;
-    t0 = (t0 - t) / 6.0f;
-    const float sync_abc = t / t0;
-    t = tbv + tc;
-    t0 = t0b + t0c;
-    t0 = (t0 - t) / 6.0f;
-    const float sync_bc = t / t0;
-    float sy = (sync_abc > sync_bc) ? sync_abc : sync_bc;
-    if (!(sy == sy)) sy = 0.0f;                        // 0/0 on all-zero windows: defined as 0 (as the oracle)
-    return sy;
+    auto finish = [](float ta, float tb, float tc, float t0a, float t0b, float t0c) {
+        float t = ta + tb + tc;
+        float t0 = t0a + t0b + t0c;
+        t0 = (t0 - t) / 6.0f;
+        const float sync_abc = t / t0;
+        t = tb + tc;
+        t0 = t0b + t0c;
+        t0 = (t0 - t) / 6.0f;
+        const float sync_bc = t / t0;
+        float sy = (sync_abc > sync_bc) ? sync_abc : sync_bc;
+        if (!(sy == sy)) sy = 0.0f;                    // 0/0 on all-zero windows: defined as 0 (as the oracle)
+        return sy;
+    };
+    return SyncPair{finish(ta0, tb0, tc0, ua0, ub0, uc0), finish(ta1, tb1, tc1, ua1, ub1, uc1)};
 }
 
 constexpr int SYNC2D_NT = 512;          // 8 waves: one bin per wave at a time, 4 bins per wave per band
 __global__ __launch_bounds__(SYNC2D_NT) void ft8_sync2d_kernel(const SyncWork *__restrict__ works, int ia, int ib, int nbins)
 {
     constexpr int ROWS = SYNC_BAND + 12, PITCH = 376;
-    __shared__ float s_s[ROWS][PITCH];
-    __shared__ float s_c0[SYNC2D_NT / 64][PITCH];
+    __shared__ __attribute__((aligned(16))) float s_s[ROWS][PITCH];              // s_s[r][m] = s(i0 + r, m), m = 1..NHSYM
+    __shared__ __attribute__((aligned(16))) float s_c0[SYNC2D_NT / 64][PITCH];
     const SyncWork *w = works + blockIdx.y;
     const int i0 = ia + blockIdx.x * SYNC_BAND;
     const int tid = threadIdx.x;
-    // stage the band: s_s[r][m-1] = s(i0+r, m); loads batched 16 deep so their latencies overlap
+    // stage the band; loads batched 16 deep so their latencies overlap
     {
         const float *sp = w->spectra;
         constexpr int TOTAL = ROWS * FT8_NHSYM;            // 16368
@@ -463,9 +488,10 @@ __global__ __launch_bounds__(SYNC2D_NT) void ft8_sync2d_kernel(const SyncWork *_
             for (int q = 0; q < 16; ++q) {
                 const int e = e0 + q * SYNC2D_NT + tid;
                 const int m = e / ROWS, r = e - m * ROWS;
-                if (e < TOTAL) s_s[r][m] = v[q];
+                if (e < TOTAL) s_s[r][m + 1] = v[q];
             }
         }
+        if (tid < ROWS) { s_s[tid][0] = 0.0f; s_s[tid][373] = 0.0f; s_s[tid][374] = 0.0f; s_s[tid][375] = 0.0f; }
     }
     __syncthreads();
 
@@ -475,27 +501,31 @@ __global__ __launch_bounds__(SYNC2D_NT) void ft8_sync2d_kernel(const SyncWork *_
     for (int rr = wv; rr < SYNC_BAND; rr += SYNC2D_NT / 64) {
         const int bin = i0 + rr;
         if (bin > ib) break;                            // wave-uniform
-        // 7-tone sums of this bin for every symbol step (sequential k, as the restatement)
-        for (int m = lane; m < FT8_NHSYM; m += 64) {
-            float acc = 0.0f;
+        // 7-tone sums of this bin for every symbol step (sequential k, as the restatement), two steps per lane and read
+        for (int mp = lane; mp < 188; mp += 64) {       // columns (2 mp, 2 mp + 1): 0..375
+            float2 acc = make_float2(0.0f, 0.0f);
 #pragma unroll
-            for (int k = 0; k < 7; ++k) acc = acc + s_s[rr + 2 * k][m];
-            c0[m] = acc;
+            for (int k = 0; k < 7; ++k) {
+                const float2 v = *reinterpret_cast<const float2 *>(&s_s[rr + 2 * k][2 * mp]);
+                acc.x = acc.x + v.x;
+                acc.y = acc.y + v.y;
+            }
+            *reinterpret_cast<float2 *>(c0 + 2 * mp) = acc;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // lags: lane -> j = lane - 62 (lags -62..1) and j = lane + 2 (lags 2..62, lanes 0..60)
-        const int ja = lane - FT8_JZ, jb = lane + 2;
-        const float sa = costas_sync(s_s, c0, rr, ja);
-        const bool okb = jb <= FT8_JZ;
-        const float sb = okb ? costas_sync(s_s, c0, rr, jb) : 0.0f;
-        const unsigned long long ka = sync_key(sa, ja + FT8_JZ);
-        const unsigned long long kb = okb ? sync_key(sb, jb + FT8_JZ) : 0ull;
+        // lags: lane -> the pair (j, j + 1), j = 2 lane - 62: -62 .. 62 in lanes 0..62 (the pair's second lag 63 does not exist)
+        const int j = 2 * lane - FT8_JZ;
+        const bool ok0 = j <= FT8_JZ, ok1 = j + 1 <= FT8_JZ;
+        SyncPair sy = SyncPair{0.0f, 0.0f};
+        if (ok0) sy = costas_sync2(s_s, c0, rr, j);
+        const unsigned long long ka = ok0 ? sync_key(sy.a, j + FT8_JZ) : 0ull;
+        const unsigned long long kb = ok1 ? sync_key(sy.b, j + 1 + FT8_JZ) : 0ull;
         unsigned long long k2 = (kb > ka) ? kb : ka;
         unsigned long long k1 = 0ull;
-        if (ja >= -10 && ja <= 10) k1 = ka;
-        if (okb && jb <= 10 && kb > k1) k1 = kb;
+        if (ok0 && j >= -10 && j <= 10) k1 = ka;
+        if (ok1 && j + 1 >= -10 && j + 1 <= 10 && kb > k1) k1 = kb;
         k2 = wave_max_u64(k2);
         k1 = wave_max_u64(k1);
         if (lane == 0) {
