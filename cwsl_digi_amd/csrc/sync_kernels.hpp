@@ -546,11 +546,12 @@ __device__ __forceinline__ bool key_less(float va, int ia_, float vb, int ib_)
     return ia_ < ib_;
 }
 
-__device__ void bitonic_sort_2048(float *kv, int *ki, int tid)
+// n = 1024 or 2048 keys (power of two >= the number of real keys; the padding sorts to the end either way)
+__device__ void bitonic_sort_n(float *kv, int *ki, int n, int tid)
 {
-    for (int size = 2; size <= 2048; size <<= 1) {
+    for (int size = 2; size <= n; size <<= 1) {
         for (int stride = size >> 1; stride >= 1; stride >>= 1) {
-            for (int t = tid; t < 1024; t += 256) {
+            for (int t = tid; t < n / 2; t += 256) {
                 const int lo = 2 * t - (t & (stride - 1));
                 const int hi = lo + stride;
                 const bool up = (lo & size) == 0;
@@ -590,17 +591,18 @@ __global__ __launch_bounds__(256) void ft8_candidates_kernel(const SyncWork *__r
     for (int i = tid; i < FT8_NH1 + 2; i += 256) { s_first[i] = -1; s_second[i] = -1; }
     const int npct = (int)lroundf(0.40f * (float)iz);
     const int lim = min(SYNC_MAXPRE, iz);
+    const int nsort = (iz <= 1024) ? 1024 : 2048;       // 200..3000 Hz is 897 bins: the smaller network (55 of 66 stages, half the pairs)
     __syncthreads();
     // --- percentile of red2
-    for (int k = tid; k < 2048; k += 256) { s_kv[k] = (k < iz) ? s_red2[ia + k] : __builtin_huge_valf(); s_ki[k] = (k < iz) ? ia + k : 0x7fffffff; }
+    for (int k = tid; k < nsort; k += 256) { s_kv[k] = (k < iz) ? s_red2[ia + k] : __builtin_huge_valf(); s_ki[k] = (k < iz) ? ia + k : 0x7fffffff; }
     __syncthreads();
-    bitonic_sort_2048(s_kv, s_ki, tid);
+    bitonic_sort_n(s_kv, s_ki, nsort, tid);
     if (tid == 0 && npct >= 1) s_base[1] = s_red2[s_ki[npct - 1]];
     __syncthreads();
     // --- order of red (ascending); descending walk list
-    for (int k = tid; k < 2048; k += 256) { s_kv[k] = (k < iz) ? s_red[ia + k] : __builtin_huge_valf(); s_ki[k] = (k < iz) ? ia + k : 0x7fffffff; }
+    for (int k = tid; k < nsort; k += 256) { s_kv[k] = (k < iz) ? s_red[ia + k] : __builtin_huge_valf(); s_ki[k] = (k < iz) ? ia + k : 0x7fffffff; }
     __syncthreads();
-    bitonic_sort_2048(s_kv, s_ki, tid);
+    bitonic_sort_n(s_kv, s_ki, nsort, tid);
     if (tid == 0 && npct >= 1) s_base[0] = s_red[s_ki[npct - 1]];
     for (int r = tid; r < lim; r += 256) s_desc[r] = s_ki[iz - 1 - r];
     __syncthreads();
