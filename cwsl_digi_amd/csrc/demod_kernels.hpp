@@ -246,7 +246,7 @@ struct DemodGeom {
 //                    prefetch registers cost a workgroup of occupancy (163 VGPRs -> 3 per CU).
 // Barriers are raw `s_barrier` behind an `s_waitcnt lgkmcnt(0)`: __syncthreads() would also drain vmcnt, i.e.
 // wait for the prefetch.
-// Diagnostic build only (-DCWSLG_STAMP, scripts/gpu_stamps.sh): per-workgroup s_memtime stamps at the phase seams,
+// Diagnostic build only (-DCWSLG_STAMP, scripts/gpu_stamps.py): per-workgroup s_memtime stamps at the phase seams,
 // written to a buffer nothing else reads; the shipped library contains none of this.
 #ifdef CWSLG_STAMP
 __device__ unsigned long long g_stamps[8 * 65536];
