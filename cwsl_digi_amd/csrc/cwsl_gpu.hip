@@ -320,14 +320,17 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
         else if (c->demod_variant == 5) go(demod_mfma1p_kernel<kTile, kDemodThreads, 5>);
         else if (c->demod_variant == 6) go(demod_mfma1p_kernel<kTile, kDemodThreads, 6>);
         else go(demod_mfma1p_kernel<kTile, kDemodThreads, 7>);
-    } else if (c->demod_variant >= 9 && c->demod_variant <= 11) {
+    } else if (c->demod_variant >= 9 && c->demod_variant <= 14) {
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0, c->stream, (const ChanWork *)w->d,
                                (const float *)c->d_taps[fs], tiles_x, (int)works.size());
         };
         if (c->demod_variant == 9) go(ring_probe_kernel<D, kTile, kDemodThreads, 0>);
         else if (c->demod_variant == 10) go(ring_probe_kernel<D, kTile, kDemodThreads, 1>);
-        else go(ring_probe_kernel<D, kTile, kDemodThreads, 2>);
+        else if (c->demod_variant == 11) go(ring_probe_kernel<D, kTile, kDemodThreads, 2>);
+        else if (c->demod_variant == 12) go(ring_probe_kernel<D, kTile, kDemodThreads, 3>);
+        else if (c->demod_variant == 13) go(ring_probe_kernel<D, kTile, kDemodThreads, 4>);
+        else go(ring_probe_kernel<D, kTile, kDemodThreads, 5>);
     } else {
         hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, 0>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
                            c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());

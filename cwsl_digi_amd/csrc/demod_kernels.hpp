@@ -801,9 +801,10 @@ __global__ __launch_bounds__(NT, 4) void ring_probe_kernel(const ChanWork *__res
                                                            int tiles_x, int n_ch)
 {
     using Geo = DemodGeom<D, T>;
-    // FLAVOUR 1: + the per-wave atomicMax on the channel's peak word; 2: + the tile kernel's LDS footprint (4 workgroups per CU)
-    __shared__ float s_pad[(FLAVOUR == 2) ? 9900 : 1];
-    if (FLAVOUR == 2) s_pad[threadIdx.x] = 0.f;
+    // FLAVOUR 1: + the per-wave atomicMax on the channel's peak word; 2: + the tile kernel's LDS footprint (4 workgroups per CU);
+    // 3, 4, 5: flavour 2 + the workgroup idles (s_sleep, no pipe used) for ~2k / 4k / 8k cycles after its loads have arrived
+    __shared__ float s_pad[(FLAVOUR >= 2) ? 9900 : 1];
+    if (FLAVOUR >= 2) s_pad[threadIdx.x] = 0.f;
     constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
     const int total = (tiles_x < 0 ? -tiles_x : tiles_x) * n_ch;
     const int per_xcd = (total + 7) >> 3;
@@ -822,7 +823,11 @@ __global__ __launch_bounds__(NT, 4) void ring_probe_kernel(const ChanWork *__res
     float s = ck.x + tn.x + taps[tid & 15];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) s += xs[it].x + xs[it].y + xs[it].z + xs[it].w;
-    if (FLAVOUR == 2) s += s_pad[(threadIdx.x * 7) % 9900];
+    if (FLAVOUR >= 2) s += s_pad[(threadIdx.x * 7) % 9900];
+    if (FLAVOUR >= 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int q = 0; q < (1 << (FLAVOUR - 3)); ++q) __builtin_amdgcn_s_sleep(32);      // 32 x 64 = 2048 cycles each
+    }
     if (tid < cur.n_out) as_global_rw(cur.out)[(size_t)cur.tile * T + tid] = s;
     if (FLAVOUR == 1 && (tid & 63) == 0) publish_peak(cur.peak, fabsf(s));
 }
