@@ -77,7 +77,7 @@ class Candidate(C.Structure):
 
 class Spot(C.Structure):
     _fields_ = [("snr_db", C.c_int32), ("dt_s", C.c_float), ("freq_hz", C.c_uint32), ("has_locator", C.c_int32),
-                ("call", C.c_char * 16), ("locator", C.c_char * 8), ("message", C.c_char * 64)]
+                ("call", C.c_char * 16), ("locator", C.c_char * 8), ("message", C.c_char * 64), ("drift", C.c_int32), ("dbm", C.c_int32)]
 
 
 class Ft4Sync(C.Structure):
@@ -187,7 +187,7 @@ def parse_decode_line(mode, line, base_freq_hz):
     if rc < 0:
         raise CwslGpuError(rc, f"parse_decode_line({mode})")
     return dict(status=("ok", "unhandled", "skip")[rc], snr_db=sp.snr_db, dt_s=sp.dt_s, freq_hz=sp.freq_hz,
-                call=sp.call.decode(), locator=sp.locator.decode() if sp.has_locator else None, message=sp.message.decode())
+                call=sp.call.decode(), locator=sp.locator.decode() if sp.has_locator else None, message=sp.message.decode(), drift=sp.drift, dbm=sp.dbm)
 
 
 def slot_clock_next(group, after_ms):

@@ -1,4 +1,4 @@
-// spot_parse.hpp -- decoder stdout -> spot record for FT8/FT4: the text stage downstream of the
+// spot_parse.hpp -- decoder stdout -> spot record for FT8/FT4/FST4/FST4W/WSPR: the text stage downstream of the
 // decoder hand-off.  Pure host text logic, no device work.
 //   line grammar     OutputHandler.cpp:505-621  parseOutputFT4FT8: "HHMMSS snr  dt freq ~  message", fixed columns
 //   message rules    OutputHandler.cpp:924-1128 handleMessageUniversal: which token is the transmitting station's call,
@@ -111,11 +111,67 @@ inline bool message_to_spot(std::string msg, std::string &call, std::string &loc
     return false;
 }
 
+// splitStringByDelim(line, ' ', true) (StringUtils.hpp:48-68)
+inline std::vector<std::string> tokens_of(const std::string &line)
+{
+    std::vector<std::string> v;
+    size_t k = 0;
+    while (k < line.size()) {
+        while (k < line.size() && line[k] == ' ') ++k;
+        size_t e = k;
+        while (e < line.size() && line[e] != ' ') ++e;
+        if (e > k) v.push_back(line.substr(k, e - k));
+        k = e;
+    }
+    return v;
+}
+inline bool num_ok(const std::string &s) { char *e = nullptr; std::strtod(s.c_str(), &e); return e != s.c_str(); }
+
+// parseOutputWSPR / parseOutputFST4W / parseOutputFST4 for ONE line (OutputHandler.cpp:314-402, 152-240, 243-312)
+inline int parse_token_line(const std::string &mode, std::string line, int64_t base_freq_hz, cwslg_spot *out)
+{
+    trim_ws(line);
+    const std::vector<std::string> tok = tokens_of(line);
+    const bool wspr = mode == "WSPR", fst4w = mode.compare(0, 6, "FST4W-") == 0;
+    if (wspr) { if (tok.size() != 8) return CWSLG_SPOT_SKIP; }
+    else {
+        if (tok.size() < (fst4w ? 8u : 4u) || line.size() <= 22) return CWSLG_SPOT_SKIP;   // the reference indexes without checking
+        if (line[18] != ' ' || line[19] != '`' || line[20] != ' ' || line[21] != ' ') return CWSLG_SPOT_SKIP;
+    }
+    if (!num_ok(tok[1]) || !num_ok(tok[2]) || !num_ok(tok[3])) return CWSLG_SPOT_SKIP;
+    out->snr_db = (int32_t)std::strtol(tok[1].c_str(), nullptr, 10);
+    out->dt_s = std::strtof(tok[2].c_str(), nullptr);
+    const double f = std::strtod(tok[3].c_str(), nullptr);
+    out->freq_hz = (uint32_t)((double)base_freq_hz + (wspr ? f * 1000000.0 : f));
+    if (wspr || fst4w) {
+        std::string call = tok[5];
+        if (wspr) unpack_call(call);                         // "WSPR callsigns may be packed"; FST4W's are taken as they come
+        if (wspr) { if (!num_ok(tok[4]) || !num_ok(tok[7])) return CWSLG_SPOT_SKIP; out->drift = (int32_t)std::strtol(tok[4].c_str(), nullptr, 10); }
+        else if (!num_ok(tok[7])) return CWSLG_SPOT_SKIP;
+        out->dbm = (int32_t)std::strtol(tok[7].c_str(), nullptr, 10);
+        if (!call_ok(call)) return CWSLG_SPOT_UNHANDLED;
+        std::strncpy(out->call, call.c_str(), sizeof(out->call) - 1);
+        std::strncpy(out->locator, tok[6].c_str(), sizeof(out->locator) - 1);
+        out->has_locator = 1;
+        return CWSLG_SPOT_OK;
+    }
+    std::string msg = line.substr(22);                       // FST4: free text through the FT8 message rules
+    trim_ws(msg);
+    std::strncpy(out->message, msg.c_str(), sizeof(out->message) - 1);
+    std::string call, loc; bool has_loc = false;
+    if (!message_to_spot(msg, call, loc, has_loc)) return CWSLG_SPOT_UNHANDLED;
+    std::strncpy(out->call, call.c_str(), sizeof(out->call) - 1);
+    if (has_loc) std::strncpy(out->locator, loc.c_str(), sizeof(out->locator) - 1);
+    out->has_locator = has_loc ? 1 : 0;
+    return CWSLG_SPOT_OK;
+}
+
 // parseOutputFT4FT8 for ONE line.  Returns a CWSLG_SPOT_* status; on CWSLG_SPOT_OK / _UNHANDLED the numeric fields are set.
 inline int parse_decode_line(const char *mode, const char *line_in, int64_t base_freq_hz, cwslg_spot *out)
 {
     std::memset(out, 0, sizeof *out);
     std::string line = line_in ? line_in : "";
+    if (std::strcmp(mode, "FT8") != 0 && std::strcmp(mode, "FT4") != 0) return parse_token_line(mode, line, base_freq_hz, out);
     trim_ws(line);
     if (line.find("DecodeFinished") != std::string::npos) return CWSLG_SPOT_SKIP;
     if (line.length() <= 28) return CWSLG_SPOT_SKIP;

@@ -173,7 +173,9 @@ int cwslg_pool_sizing(const int *counts, float decoderburden, int n_decoders, in
 /* findBand (CWSL_Utils.hpp:28-55): index of the first band with |f - L0| <= Fs/2, or -1. */
 int cwslg_find_band(const int64_t *lo_hz, const uint32_t *fs_hz, int n_bands, int64_t f_hz);
 
-/* ---- decoder stdout -> spot record, FT8/FT4 -----------------------------------------------
+/* ---- decoder stdout -> spot record, FT8/FT4/FST4/FST4W/WSPR -----------------------------------------------
+ * FST4-*: "HHMM snr  dt freq `  message" (OutputHandler.cpp:243-312); FST4W-*: the same columns with call, locator and
+ * dBm as tokens (:152-240); WSPR: wsprd's eight tokens "id snr dt MHz drift call locator dBm" (:314-402).
  * One line of jt9's stdout ("HHMMSS snr  dt freq ~  message", fixed columns: OutputHandler.cpp:505-621) -> the
  * arguments reporter->handle() would receive (message rules: OutputHandler.cpp:924-1128; call / locator checks
  * :788-922, HamUtils.hpp:26-43).  base_freq_hz = the decoder's dial frequency (ItemToDecode::baseFreq).
@@ -189,7 +191,9 @@ typedef struct {
     int32_t  has_locator;
     char     call[16];
     char     locator[8];
-    char     message[64];      /* the message text, trimmed                                           */
+    char     message[64];      /* the message text, trimmed (FT8 / FT4 / FST4)                        */
+    int32_t  drift;            /* WSPR: Hz per minute                                                 */
+    int32_t  dbm;              /* WSPR / FST4W: reported power                                        */
 } cwslg_spot;
 int cwslg_parse_decode_line(const char *mode, const char *line, int64_t base_freq_hz, cwslg_spot *out);
 

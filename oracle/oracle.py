@@ -477,7 +477,7 @@ def ft4_sync_all(frame_i16, cands):
 
 class _Spot(C.Structure):
     _fields_ = [("snr_db", C.c_int32), ("dt_s", C.c_float), ("freq_hz", C.c_uint32), ("has_locator", C.c_int32),
-                ("call", C.c_char * 16), ("locator", C.c_char * 8), ("message", C.c_char * 64)]
+                ("call", C.c_char * 16), ("locator", C.c_char * 8), ("message", C.c_char * 64), ("drift", C.c_int32), ("dbm", C.c_int32)]
 
 
 def parse_decode_line(mode, line, base_freq_hz):
@@ -485,7 +485,7 @@ def parse_decode_line(mode, line, base_freq_hz):
     sp = _Spot()
     rc = lib().orc_parse_decode_line(mode.encode(), line.encode(), int(base_freq_hz), C.byref(sp))
     return dict(status=("ok", "unhandled", "skip")[rc], snr_db=sp.snr_db, dt_s=sp.dt_s, freq_hz=sp.freq_hz,
-                call=sp.call.decode(), locator=sp.locator.decode() if sp.has_locator else None, message=sp.message.decode())
+                call=sp.call.decode(), locator=sp.locator.decode() if sp.has_locator else None, message=sp.message.decode(), drift=sp.drift, dbm=sp.dbm)
 
 
 # ---- host-service rules (host_oracle.c; CWSL_DIGI.cpp:174-451, 857-887; CWSL_Utils.hpp:28-55) ----

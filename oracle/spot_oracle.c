@@ -17,6 +17,7 @@
 typedef struct {
     int32_t snr_db; float dt_s; uint32_t freq_hz; int32_t has_locator;
     char call[16]; char locator[8]; char message[64];
+    int32_t drift, dbm;
 } orc_spot_t;
 
 static void trim(char *s)
@@ -147,11 +148,78 @@ static int handle_message(const char *in, char *o_call, char *o_loc, int *has_lo
     return 0;
 }
 
+/* splitStringByDelim(line, ' ', true): StringUtils.hpp:48-68 */
+static int split(const char *line, char tok[][64], int max)
+{
+    int n = 0;
+    const char *p = line;
+    while (*p) {
+        while (*p == ' ') ++p;
+        if (!*p) break;
+        const char *e = p;
+        while (*e && *e != ' ') ++e;
+        if (n < max) { size_t l = (size_t)(e - p); if (l > 63) l = 63; memcpy(tok[n], p, l); tok[n][l] = 0; }
+        ++n;
+        p = e;
+    }
+    return n;
+}
+static int isnum(const char *s) { char *e; strtod(s, &e); return e != s; }
+
+/* one line of parseOutputWSPR (:314-402), parseOutputFST4W (:152-240) or parseOutputFST4 (:243-312) */
+static int token_line(const char *mode, const char *line_in, int64_t base_freq, orc_spot_t *out)
+{
+    char line[512], tok[16][64];
+    snprintf(line, sizeof line, "%s", line_in);
+    trim(line);
+    const int n = split(line, tok, 16);
+    const int wspr = !strcmp(mode, "WSPR"), fst4w = !strncmp(mode, "FST4W-", 6);
+    if (wspr) {
+        if (n != 8) return 2;
+    } else {
+        if (n < (fst4w ? 8 : 4) || strlen(line) <= 22) return 2;          /* lineVec[k] / line.at(k) would be out of range */
+        if (line[18] != ' ') return 2;
+        if (line[19] != '`') return 2;
+        if (line[20] != ' ') return 2;
+        if (line[21] != ' ') return 2;
+    }
+    if (!isnum(tok[1]) || !isnum(tok[2]) || !isnum(tok[3])) return 2;      /* std::stoi / stof / stod would throw */
+    out->snr_db = (int32_t)strtol(tok[1], NULL, 10);
+    out->dt_s = strtof(tok[2], NULL);
+    double freqHz = (double)base_freq;
+    freqHz += wspr ? strtod(tok[3], NULL) * 1000000.0 : strtod(tok[3], NULL);
+    out->freq_hz = (uint32_t)freqHz;
+    if (wspr || fst4w) {
+        char call[64];
+        snprintf(call, sizeof call, "%s", tok[5]);
+        if (wspr) {
+            parse_call(call);
+            if (!isnum(tok[4]) || !isnum(tok[7])) return 2;
+            out->drift = (int32_t)strtol(tok[4], NULL, 10);
+        } else if (!isnum(tok[7])) return 2;
+        out->dbm = (int32_t)strtol(tok[7], NULL, 10);
+        if (!check_call(call)) return 1;
+        snprintf(out->call, sizeof out->call, "%.15s", call);
+        snprintf(out->locator, sizeof out->locator, "%.7s", tok[6]);
+        out->has_locator = 1;
+        return 0;
+    }
+    char msg[256], c[256], l[256]; int has = 0;
+    sub(msg, line, 22, strlen(line) - 22); trim(msg);
+    snprintf(out->message, sizeof out->message, "%.63s", msg);
+    if (!handle_message(msg, c, l, &has)) return 1;
+    snprintf(out->call, sizeof out->call, "%.15s", c);
+    if (has) snprintf(out->locator, sizeof out->locator, "%.7s", l);
+    out->has_locator = has;
+    return 0;
+}
+
 /* one line of parseOutputFT4FT8: 0 ok, 1 unhandled, 2 skipped */
 int orc_parse_decode_line(const char *mode, const char *line_in, int64_t base_freq, orc_spot_t *out)
 {
     char line[512], f[16], msg[256];
     memset(out, 0, sizeof *out);
+    if (strcmp(mode, "FT8") && strcmp(mode, "FT4")) return token_line(mode, line_in, base_freq, out);
     snprintf(line, sizeof line, "%s", line_in);
     trim(line);
     if (strstr(line, "DecodeFinished")) return 2;
@@ -178,8 +246,8 @@ int orc_parse_decode_line(const char *mode, const char *line_in, int64_t base_fr
     if (!strcmp(mode, "FT8") && semi) text = semi + 1;             /* Fox/Hound: only the second part names the sender */
     char call[256], loc[256]; int has = 0;
     if (!handle_message(text, call, loc, &has)) return 1;
-    snprintf(out->call, sizeof out->call, "%s", call);
-    if (has) snprintf(out->locator, sizeof out->locator, "%s", loc);
+    snprintf(out->call, sizeof out->call, "%.15s", call);
+    if (has) snprintf(out->locator, sizeof out->locator, "%.7s", loc);
     out->has_locator = has;
     return 0;
 }

@@ -64,7 +64,7 @@ def test_line_grammar(oracle):
         assert P.parse_decode_line("FT8", b, 0)["status"] == "skip", b
         assert oracle.parse_decode_line("FT8", b, 0)["status"] == "skip", b
     with pytest.raises(P.CwslGpuError):
-        P.parse_decode_line("WSPR", good, 0)
+        P.parse_decode_line("JT65", good, 0)
     # leading / trailing blanks are trimmed before the columns are read (OutputHandler.cpp:515)
     assert P.parse_decode_line("FT8", "   " + good + "  \r", 0)["call"] == "K1ABC"
 
@@ -82,3 +82,51 @@ def test_random_messages_agree_with_oracle(oracle):
             assert got == want, (mode, msg, got, want)
             n_ok += got["status"] == "ok"
     assert n_ok > 200
+
+
+# ---- WSPR (wsprd), FST4W and FST4 (jt9 -W / -7) lines: OutputHandler.cpp:314-402, 152-240, 243-312
+TOKEN_KNOWN = [
+    # (mode, line, base, status, call, locator, freq_hz, snr, drift, dbm)
+    ("WSPR", "9550  -0  0.3   0.001549  0  W8EDU EN91 23", 14095600, "ok", "W8EDU", "EN91", 14097149, 0, 0, 23),
+    ("WSPR", "6a80 -20  0.2   0.001478  -1 <G0FCA> IO83UQ 30", 7038600, "ok", "G0FCA", "IO83UQ", 7040078, -20, -1, 30),
+    ("WSPR", "4dab -25 -0.1", 14095600, "skip", "", None, 0, 0, 0, 0),
+    ("WSPR", "9550   8  0.1   0.001574  0  QRP FN20 33", 14095600, "unhandled", "", None, 14097174, 8, 0, 33),
+    ("FST4W-120", "0000 -13  0.4 1480 `  W3TS FN10 30", 474200, "ok", "W3TS", "FN10", 475680, -13, 0, 30),
+    ("FST4W-300", "0000 -28  0.1 1512 `  <PJ4/K1ABC> FK52 23", 136000, "ok", "<PJ4/K1ABC>", "FK52", 137512, -28, 0, 23),   # no unpacking here
+    ("FST4W-120", "0000 -13  0.4 1480 ~  W3TS FN10 30", 474200, "skip", "", None, 0, 0, 0, 0),
+    ("FST4-60", "0000 -13  0.4 1080 `  CQ W3TS FN10", 1836600, "ok", "W3TS", "FN10", 1837680, -13, 0, 0),
+    ("FST4-120", "0000  -7 -0.2  990 `  K1ABC W9XYZ R-05", 1836600, "ok", "W9XYZ", None, 1837590, -7, 0, 0),
+    ("FST4-300", "0000  -7 -0.2  990 `  TNX 73 GL", 1836600, "unhandled", "", None, 1837590, -7, 0, 0),
+]
+
+
+@pytest.mark.parametrize("mode,line,base,status,call,loc,freq,snr,drift,dbm", TOKEN_KNOWN)
+def test_token_modes_known_answers(oracle, mode, line, base, status, call, loc, freq, snr, drift, dbm):
+    got = P.parse_decode_line(mode, line, base)
+    assert got == oracle.parse_decode_line(mode, line, base)
+    assert (got["status"], got["call"], got["locator"]) == (status, call, loc), got
+    if status != "skip":
+        assert (got["freq_hz"], got["snr_db"], got["drift"], got["dbm"]) == (freq, snr, drift, dbm), got
+
+
+def test_token_modes_random_lines_agree_with_oracle(oracle):
+    rng = random.Random(21)
+    calls = ["W8EDU", "<G0FCA>", "QRP", "K1ABC/P", "FN20", "5B4AMM", "A1", "<...>"]
+    locs = ["EN91", "IO83UQ", "FN", "XX00aa", "1234"]
+    for _ in range(1500):
+        mode = rng.choice(["WSPR", "FST4W-120", "FST4W-1800", "FST4-60", "FST4-900"])
+        snr, dt, f = rng.randrange(-33, 12), rng.randrange(-15, 30) / 10, rng.randrange(900, 1600)
+        if mode == "WSPR":
+            toks = [f"{rng.randrange(0, 65536):04x}", f"{snr:>3}", f"{dt:>4.1f}", f"{f / 1e6:>10.6f}", f"{rng.randrange(-3, 4):>2}",
+                    rng.choice(calls), rng.choice(locs), str(rng.choice([0, 10, 23, 30, 37]))]
+            if rng.random() < 0.1:
+                toks = toks[:rng.randrange(1, 8)]
+            line = "  ".join(toks)
+        elif mode.startswith("FST4W"):
+            line = f"0000 {snr:>3} {dt:>4.1f} {f:>4} {rng.choice('`~')}  {rng.choice(calls)} {rng.choice(locs)} {rng.choice([23, 30])}"
+        else:
+            line = f"0000 {snr:>3} {dt:>4.1f} {f:>4} `  " + " ".join(rng.choice(["CQ", "K1ABC", "W9XYZ", "FN42", "R-05", "73", "RR73"]) for _ in range(rng.randrange(1, 5)))
+        assert P.parse_decode_line(mode, line, 474200) == oracle.parse_decode_line(mode, line, 474200), (mode, line)
+    for m in ("JS8", "JT65", "Q65-30", "PSK31"):
+        with pytest.raises(P.CwslGpuError):
+            P.parse_decode_line(m, "x", 0)
