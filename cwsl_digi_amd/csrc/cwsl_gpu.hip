@@ -1150,9 +1150,7 @@ int cwslg_find_band(const int64_t *lo_hz, const uint32_t *fs_hz, int n_bands, in
 int cwslg_parse_decode_line(const char *mode, const char *line, int64_t base_freq_hz, cwslg_spot *out)
 {
     if (!mode || !line || !out) return CWSLG_ERR_ARG;
-    const bool known = !std::strcmp(mode, "FT8") || !std::strcmp(mode, "FT4") || !std::strcmp(mode, "WSPR") ||
-                       cwslg::handoff::is_fst4(mode) || cwslg::handoff::is_fst4w(mode);
-    if (!known || !cwslg::find_mode(mode)) return CWSLG_ERR_MODE;            // JS8 / JT65 / Q65 line formats are not restated
+    if (!cwslg::find_mode(mode) || !std::strcmp(mode, "JS8")) return CWSLG_ERR_MODE;   // JS8's varicode frames are not restated
     return cwslg::host::parse_decode_line(mode, line, base_freq_hz, out);
 }
 

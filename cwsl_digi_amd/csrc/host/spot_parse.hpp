@@ -171,14 +171,23 @@ inline int parse_decode_line(const char *mode, const char *line_in, int64_t base
 {
     std::memset(out, 0, sizeof *out);
     std::string line = line_in ? line_in : "";
-    if (std::strcmp(mode, "FT8") != 0 && std::strcmp(mode, "FT4") != 0) return parse_token_line(mode, line, base_freq_hz, out);
+    const bool jt65 = std::strcmp(mode, "JT65") == 0;
+    const bool col = jt65 || !std::strcmp(mode, "FT8") || !std::strcmp(mode, "FT4") || !std::strcmp(mode, "Q65-30");
+    if (!col) return parse_token_line(mode, line, base_freq_hz, out);
     trim_ws(line);
     if (line.find("DecodeFinished") != std::string::npos) return CWSLG_SPOT_SKIP;
-    if (line.length() <= 28) return CWSLG_SPOT_SKIP;
-    if (line[6] != ' ' || line[10] != ' ' || line[15] != ' ' || line[20] != ' ') return CWSLG_SPOT_SKIP;
-    if (line[21] != '~' && line[21] != '+') return CWSLG_SPOT_SKIP;
-    if (line[22] != ' ' || line[23] != ' ') return CWSLG_SPOT_SKIP;
-    std::string snr = line.substr(7, 3), dt = line.substr(11, 4), fq = line.substr(16, 4), msg = line.substr(24);
+    std::string snr, dt, fq, msg;
+    if (jt65) {                                                    // "HHMM snr  dt freq  #  message" (OutputHandler.cpp:623-695)
+        if (line.length() <= 27) return CWSLG_SPOT_SKIP;
+        if (line[4] != ' ' || line[8] != ' ' || line[13] != ' ' || line[20] != ' ') return CWSLG_SPOT_SKIP;
+        snr = line.substr(5, 3); dt = line.substr(9, 4); fq = line.substr(14, 4); msg = line.substr(22);
+    } else {                                                       // FT8 / FT4 (:505-621), Q65 (:697-780): the same columns
+        if (line.length() <= 28) return CWSLG_SPOT_SKIP;
+        if (line[6] != ' ' || line[10] != ' ' || line[15] != ' ' || line[20] != ' ') return CWSLG_SPOT_SKIP;
+        if (line[21] != '~' && line[21] != '+') return CWSLG_SPOT_SKIP;
+        if (line[22] != ' ' || line[23] != ' ') return CWSLG_SPOT_SKIP;
+        snr = line.substr(7, 3); dt = line.substr(11, 4); fq = line.substr(16, 4); msg = line.substr(24);
+    }
     trim_ws(snr); trim_ws(dt); trim_ws(fq); trim_ws(msg);
     char *e1 = nullptr, *e2 = nullptr, *e3 = nullptr;
     const double f = std::strtod(fq.c_str(), &e1);                              // std::stod / stoi / stof throw on garbage:

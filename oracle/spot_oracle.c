@@ -219,10 +219,34 @@ int orc_parse_decode_line(const char *mode, const char *line_in, int64_t base_fr
 {
     char line[512], f[16], msg[256];
     memset(out, 0, sizeof *out);
-    if (strcmp(mode, "FT8") && strcmp(mode, "FT4")) return token_line(mode, line_in, base_freq, out);
+    const int jt65 = !strcmp(mode, "JT65");
+    if (!jt65 && strcmp(mode, "FT8") && strcmp(mode, "FT4") && strcmp(mode, "Q65-30")) return token_line(mode, line_in, base_freq, out);
     snprintf(line, sizeof line, "%s", line_in);
     trim(line);
     if (strstr(line, "DecodeFinished")) return 2;
+    if (jt65) {                                           /* parseOutputJT65, :623-695 */
+        if (strlen(line) <= 27) return 2;
+        if (line[4] != ' ') return 2;
+        sub(f, line, 5, 3); trim(f);
+        char *e; const long snr = strtol(f, &e, 10); if (e == f) return 2;
+        if (line[8] != ' ') return 2;
+        sub(f, line, 9, 4); trim(f);
+        const float dt = strtof(f, &e); if (e == f) return 2;
+        if (line[13] != ' ') return 2;
+        sub(f, line, 14, 4); trim(f);
+        const double fq = strtod(f, &e); if (e == f) return 2;
+        if (line[20] != ' ') return 2;
+        if (line[19] != '#' && line[20] != ' ') return 2;
+        sub(msg, line, 22, strlen(line)); trim(msg);
+        out->snr_db = (int32_t)snr; out->dt_s = dt; out->freq_hz = (uint32_t)(fq + (double)base_freq);
+        snprintf(out->message, sizeof out->message, "%.63s", msg);
+        char call[256], loc[256]; int has = 0;
+        if (!handle_message(msg, call, loc, &has)) return 1;
+        snprintf(out->call, sizeof out->call, "%.15s", call);
+        if (has) snprintf(out->locator, sizeof out->locator, "%.7s", loc);
+        out->has_locator = has;
+        return 0;
+    }
     if (strlen(line) <= 28) return 2;
     if (line[6] != ' ') return 2;
     sub(f, line, 7, 3); trim(f);

@@ -64,7 +64,7 @@ def test_line_grammar(oracle):
         assert P.parse_decode_line("FT8", b, 0)["status"] == "skip", b
         assert oracle.parse_decode_line("FT8", b, 0)["status"] == "skip", b
     with pytest.raises(P.CwslGpuError):
-        P.parse_decode_line("JT65", good, 0)
+        P.parse_decode_line("JS8", good, 0)
     # leading / trailing blanks are trimmed before the columns are read (OutputHandler.cpp:515)
     assert P.parse_decode_line("FT8", "   " + good + "  \r", 0)["call"] == "K1ABC"
 
@@ -127,6 +127,27 @@ def test_token_modes_random_lines_agree_with_oracle(oracle):
         else:
             line = f"0000 {snr:>3} {dt:>4.1f} {f:>4} `  " + " ".join(rng.choice(["CQ", "K1ABC", "W9XYZ", "FN42", "R-05", "73", "RR73"]) for _ in range(rng.randrange(1, 5)))
         assert P.parse_decode_line(mode, line, 474200) == oracle.parse_decode_line(mode, line, 474200), (mode, line)
-    for m in ("JS8", "JT65", "Q65-30", "PSK31"):
+    for m in ("JS8", "PSK31"):
         with pytest.raises(P.CwslGpuError):
             P.parse_decode_line(m, "x", 0)
+
+
+def test_jt65_and_q65_columns(oracle):
+    """JT65: "HHMM snr  dt freq  #  msg" (OutputHandler.cpp:623-695); Q65: FT8's columns without the Fox/Hound split (:697-780)."""
+    jt = "0001 -11  0.3 1234  #  CQ K1ABC FN42"
+    assert jt[4] == " " and jt[8] == " " and jt[13] == " " and jt[20] == " " and jt[22:] == "CQ K1ABC FN42"
+    for line, mode in ((jt, "JT65"), ("123045 -12  0.3 1234 ~  CQ K1ABC FN42", "Q65-30"), ("123045 -12  0.3 1234 ~  K1ABC RR73; W9XYZ <KH1/KH7Z> -08", "Q65-30")):
+        got = P.parse_decode_line(mode, line, 14076000)
+        assert got == oracle.parse_decode_line(mode, line, 14076000)
+    got = P.parse_decode_line("JT65", jt, 14076000)
+    assert (got["status"], got["call"], got["locator"], got["freq_hz"], got["snr_db"]) == ("ok", "K1ABC", "FN42", 14077234, -11)
+    assert P.parse_decode_line("Q65-30", "123045 -12  0.3 1234 ~  K1ABC RR73; W9XYZ <KH1/KH7Z> -08", 0)["status"] == "unhandled"
+    assert P.parse_decode_line("JT65", jt[:4] + "x" + jt[5:], 0)["status"] == "skip"
+    rng = random.Random(31)
+    for _ in range(1000):
+        msg = " ".join(rng.choice(["CQ", "K1ABC", "W9XYZ", "FN42", "R-05", "73", "RR73", "<PJ4/K1ABC>", "DX"]) for _ in range(rng.randrange(1, 5)))
+        snr, dt, f = rng.randrange(-30, 10), rng.randrange(-20, 30) / 10, rng.randrange(200, 3000)
+        l65 = f"0001 {snr:>3} {dt:>4.1f} {f:>4}  #  {msg}"
+        lq = f"123045 {snr:>3} {dt:>4.1f} {f:>4} ~  {msg}"
+        assert P.parse_decode_line("JT65", l65, 7076000) == oracle.parse_decode_line("JT65", l65, 7076000), l65
+        assert P.parse_decode_line("Q65-30", lq, 7076000) == oracle.parse_decode_line("Q65-30", lq, 7076000), lq
