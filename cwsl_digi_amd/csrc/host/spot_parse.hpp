@@ -177,7 +177,7 @@ inline int parse_decode_line(const char *mode, const char *line_in, int64_t base
     trim_ws(line);
     if (line.find("DecodeFinished") != std::string::npos) return CWSLG_SPOT_SKIP;
     std::string snr, dt, fq, msg;
-    if (jt65) {                                                    // "HHMM snr  dt freq  #  message" (OutputHandler.cpp:623-695)
+    if (jt65) {                                                    // "HHMM snr  dt freq #  message" (OutputHandler.cpp:623-695)
         if (line.length() <= 27) return CWSLG_SPOT_SKIP;
         if (line[4] != ' ' || line[8] != ' ' || line[13] != ' ' || line[20] != ' ') return CWSLG_SPOT_SKIP;
         snr = line.substr(5, 3); dt = line.substr(9, 4); fq = line.substr(14, 4); msg = line.substr(22);

@@ -174,7 +174,7 @@ int cwslg_pool_sizing(const int *counts, float decoderburden, int n_decoders, in
 int cwslg_find_band(const int64_t *lo_hz, const uint32_t *fs_hz, int n_bands, int64_t f_hz);
 
 /* ---- decoder stdout -> spot record, every mode but JS8 -----------------------------------------------
- * JT65: "HHMM snr  dt freq  #  message" (OutputHandler.cpp:623-695); Q65-30: FT8's columns (:697-780);
+ * JT65: "HHMM snr  dt freq #  message" (OutputHandler.cpp:623-695); Q65-30: FT8's columns (:697-780);
  * FST4-*: "HHMM snr  dt freq `  message" (OutputHandler.cpp:243-312); FST4W-*: the same columns with call, locator and
  * dBm as tokens (:152-240); WSPR: wsprd's eight tokens "id snr dt MHz drift call locator dBm" (:314-402).
  * One line of jt9's stdout ("HHMMSS snr  dt freq ~  message", fixed columns: OutputHandler.cpp:505-621) -> the

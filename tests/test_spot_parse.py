@@ -133,9 +133,9 @@ def test_token_modes_random_lines_agree_with_oracle(oracle):
 
 
 def test_jt65_and_q65_columns(oracle):
-    """JT65: "HHMM snr  dt freq  #  msg" (OutputHandler.cpp:623-695); Q65: FT8's columns without the Fox/Hound split (:697-780)."""
-    jt = "0001 -11  0.3 1234  #  CQ K1ABC FN42"
-    assert jt[4] == " " and jt[8] == " " and jt[13] == " " and jt[20] == " " and jt[22:] == "CQ K1ABC FN42"
+    """JT65: "HHMM snr  dt freq #  msg" (OutputHandler.cpp:623-695); Q65: FT8's columns without the Fox/Hound split (:697-780)."""
+    jt = "0001 -11  0.3 1234 #  CQ K1ABC FN42"
+    assert jt[4] == " " and jt[8] == " " and jt[13] == " " and jt[19] == "#" and jt[20] == " " and jt[22:] == "CQ K1ABC FN42"
     for line, mode in ((jt, "JT65"), ("123045 -12  0.3 1234 ~  CQ K1ABC FN42", "Q65-30"), ("123045 -12  0.3 1234 ~  K1ABC RR73; W9XYZ <KH1/KH7Z> -08", "Q65-30")):
         got = P.parse_decode_line(mode, line, 14076000)
         assert got == oracle.parse_decode_line(mode, line, 14076000)
@@ -147,7 +147,7 @@ def test_jt65_and_q65_columns(oracle):
     for _ in range(1000):
         msg = " ".join(rng.choice(["CQ", "K1ABC", "W9XYZ", "FN42", "R-05", "73", "RR73", "<PJ4/K1ABC>", "DX"]) for _ in range(rng.randrange(1, 5)))
         snr, dt, f = rng.randrange(-30, 10), rng.randrange(-20, 30) / 10, rng.randrange(200, 3000)
-        l65 = f"0001 {snr:>3} {dt:>4.1f} {f:>4}  #  {msg}"
+        l65 = f"0001 {snr:>3} {dt:>4.1f} {f:>4} #  {msg}"
         lq = f"123045 {snr:>3} {dt:>4.1f} {f:>4} ~  {msg}"
         assert P.parse_decode_line("JT65", l65, 7076000) == oracle.parse_decode_line("JT65", l65, 7076000), l65
         assert P.parse_decode_line("Q65-30", lq, 7076000) == oracle.parse_decode_line("Q65-30", lq, 7076000), lq
