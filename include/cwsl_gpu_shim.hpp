@@ -109,6 +109,25 @@ public:
         out.resize(n);
         return n;
     }
+    // FT4 channels: every candidate refined coherently (start sample, frequency tweak, sync) -- cwslg_fetch_ft4_sync
+    int ft4Sync(std::vector<cwslg_ft4_sync> &out, int max = 1800)
+    {
+        out.resize(max);
+        int n = 0;
+        const int rc = cwslg_fetch_ft4_sync(ctx_.raw(), id_, out.data(), max, &n);
+        if (rc == CWSLG_ERR_NO_FRAME) { out.clear(); return 0; }
+        check(ctx_.raw(), rc);
+        out.resize(n);
+        return n;
+    }
+    // what decodeUsingShMem does between lock and unlock (DecoderPool.hpp:451-590): the jt9 block, d2 straight from HBM
+    bool fillDecoderBlock(void *block, std::size_t bytes, int decodedepth, int highestDecodeFreq, std::uint64_t &startEpoch, bool js8 = false)
+    {
+        const int rc = cwslg_fill_decoder_block(ctx_.raw(), id_, block, bytes, js8 ? 1 : 0, decodedepth, highestDecodeFreq, &startEpoch);
+        if (rc == CWSLG_ERR_NO_FRAME) return false;
+        check(ctx_.raw(), rc);
+        return true;
+    }
 private:
     Context &ctx_;
     int id_ = -1;
