@@ -50,6 +50,16 @@ def host_cores():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown CPU"
+
+
 def slot_freq(gs):
     """Tuning offset of global slot gs: spread over the legal band (|F|<=96k, |F+6k|<=96k)."""
     return -90000 + (gs * 4373) % 176000
@@ -211,7 +221,8 @@ def main():
         tN = fn(cores, slots_each) if slots_each > 1 else tc
         cpu = {"value": cores * slots_each * n_eff / tN / 1e6, "unit": "Msamples/s", "cores": cores, "kind": kind,
                "sample": f"{cores} channels x {slots_each} FT8 slots (2.88 M IQ samples each) on {cores} threads, {what}; "
-                         f"single thread: {2 * n_eff / t1 / 1e6:.1f} Msamples/s"}
+                         f"single thread: {2 * n_eff / t1 / 1e6:.1f} Msamples/s; host CPU: {cpu_model()}, "
+                         f"{len(os.sched_getaffinity(0))} logical CPUs visible, {cores} usable under the cgroup quota"}
 
     if rank == 0:
         launches = max(1, st["demod_launches"])
