@@ -270,6 +270,19 @@ class Context:
     def __enter__(self):
         return self
 
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
     def __exit__(self, *a):
         self.close()
 
