@@ -1029,6 +1029,55 @@ int cwslg_channel_close(cwslg_ctx *c, int ch_id)
     return CWSLG_OK;
 }
 
+// SSBD::Tune(F, isUSB, reset = true) (SSBD.hpp:96-123): new tone and phasor step, workspace zeroed, index 0, phase (1, 0).
+// Samples pushed before the call are demodulated with the old tuning; the frame keeps filling where it was.
+int cwslg_channel_tune(cwslg_ctx *c, int ch_id, int32_t demod_hz, int usb)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
+    hipSetDevice(c->device);
+    Channel &ch = c->chans[ch_id];
+    Receiver &rx = c->rxs[ch.rx];
+    const double f_hz = (double)(float)demod_hz;
+    int rc = check_tuning(rx.fs, kSsbBw, f_hz, usb != 0);
+    if (rc) return fail(c, rc, "%s", cwslg_strerror(rc));                      // the channel keeps its old tuning, as after a throw
+    if ((rc = process_locked(c)) != CWSLG_OK) return rc;                        // everything already pushed: old tone
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    DemodConstants k = make_constants(rx.fs, kSsbBw, f_hz, usb != 0);
+    const auto new_key = std::make_tuple(rx.fs, demod_hz, usb ? 1 : 0, std::get<3>(ch.phasor_key));
+    if (new_key != ch.phasor_key) {
+        PhasorTable &pt = c->phasors[new_key];
+        if (pt.refs == 0) {
+            pt.d_ckpt = nullptr;
+            if (hipMalloc(&pt.d_ckpt, std::get<3>(new_key) * sizeof(float2)) != hipSuccess) {
+                c->phasors.erase(new_key);
+                return fail(c, CWSLG_ERR_NOMEM, "phasor table allocation failed");
+            }
+            pt.n_ckpt = std::get<3>(new_key);
+            pt.inc = make_float2(k.inc.real(), k.inc.imag());
+            pt.built = false;
+            c->phasor_todo.push_back(new_key);
+        }
+        pt.refs++;
+        auto it = c->phasors.find(ch.phasor_key);
+        if (it != c->phasors.end() && --it->second.refs == 0) {
+            c->phasor_todo.erase(std::remove(c->phasor_todo.begin(), c->phasor_todo.end(), ch.phasor_key), c->phasor_todo.end());
+            hipFree(it->second.d_ckpt);
+            c->phasors.erase(it);
+        }
+        ch.phasor_key = new_key;
+    }
+    ch.k = k;
+    ch.demod_hz = demod_hz;
+    ch.usb = usb != 0;
+    HIPCHK(c, hipMemcpyAsync(ch.d_tone, ch.k.tone.data(), ch.k.block * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ch.origin_abs = (int64_t)rx.total;                                          // workspace zeroed, phase (1,0): history restarts here
+    ch.pend_lo = ch.origin_abs;
+    return CWSLG_OK;
+}
+
 int cwslg_channel_info(cwslg_ctx *c, int ch_id, uint32_t *in_size, uint32_t *out_size, uint32_t *out_rate,
                        uint32_t *delay, size_t *frame_len)
 {

@@ -114,6 +114,11 @@ int cwslg_ring_info(cwslg_ctx *ctx, int rx_id, void **d_ring, uint32_t *capacity
  *      mode is the decoder= line's mode string ("FT8", "FT4", "WSPR", "FST4W-120", ...). ---- */
 int cwslg_channel_open(cwslg_ctx *ctx, int rx_id, int32_t demod_hz, int usb, const char *mode, int *ch_id);
 int cwslg_channel_close(cwslg_ctx *ctx, int ch_id);
+/* SSBD::Tune(F, isUSB) with its default reset = true (SSBD.hpp:96-123): the channel gets a new tone and phasor step, its
+ * filter history is forgotten and its phasor restarts at (1, 0); samples pushed before the call keep the old tuning and
+ * the frame keeps filling where it was.  The band checks fail with the same two statuses / messages as at open, and then
+ * leave the old tuning in place.  (Tune's reset = false -- a phase-continuous retune over a live workspace -- is not offered.) */
+int cwslg_channel_tune(cwslg_ctx *ctx, int ch_id, int32_t demod_hz, int usb);
 /* SSBD getters (SSBD.hpp:140-154) for the shim */
 int cwslg_channel_info(cwslg_ctx *ctx, int ch_id, uint32_t *in_size, uint32_t *out_size,
                        uint32_t *out_rate, uint32_t *delay, size_t *frame_len);

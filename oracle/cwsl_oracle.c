@@ -75,10 +75,23 @@ int orc_demod_open(orc_demod_t *d, uint64_t fs, uint64_t bw, double f_hz, int us
     for (uint32_t n = 0; n < d->ntaps; ++n) acc += d->taps[n];
     for (uint32_t n = 0; n < d->ntaps; ++n) d->taps[n] /= acc;
 
-    /* Tune(): range checks use integer Fs/2 promoted to double (:100-103) */
+    {
+        const int rc = orc_demod_tune(d, f_hz, usb);            /* :81 the constructor ends in Tune(F, isUSB) */
+        if (rc != ORC_OK) { orc_demod_close(d); return rc; }
+    }
+    return ORC_OK;
+}
+
+/* SSBD::Tune(F, isUSB, reset = true), SSBD.hpp:96-123.  On a range error the object is left untouched (the throw
+ * happens before anything is stored). */
+int orc_demod_tune(orc_demod_t *d, double f_hz, int usb)
+{
+    const uint64_t fs = d->fs, bw = d->bw;
+    /* range checks use integer Fs/2 promoted to double (:100-103) */
     const double half_band = (double)(fs / 2);
-    if (fabs(f_hz) > half_band) { orc_demod_close(d); return ORC_ERR_BAND_LOW; }
-    if (fabs(f_hz + (double)bw * (usb ? 1.0 : -1.0)) > half_band) { orc_demod_close(d); return ORC_ERR_BAND_HIGH; }
+    if (fabs(f_hz) > half_band) return ORC_ERR_BAND_LOW;
+    if (fabs(f_hz + (double)bw * (usb ? 1.0 : -1.0)) > half_band) return ORC_ERR_BAND_HIGH;
+    d->usb = usb ? 1 : 0;
 
     d->sign = usb ? 1.0f : -1.0f;                               /* :110 */
     /* :111  -2.0*PI*(F + sign*B/2.0)/Fs : sign*B is a float product, the rest double */
@@ -95,7 +108,8 @@ int orc_demod_open(orc_demod_t *d, uint64_t fs, uint64_t bw, double f_hz, int us
         d->inc_re = crealf(e);
         d->inc_im = cimagf(e);
     }
-    d->head = 0;                                                /* :117-121 */
+    for (int k = 0; k < ORC_NUM_WS; ++k) { d->ws_re[k] = 0.0f; d->ws_im[k] = 0.0f; }     /* :117-121 */
+    d->head = 0;
     d->ph_re = 1.0f; d->ph_im = 0.0f;
     return ORC_OK;
 }

@@ -66,6 +66,8 @@ typedef struct {
 int  orc_lowpass_design(size_t order, double bandwidth, float *taps);           /* LowPass.hpp:16-35 */
 int  orc_demod_open(orc_demod_t *d, uint64_t fs, uint64_t bw, double f_hz, int usb); /* SSBD.hpp:48-83,97-123 */
 void orc_demod_close(orc_demod_t *d);
+/* SSBD::Tune(F, isUSB, reset = true) on an open demodulator (SSBD.hpp:96-123) */
+int  orc_demod_tune(orc_demod_t *d, double f_hz, int usb);
 /* one Iterate(): consumes 4*block complex samples, emits 4 floats (SSBD.hpp:127-137,160-183) */
 void orc_demod_iterate(orc_demod_t *d, const float *iq_ri, float *out4);
 /* n_complex must be a multiple of 4*block; phase_trace (optional) gets the phasor before every block */

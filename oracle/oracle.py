@@ -60,6 +60,7 @@ def lib():
         L.orc_lowpass_design.argtypes = [C.c_size_t, C.c_double, _f32p]
         L.orc_demod_open.argtypes = [C.POINTER(_Demod), C.c_uint64, C.c_uint64, C.c_double, C.c_int]
         L.orc_demod_close.argtypes = [C.POINTER(_Demod)]
+        L.orc_demod_tune.argtypes = [C.POINTER(_Demod), C.c_double, C.c_int]
         L.orc_demod_run.argtypes = [C.POINTER(_Demod), _f32p, C.c_uint64, _f32p, C.c_void_p]
         L.orc_rx_period.argtypes = [C.c_char_p]; L.orc_rx_period.restype = C.c_double
         L.orc_frame_len.argtypes = [C.c_char_p]; L.orc_frame_len.restype = C.c_size_t
@@ -129,6 +130,7 @@ def ref():
         R.ref_ssbd_run.argtypes = [C.c_void_p, _f32p, C.c_uint64, _f32p, C.c_void_p]
         R.ref_ssbd_run.restype = C.c_int
         R.ref_build_lowpass.argtypes = [C.c_uint64, C.c_double, _f32p]
+        R.ref_ssbd_tune.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_char_p, C.c_int]
         R.ref_bench_cpu.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint64]
         R.ref_bench_cpu.restype = C.c_double
         R.ref_inst_new.argtypes = [C.c_uint64, C.c_uint32, C.c_double, C.c_uint64]; R.ref_inst_new.restype = C.c_void_p
@@ -185,6 +187,12 @@ class Demod:
     @property
     def phase_delta(self):
         return np.float32(self.s.phase_delta)
+
+    def tune(self, f_hz, usb=True):
+        """SSBD::Tune(F, isUSB) on the live object; raises ValueError with the reference's text, state untouched."""
+        rc = lib().orc_demod_tune(C.byref(self.s), float(f_hz), 1 if usb else 0)
+        if rc != 0:
+            raise ValueError({-2: "Signal outside of band (low)", -3: "Signal outside of band (high)"}.get(rc, str(rc)))
 
     def run(self, iq, trace=False):
         """iq: complex64[n] (n multiple of 4*block) -> float32[n/block] (+ complex64 phasor trace)."""
@@ -257,6 +265,11 @@ class RefDemod:
 
     __del__ = close
 
+    def tune(self, f_hz, usb=True):
+        err = C.create_string_buffer(256)
+        if ref().ref_ssbd_tune(self.h, float(f_hz), 1 if usb else 0, err, 256) != 0:
+            raise ValueError(err.value.decode())
+
     @property
     def taps(self):
         t = np.empty(self.ntaps, np.float32); ref().ref_ssbd_get_taps(self.h, t); return t
@@ -301,6 +314,12 @@ class Channel:
             lib().orc_channel_close(C.byref(self.c)); self.c = None
 
     __del__ = close
+
+    def tune(self, demod_hz, usb=True):
+        """Instance's SSBD retuned in place (SSBD::Tune): float(demod_hz) as at construction (Instance.cpp:187)."""
+        rc = lib().orc_demod_tune(C.byref(self.c.demod), float(np.float32(demod_hz)), 1 if usb else 0)
+        if rc != 0:
+            raise ValueError({-2: "Signal outside of band (low)", -3: "Signal outside of band (high)"}.get(rc, str(rc)))
 
     def push(self, iq_block):
         iq_block = np.ascontiguousarray(iq_block, dtype=np.complex64)

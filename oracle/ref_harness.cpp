@@ -114,6 +114,16 @@ int ref_ssbd_run(void* h, const float* iq_ri, uint64_t n_complex, float* out, fl
     return rc;
 }
 
+// SSBD::Tune on a live object (SSBD.hpp:96-123); 0 ok, -1 = threw (message in err)
+int ref_ssbd_tune(void* h, double F, int usb, char* err, int errlen)
+{
+    try { static_cast<SSBD<float>*>(h)->Tune(F, usb != 0); return 0; }
+    catch (const std::exception& e) {
+        if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+        return -1;
+    }
+}
+
 // BuildLowPass<float> alone (LowPass.hpp:16-35), un-normalised.
 void ref_build_lowpass(uint64_t order, double bandwidth, float* taps)
 {

@@ -112,3 +112,23 @@ def test_locator_and_trim_helpers_match_reference(ref):
         core = "123045 -12  0.3 1234 ~  CQ K1ABC FN42"
         assert ref.ref_trim(pad_l + core + pad_r) == core
         assert P.parse_decode_line("FT8", pad_l + core + pad_r, 0)["call"] == "K1ABC"
+
+
+def test_tune_on_a_live_demodulator_matches_reference(ref):
+    """SSBD::Tune(F, isUSB) mid-stream: the oracle's orc_demod_tune against the compiled header, incl. a rejected retune."""
+    fs = 96000
+    iq = ref.synth_iq(3, 64 * 32 * 12, fs, tones_hz=[-20000 + 1000.0, 31000 + 1700.0], amp=9000.0)
+    a, b = ref.Demod(fs, -20000), ref.RefDemod(fs, -20000)
+    n1 = 64 * 32 * 5
+    ya, yb = a.run(iq[:n1]), b.run(iq[:n1])
+    assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32))
+    for obj in (a, b):
+        with pytest.raises(ValueError, match=r"Signal outside of band \(high\)"):
+            obj.tune(45000)                                   # |F + B| > Fs/2: thrown before anything is stored
+    a.tune(31000); b.tune(31000)
+    ya, yb = a.run(iq[n1:]), b.run(iq[n1:])
+    assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32))
+    assert np.array_equal(a.tone.view(np.uint32), b.tone.view(np.uint32))
+    # a retuned object equals a freshly constructed one from that point on (workspace, index and phase are reset)
+    c = ref.Demod(fs, 31000)
+    assert np.array_equal(c.run(iq[n1:]).view(np.uint32), ya.view(np.uint32))
