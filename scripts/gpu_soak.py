@@ -24,7 +24,7 @@ def main():
 
     rng = np.random.default_rng(args.seed)
     t_end = time.time() + args.seconds
-    st = dict(iterations=0, exact_frames=0, fast_frames=0, ft8_lists=0, ft4_lists=0, ft4_records=0, candidates=0,
+    st = dict(iterations=0, retunes=0, exact_frames=0, fast_frames=0, ft8_lists=0, ft4_lists=0, ft4_records=0, candidates=0,
               worst_fast_rel=0.0, failures=[])
     period = {"FT8": 15.0, "FT4": 7.5, "JT65": 6.0}
     while time.time() < t_end and not st["failures"]:
@@ -54,15 +54,21 @@ def main():
             ctx.enable_sync(True, 1.5, max_cand, 200, f_hi)
             rx = ctx.receiver_open(fs, blk, 0)
             ch = ctx.channel_open(rx, f, mode)
-            ctx.slot_boundary(mode, 10)
-            pos = 0
-            while pos < n:                          # ragged multi-block pushes
-                m = min(n - pos, blk * int(rng.integers(1, 60)))
-                ctx.push_iq(rx, iq[pos:pos + m]); pos += m
-            ctx.slot_boundary(mode, 25)
+            for _ in range(int(rng.integers(0, 3))):            # neighbours sharing the receiver's IQ (must not matter)
+                ctx.channel_open(rx, int(rng.integers(-half, half - 6000)), str(rng.choice(["FT8", "FT4"])))
             oc = O.Channel(mode, fs, blk, f)
-            oc.boundary(10)
-            oc.push_many(iq)
+            ctx.slot_boundary(mode, 10); oc.boundary(10)
+            retune_at = int(rng.integers(1, max(2, n // blk))) * blk if rng.random() < 0.25 else -1
+            f2 = int(rng.integers(-half, half - 6000))
+            pos = 0
+            while pos < n:                          # ragged multi-block pushes; sometimes SSBD::Tune in mid-slot
+                m = min(n - pos, blk * int(rng.integers(1, 60)))
+                if 0 <= retune_at - pos < m and retune_at > pos:
+                    m = retune_at - pos
+                if pos == retune_at:
+                    ctx.channel_tune(ch, f2); oc.tune(f2); st["retunes"] += 1
+                ctx.push_iq(rx, iq[pos:pos + m]); oc.push_many(iq[pos:pos + m]); pos += m
+            ctx.slot_boundary(mode, 25)
             ref = oc.boundary(25, want_f32=True)
             a, nv = ctx.fetch_audio_f32(ch)
             g = ctx.fetch_frame(ch)
