@@ -8,10 +8,15 @@ rounded to int16 [and, once enabled, the FT8 sync stage runs on every frame].  I
 in HBM before the timed region (each receiver's ring holds a full slot, filled by the device-side
 synthetic source; the timed region re-commits it lap after lap without copying).
 
+Workload.  N = 1 (the default): the north-star single-GPU workload, 4096 FT8 slots resident on ONE MI355X
+(94 GB of IQ + 20 GB of frames, checkpoints and spectra).  N > 1: BASELINE configs[3], 512 slots per GPU
+(4096 / 8), fixed per GPU as N grows ("weak").  --slots overrides either.
+
 One process per GPU.  N>1 is launched by torch.distributed.run; slots shard across ranks
-(slot s of rank r is global slot r*S+s) with no data-path collective; the only collective is a
-4-byte all-reduce on RCCL at every slot boundary (the north_star's "barrier on the mode's slot
-boundary").  value = all ranks' samples / max-over-ranks time.
+(slot s of rank r is global slot r*S+s) with no data-path collective; the only collective is an
+8-byte all-reduce on RCCL at every slot boundary (the north_star's "barrier on the mode's slot
+boundary"), issued from INSIDE cwslg_slot_boundary through the C ABI's rendezvous hook
+(cwslg_set_boundary_rendezvous).  value = all ranks' samples / max-over-ranks time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -70,7 +75,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--slots", type=int, default=512, help="FT8 slots per GPU")
+    ap.add_argument("--slots", type=int, default=0, help="FT8 slots per GPU (default: 4096 on one GPU = the north-star workload; 512 per GPU when N > 1 = configs[3])")
     ap.add_argument("--sync", type=int, default=1, help="run the FT8 sync stage (symbol spectra + Costas search) at every boundary")
     ap.add_argument("--channels-per-rx", type=int, default=1,
                     help="1 = private IQ stream per slot (BASELINE configs); C>1 = the reference's topology, C decoders share one receiver's IQ (<=8)")
@@ -79,7 +84,7 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses GPU 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
-    ap.add_argument("--verify", type=int, default=1, help="slots checked against the oracle after the timed region")
+    ap.add_argument("--verify", type=int, default=8, help="slots (spread over the whole range) checked against the oracle after the timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,8 +107,10 @@ def main():
             dist.init_process_group(args.dist_backend)
     dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
 
-    S = args.slots
+    S = args.slots if args.slots > 0 else (4096 if world == 1 else 512)
     ctx = P.Context(local_rank)
+    if world > 1:
+        shard.install_rendezvous(ctx, dev)     # cwslg_slot_boundary itself now ends in the all-reduce
     if args.exact:
         ctx.set_exact(True)
     if args.sync:
@@ -140,11 +147,8 @@ def main():
     def step(k):
         ctx.ring_commit_all(SLOT_SAMPLES, IQ_LEN)     # the slot's IQ is already in HBM: bookkeeping only
         ctx.process()                                  # batched NCO mix + polyphase decimate, all slots
-        ctx.slot_boundary("FT8", 15 * (k + 2))         # batched peak-normalise + int16 (+ sync) ; frames swap
-        if world > 1:
-            ctx.synchronize()                          # frames of this epoch are final on this GPU ...
-            total = shard.slot_boundary_rendezvous(S, dev)   # ... and on every other GPU: 4-byte RCCL all-reduce (frames finalised)
-            assert total == S * world
+        ctx.slot_boundary("FT8", 15 * (k + 2))         # batched peak-normalise + int16 (+ sync); frames swap; with N > 1 the call
+                                                       # waits for this GPU's stream and all-reduces the frame count over RCCL
     def barrier():
         ctx.synchronize()
         torch.cuda.synchronize()
@@ -164,6 +168,8 @@ def main():
     dt = time.perf_counter() - t0
     ctx.set_timing(False)
     st = ctx.stats()
+    if world > 1:
+        assert st["rendezvous_calls"] == args.steps and st["rendezvous_frames"] == S * world, st
 
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -180,7 +186,8 @@ def main():
         worst = 0.0
         mism = 0
         laps = args.warmup + args.steps
-        for s in range(min(args.verify, S)):
+        picks = sorted({int(round(x)) for x in np.linspace(0, S - 1, min(args.verify, S))})
+        for s in picks:
             f, tones, seed = freqs[s]
             ring = O.synth_iq(seed, cap, FS, tones_hz=tones, amp=2.0e4)    # ring content (sample index = ring index)
             start = ((laps - 1) * SLOT_SAMPLES) % cap
@@ -195,7 +202,7 @@ def main():
             peak = float(np.abs(ref["f32"]).max())
             worst = max(worst, float(np.abs(a.astype(np.float64) - ref["f32"]).max()) / peak)
             mism += int((g["i16"] != ref["i16"]).sum())
-        verify = {"slots_checked": min(args.verify, S), "max_rel_err": worst, "int16_mismatches": mism,
+        verify = {"slots_checked": len(picks), "slots": picks, "max_rel_err": worst, "int16_mismatches": mism,
                   "tolerance": 1e-5}
         if worst > 1e-5:
             print(f"PARITY FAILURE: {worst}", file=sys.stderr)
@@ -230,13 +237,16 @@ def main():
         samples_per_launch = S * SLOT_SAMPLES
         bps = 8.0 / C + 4.0 / 16                      # IQ is fetched once per receiver, audio written per channel
         achieved = bps * samples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
+        # HBM traffic cannot be counted from inside the process (PMC counters need rocprofv3): the figure is REPLAYED
+        # from the committed PMC summary of this same command and slot count, and labelled so
+        traffic, traffic_source = None, None
         tp = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
         if os.path.isfile(tp):
             try:
-                tj = json.load(open(tp))
-                if tj.get("slots") == S and C == 1 and not args.exact:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                for tj in json.load(open(tp)).get("runs", []):
+                    if tj.get("slots") == S and C == 1 and not args.exact:
+                        traffic = tj.get("hbm_bytes_per_launch")
+                        traffic_source = "replayed: " + tj.get("source", "profiles/traffic_per_launch.json")
             except Exception:
                 traffic = None
         out = {
@@ -245,12 +255,13 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{S} FT8 slots/GPU x 15 s (2.88 M IQ samples) at 192 kHz, " + ("private IQ stream per slot " if C == 1 else f"{C} slots share each receiver's IQ (reference topology) ") +
-                                   f"(BASELINE configs[3] share 4096/8=512 per GPU; same kernel as configs[1]'s 64 slots)",
+                                   ("(north_star: 4096 concurrent FT8 slots on ONE MI355X, all inputs resident in HBM)" if S == 4096 and world == 1 else
+                                    "(BASELINE configs[3]: 4096 slots sharded 512 per GPU)" if S == 512 else "(--slots override)"),
                        "slots_per_gpu": S, "channels_per_receiver": C, "fs_hz": FS, "iq_block": IQ_LEN, "stages": "nco-mix+polyphase-decimate, peak-normalise+int16" + (", ft8 symbol-spectra+costas-sync+candidates" if args.sync else ""),
-                       "sharding": f"slots x{world}, RCCL 4-byte all-reduce per slot boundary" if world > 1 else "single GPU"},
+                       "sharding": f"slots x{world}, one 8-byte RCCL all-reduce per slot boundary inside cwslg_slot_boundary" if world > 1 else "single GPU"},
             "realtime_ft8_slots": msps / 0.192,
             "roofline": {"bound": "hbm", "kernel": "demod_exact_kernel<16,256,256>" if args.exact else "demod_kernel<16,256,256,0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "bytes_per_sample": bps, "samples_per_launch": samples_per_launch,
                          "valu_tflops": 80.0 * samples_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
                          "avg_launch_ms": avg_ms, "launches": st["demod_launches"],

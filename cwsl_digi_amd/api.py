@@ -21,6 +21,7 @@ STATUS_NAMES = {
     -11: "ERR_BLOCK",
 }
 ERR_NO_FRAME = -9
+ERR_HIP = -8
 
 # CWSL_DIGI_Types.hpp:83-143
 GROUPS = {"FT8": 0, "FT4": 1, "Q65_30": 2, "S60": 3, "S120": 4, "S300": 5, "S900": 6, "S1800": 7}
@@ -90,8 +91,12 @@ class Stats(C.Structure):
                 ("finalize_launches", C.c_uint64), ("sync_launches", C.c_uint64), ("frames_emitted", C.c_uint64),
                 ("frames_discarded", C.c_uint64), ("blocks_dropped", C.c_uint64),
                 ("h2d_bytes", C.c_uint64), ("demod_ms", C.c_double), ("finalize_ms", C.c_double),
-                ("sync_ms", C.c_double)]
+                ("sync_ms", C.c_double), ("phasor_regrows", C.c_uint64), ("rendezvous_calls", C.c_uint64),
+                ("rendezvous_frames", C.c_uint64)]
 
+
+# int (*)(void *user, int group, uint64_t epoch_s, uint64_t frames_local, uint64_t *frames_total)
+RENDEZVOUS_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64))
 
 _lib = None
 
@@ -101,6 +106,7 @@ ABI_SYMBOLS = [
     "cwslg_set_scale_factors", "cwslg_set_exact", "cwslg_receiver_open", "cwslg_receiver_close", "cwslg_push_iq",
     "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_parse_decoder_line", "cwslg_channel_open_line", "cwslg_channel_open", "cwslg_channel_close", "cwslg_channel_tune",
     "cwslg_channel_info", "cwslg_process", "cwslg_slot_boundary", "cwslg_slot_boundary_channel",
+    "cwslg_set_boundary_rendezvous", "cwslg_rccl_unique_id", "cwslg_rccl_init",
     "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_write_wav", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
     "cwslg_enable_sync", "cwslg_fetch_candidates", "cwslg_set_ft4_syncmin", "cwslg_enable_ft4_coherent", "cwslg_fetch_ft4_sync", "cwslg_sync_debug_fetch", "cwslg_get_stats", "cwslg_reset_stats",
     "cwslg_set_timing", "cwslg_stream", "cwslg_channel_constants", "cwslg_phasor_checkpoint_stride", "cwslg_channel_phasor_checkpoints",
@@ -109,15 +115,25 @@ ABI_SYMBOLS = [
 ]
 
 
+def rccl_unique_id():
+    """128-byte ncclUniqueId made by this process (rank 0 hands it to the other ranks)."""
+    L = load_library()
+    buf = C.create_string_buffer(128)
+    rc = L.cwslg_rccl_unique_id(buf)
+    if rc < 0:
+        raise CwslGpuError(rc, L.cwslg_strerror(rc).decode())
+    return buf.raw
+
+
 def load_library(build_if_missing=True):
     """dlopen libcwslgpu.so.  Raises (never falls back) if it is absent and cannot be built."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.isfile(_LIB_PATH):
-        if not build_if_missing:
-            raise CwslGpuError(-7, f"{_LIB_PATH} not built")
-        _build.build()
+    if not build_if_missing and not os.path.isfile(_LIB_PATH):
+        raise CwslGpuError(-7, f"{_LIB_PATH} not built")
+    if build_if_missing and not os.environ.get("CWSLG_LIB"):
+        _build.build()          # returns at once when the library is newer than every source; serialised by a file lock
     try:
         # If torch is (or will be) in the process, let it load ITS libamdhip64 first: both copies carry
         # SONAME libamdhip64.so.7 and two HIP runtimes in one process do not share device pointers.
@@ -133,6 +149,9 @@ def load_library(build_if_missing=True):
     L.cwslg_last_error.argtypes = [vp]; L.cwslg_last_error.restype = C.c_char_p
     L.cwslg_set_scale_factors.argtypes = [vp, f32, f32]
     L.cwslg_set_exact.argtypes = [vp, i32]
+    L.cwslg_set_boundary_rendezvous.argtypes = [vp, RENDEZVOUS_FN, vp]
+    L.cwslg_rccl_unique_id.argtypes = [vp]
+    L.cwslg_rccl_init.argtypes = [vp, vp, i32, i32]
     L.cwslg_receiver_open.argtypes = [vp, u32, u32, C.c_int32, u32, C.POINTER(i32)]
     L.cwslg_receiver_close.argtypes = [vp, i32]
     L.cwslg_push_iq.argtypes = [vp, i32, vp, u32]
@@ -281,18 +300,6 @@ class Context:
         except Exception:
             pass
 
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        self.close()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
     def _chk(self, rc):
         if rc < 0:
             raise CwslGpuError(rc, self.L.cwslg_last_error(self.h).decode() or self.L.cwslg_strerror(rc).decode())
@@ -368,6 +375,30 @@ class Context:
         else:
             g = int(group)
         self._chk(self.L.cwslg_slot_boundary(self.h, g, int(epoch_s)))
+
+    def set_boundary_rendezvous(self, fn):
+        """Install the multi-GPU slot-boundary rendezvous: fn(group, epoch_s, frames_local) -> frames over all
+        processes (e.g. shard.slot_boundary_rendezvous over torch.distributed).  None removes it."""
+        if fn is None:
+            self._rdv_cb = None
+            self._chk(self.L.cwslg_set_boundary_rendezvous(self.h, RENDEZVOUS_FN(), None))
+            return
+
+        def tramp(_user, group, epoch_s, frames_local, total_out):
+            try:
+                total_out[0] = int(fn(int(group), int(epoch_s), int(frames_local)))
+                return 0
+            except Exception:                              # an exception must not unwind through the C caller
+                import traceback
+                traceback.print_exc()
+                return ERR_HIP
+        self._rdv_cb = RENDEZVOUS_FN(tramp)                 # keep the trampoline alive as long as it is installed
+        self._chk(self.L.cwslg_set_boundary_rendezvous(self.h, self._rdv_cb, None))
+
+    def rccl_init(self, unique_id, rank, world):
+        """Built-in RCCL rendezvous (what a C++ host uses): unique_id = bytes from rccl_unique_id() of rank 0."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self.L.cwslg_rccl_init(self.h, buf, int(rank), int(world)))
 
     def slot_boundary_channel(self, ch, epoch_s):
         self._chk(self.L.cwslg_slot_boundary_channel(self.h, ch, int(epoch_s)))

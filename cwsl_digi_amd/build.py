@@ -45,11 +45,23 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: libcwslgpu.so cannot be built (and there is no CPU fallback)")
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB] + sources()
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    build_skimmer(force=True, verbose=verbose)
+    # one builder at a time (N ranks may import together); the library appears atomically
+    import fcntl
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():          # another process built it while this one waited
+            return LIB
+        tmp = LIB + ".tmp.%d" % os.getpid()
+        cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp] + sources() + ["-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        build_skimmer(force=True, verbose=verbose)
     return LIB
 
 

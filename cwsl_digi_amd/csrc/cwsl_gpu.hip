@@ -7,6 +7,8 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC (see cwsl_digi_amd/build.py)
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types only: the library itself is opened lazily by cwslg_rccl_init (multi_gpu.inc)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cctype>
@@ -151,6 +153,11 @@ struct cwslg_ctx {
     SyncShared sync_shared;
     Ft4Tables ft4_tables{};
     bool ft4_dft_valu = false;         // CWSLG_FT4_DFT=valu
+    // multi-GPU slot-boundary rendezvous (multi_gpu.inc)
+    cwslg_rendezvous_fn rdv_fn = nullptr;
+    void *rdv_user = nullptr;
+    ncclComm_t rccl_comm = nullptr;
+    uint64_t *d_rdv = nullptr, *h_rdv = nullptr;   // [2]: local count, sum over ranks
 };
 
 namespace {
@@ -343,10 +350,70 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     return CWSLG_OK;
 }
 
+
+// Point a channel at the phasor table `new_key` (creating and scheduling it if nobody uses it yet) and drop its
+// reference to the old one.  Caller holds the mutex and has synchronised the stream if the old table may be in use.
+int retarget_phasor(cwslg_ctx *c, Channel &ch, const std::tuple<uint32_t, int32_t, int, size_t> &new_key, float2 inc)
+{
+    if (new_key == ch.phasor_key) return CWSLG_OK;
+    PhasorTable &pt = c->phasors[new_key];
+    if (pt.refs == 0) {
+        pt.d_ckpt = nullptr;
+        if (hipMalloc(&pt.d_ckpt, std::get<3>(new_key) * sizeof(float2)) != hipSuccess) {
+            c->phasors.erase(new_key);
+            return fail(c, CWSLG_ERR_NOMEM, "phasor table allocation failed");
+        }
+        pt.n_ckpt = std::get<3>(new_key);
+        pt.inc = inc;
+        pt.built = false;
+        c->phasor_todo.push_back(new_key);
+    }
+    pt.refs++;
+    auto it = c->phasors.find(ch.phasor_key);
+    if (it != c->phasors.end() && --it->second.refs == 0) {
+        c->phasor_todo.erase(std::remove(c->phasor_todo.begin(), c->phasor_todo.end(), ch.phasor_key), c->phasor_todo.end());
+        hipFree(it->second.d_ckpt);
+        c->phasors.erase(it);
+    }
+    ch.phasor_key = new_key;
+    return CWSLG_OK;
+}
+
+// Checkpoints a launch may touch for blocks [q_first, q_first + n_blocks): the last tile is walked whole (kTile + 31
+// blocks from its first input block) and every lane of phase 0 reads one checkpoint whether it is used or not.
+inline size_t ckpt_need(long long q_first, unsigned n_blocks)
+{
+    const long long tiles = ((long long)n_blocks + kTile - 1) / kTile;
+    const long long last = std::max<long long>(0, q_first + tiles * kTile + 31);
+    return (size_t)(last / kCkptStride) + 4;
+}
+
 // Demodulate everything pending.  Caller holds the mutex.
 int process_locked(cwslg_ctx *c)
 {
-    int rc = build_pending_phasors(c);
+    int rc = CWSLG_OK;
+    // The phasor recurrence restarts only when a frame is EMITTED (Instance.cpp:251).  A channel whose boundaries keep
+    // discarding (epoch 0, or a first boundary that arrives late) keeps counting blocks from its creation, so its
+    // checkpoint table is grown -- the same serial recurrence walked further, bit-identical -- before any launch
+    // could index past it.
+    for (size_t r = 0; r < c->rxs.size(); ++r) {
+        Receiver &rx = c->rxs[r];
+        if (!rx.open) continue;
+        for (int id : rx.channels) {
+            Channel &ch = c->chans[id];
+            if (!ch.open || ch.pend_n == 0) continue;
+            const size_t need = ckpt_need((ch.pend_lo - ch.origin_abs) / (int64_t)rx.D, ch.pend_n / rx.D);
+            const size_t have = std::get<3>(ch.phasor_key);
+            if (need <= have) continue;
+            HIPCHK(c, hipStreamSynchronize(c->stream));             // the old table may be in use by a queued launch
+            auto key = ch.phasor_key;
+            std::get<3>(key) = std::max(need, 2 * have);
+            rc = retarget_phasor(c, ch, key, make_float2(ch.k.inc.real(), ch.k.inc.imag()));
+            if (rc) return rc;
+            c->stats.phasor_regrows++;
+        }
+    }
+    rc = build_pending_phasors(c);
     if (rc) return rc;
     // one launch per distinct sample rate; channels grouped by receiver so that a receiver's channels are neighbours
     std::map<uint32_t, std::vector<ChanWork>> by_fs;
@@ -462,8 +529,9 @@ int reserve_ring(cwslg_ctx *c, Receiver &rx, uint32_t n)
     return CWSLG_OK;
 }
 
-int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s)
+int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s, uint64_t *n_emitted = nullptr)
 {
+    if (n_emitted) *n_emitted = 0;
     if (ids.empty()) return CWSLG_OK;
     int rc = process_locked(c);          // everything pushed so far belongs to the finishing slot
     if (rc) return rc;
@@ -519,6 +587,7 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s)
     HIPCHK(c, hipEventRecord(w->done, c->stream));
     w->in_flight = true;
     c->stats.finalize_launches++;
+    if (n_emitted) *n_emitted = emitted.size();
     // optional sync stage on the freshly finalised int16 frames
     if (c->sync_cfg.enabled && !emitted.empty()) {
         rc = sync_launch(c, emitted);
@@ -531,6 +600,8 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s)
 
 // sync stage glue (kept in its own file so this one stays readable)
 #include "sync_host.inc"
+// multi-GPU rendezvous: callback hook + the built-in RCCL form
+#include "multi_gpu.inc"
 
 // =============================================================================================
 extern "C" {
@@ -615,6 +686,7 @@ void cwslg_destroy(cwslg_ctx *c)
     }
     drain_spans(c);
     for (auto &p : c->ev_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    rccl_release(c);
     sync_free_shared(c->sync_shared);
     if (c->d_sincos) hipFree(c->d_sincos);
     if (c->h_stage) hipHostFree(c->h_stage);
@@ -897,7 +969,7 @@ int cwslg_channel_open(cwslg_ctx *c, int rx_id, int32_t demod_hz, int usb, const
     HIPCHK_FREE(hipStreamSynchronize(c->stream));   // k.tone is a temporary host vector: finish the copy now
     // phasor checkpoints: cover the first frame, which continues across the discarded partial slot
     // (up to 2 frames of blocks since creation), plus one tile of slack
-    const size_t n_ckpt = (2 * ch.frame_len + kTile + 64) / kCkptStride + 2;
+    const size_t n_ckpt = ckpt_need(2 * (long long)ch.frame_len, 0) + kTile / kCkptStride;
     ch.phasor_key = std::make_tuple(rx.fs, demod_hz, usb ? 1 : 0, n_ckpt);
     PhasorTable &pt = c->phasors[ch.phasor_key];
     if (pt.refs == 0) {
@@ -1046,28 +1118,7 @@ int cwslg_channel_tune(cwslg_ctx *c, int ch_id, int32_t demod_hz, int usb)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     DemodConstants k = make_constants(rx.fs, kSsbBw, f_hz, usb != 0);
     const auto new_key = std::make_tuple(rx.fs, demod_hz, usb ? 1 : 0, std::get<3>(ch.phasor_key));
-    if (new_key != ch.phasor_key) {
-        PhasorTable &pt = c->phasors[new_key];
-        if (pt.refs == 0) {
-            pt.d_ckpt = nullptr;
-            if (hipMalloc(&pt.d_ckpt, std::get<3>(new_key) * sizeof(float2)) != hipSuccess) {
-                c->phasors.erase(new_key);
-                return fail(c, CWSLG_ERR_NOMEM, "phasor table allocation failed");
-            }
-            pt.n_ckpt = std::get<3>(new_key);
-            pt.inc = make_float2(k.inc.real(), k.inc.imag());
-            pt.built = false;
-            c->phasor_todo.push_back(new_key);
-        }
-        pt.refs++;
-        auto it = c->phasors.find(ch.phasor_key);
-        if (it != c->phasors.end() && --it->second.refs == 0) {
-            c->phasor_todo.erase(std::remove(c->phasor_todo.begin(), c->phasor_todo.end(), ch.phasor_key), c->phasor_todo.end());
-            hipFree(it->second.d_ckpt);
-            c->phasors.erase(it);
-        }
-        ch.phasor_key = new_key;
-    }
+    if ((rc = retarget_phasor(c, ch, new_key, make_float2(k.inc.real(), k.inc.imag()))) != CWSLG_OK) return rc;
     ch.k = k;
     ch.demod_hz = demod_hz;
     ch.usb = usb != 0;
@@ -1104,12 +1155,30 @@ int cwslg_process(cwslg_ctx *c)
 int cwslg_slot_boundary(cwslg_ctx *c, int group, uint64_t epoch_s)
 {
     if (!c || group < 0 || group >= CWSLG_NUM_GROUPS) return CWSLG_ERR_ARG;
+    cwslg_rendezvous_fn fn = nullptr;
+    void *user = nullptr;
+    uint64_t mine = 0;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        hipSetDevice(c->device);
+        std::vector<int> ids;
+        for (size_t k = 0; k < c->chans.size(); ++k)
+            if (c->chans[k].open && c->chans[k].group == group) ids.push_back((int)k);
+        int rc = boundary_locked(c, ids, epoch_s, &mine);
+        if (rc) return rc;
+        fn = c->rdv_fn;
+        user = c->rdv_user;
+        if (!fn) return CWSLG_OK;
+        HIPCHK(c, hipStreamSynchronize(c->stream));        // this GPU's frames of the epoch are final ...
+        drain_spans(c);
+    }
+    uint64_t total = mine;                                  // ... and after the rendezvous so are every other GPU's
+    const int rc = fn(user, group, epoch_s, mine, &total);
     std::lock_guard<std::mutex> g(c->mu);
-    hipSetDevice(c->device);
-    std::vector<int> ids;
-    for (size_t k = 0; k < c->chans.size(); ++k)
-        if (c->chans[k].open && c->chans[k].group == group) ids.push_back((int)k);
-    return boundary_locked(c, ids, epoch_s);
+    if (rc < 0) return fail(c, rc, "slot-boundary rendezvous failed (%d)", rc);
+    c->stats.rendezvous_calls++;
+    c->stats.rendezvous_frames = total;
+    return CWSLG_OK;
 }
 
 int cwslg_slot_boundary_channel(cwslg_ctx *c, int ch_id, uint64_t epoch_s)

@@ -76,7 +76,9 @@ int usage()
     std::fprintf(stderr,
         "usage: cwsl_gpu_skimmer --config config.ini --rx file=PATH|-[,header=1][,fs=N,block=N,lo=HZ] [--rx udp=PORT,fs=..]...\n"
         "         --out DIR [--start-ms UTC_MS] [--pace samples|wall] [--exact] [--sync 0|1] [--wav route|always|never]\n"
-        "         [--max-seconds S] [--device N] [--dry-run]\n");
+        "         [--max-seconds S] [--device N] [--dry-run]\n"
+        "         [--world N --rank R --rccl-id FILE]   one process per GPU: decoders shard by receiver (receiver k -> rank k mod N),\n"
+        "                                               RCCL rendezvous at every slot boundary; rank 0 writes FILE, the others read it\n");
     return 2;
 }
 
@@ -95,7 +97,8 @@ int main(int argc, char **argv)
     std::vector<std::string> rx_args;
     uint64_t start_ms = 0;
     bool exact = false, dry = false, have_start = false;
-    int sync = 1, device = -1;
+    int sync = 1, device = -1, world = 1, rank = 0;
+    std::string rccl_id_path;
     double max_seconds = 0;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -110,11 +113,15 @@ int main(int argc, char **argv)
         else if (a == "--sync" && (v = need("sync"))) sync = std::atoi(v);
         else if (a == "--device" && (v = need("device"))) device = std::atoi(v);
         else if (a == "--max-seconds" && (v = need("max"))) max_seconds = std::atof(v);
+        else if (a == "--world" && (v = need("world"))) world = std::atoi(v);
+        else if (a == "--rank" && (v = need("rank"))) rank = std::atoi(v);
+        else if (a == "--rccl-id" && (v = need("id"))) rccl_id_path = v;
         else if (a == "--exact") exact = true;
         else if (a == "--dry-run") dry = true;
         else return usage();
     }
     if (cfg_path.empty() || rx_args.empty()) return usage();
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && rccl_id_path.empty())) return usage();
 
     SkimmerConfig cfg;
     if (!load_config(cfg_path.c_str(), cfg)) { std::fprintf(stderr, "config: %s\n", cfg.error.c_str()); return 1; }
@@ -134,6 +141,23 @@ int main(int argc, char **argv)
         c.rx = find_band(los.data(), fss.data(), (int)rxs.size(), (int64_t)d.calibrated_hz);
         if (c.rx < 0) { std::fprintf(stderr, "decoder %u %s: no receiver covers it\n", d.freq_hz, d.mode); return 1; }
         chans.push_back(c);
+    }
+    // one process per GPU: a band's IQ goes to exactly one GPU (the reference creates one Receiver per
+    // band, CWSL_DIGI.cpp:115-129), so receiver k and all of its decoders belong to rank k mod world
+    if (world > 1) {
+        std::vector<Chan> mine;
+        for (const Chan &c : chans) if (c.rx % world == rank) mine.push_back(c);
+        chans.swap(mine);
+        std::vector<std::string> lines;
+        {
+            size_t k = 0;
+            for (const cwslg_decoder_spec &d : cfg.decoders) {
+                const int rx = find_band(los.data(), fss.data(), (int)rxs.size(), (int64_t)d.calibrated_hz);
+                if (rx % world == rank) lines.push_back(cfg.decoder_lines[k]);
+                ++k;
+            }
+        }
+        cfg.decoder_lines.swap(lines);
     }
     if (!have_start) start_ms = (uint64_t)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count();
 
@@ -157,11 +181,39 @@ int main(int argc, char **argv)
     int rc = cwslg_create(&ctx, device);
     if (rc != CWSLG_OK) { std::fprintf(stderr, "cwslg_create: %s\n", cwslg_strerror(rc)); return 3; }
     auto die = [&](const char *what, int code) { std::fprintf(stderr, "%s: %s (%s)\n", what, cwslg_strerror(code), cwslg_last_error(ctx)); cwslg_destroy(ctx); std::exit(4); };
-    cwslg_set_scale_factors(ctx, cfg.ft_scale, cfg.wspr_scale);
-    if (exact) cwslg_set_exact(ctx, 1);
-    if (sync) cwslg_enable_sync(ctx, 1, 1.5f, 200, 200, cfg.highest_decode_hz);
-    for (Rx &r : rxs)
+    if ((rc = cwslg_set_scale_factors(ctx, cfg.ft_scale, cfg.wspr_scale)) != CWSLG_OK) die("set_scale_factors", rc);
+    if (exact && (rc = cwslg_set_exact(ctx, 1)) != CWSLG_OK) die("set_exact", rc);
+    if (sync && (rc = cwslg_enable_sync(ctx, 1, 1.5f, 200, 200, cfg.highest_decode_hz)) != CWSLG_OK) {
+        // e.g. wsjtx.highestdecodefreq <= 200: no candidate search is possible; frames are still produced
+        std::fprintf(stderr, "sync stage disabled: %s (%s)\n", cwslg_strerror(rc), cwslg_last_error(ctx));
+        sync = 0;
+    }
+    if (world > 1) {
+        // ncclUniqueId hand-over through a file: rank 0 creates it (written whole, then renamed), the others wait for it
+        unsigned char id[CWSLG_RCCL_ID_BYTES];
+        if (rank == 0) {
+            if ((rc = cwslg_rccl_unique_id(id)) != CWSLG_OK) die("rccl_unique_id", rc);
+            const std::string tmp = rccl_id_path + ".tmp";
+            FILE *f = std::fopen(tmp.c_str(), "wb");
+            if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id) { std::fprintf(stderr, "cannot write %s\n", tmp.c_str()); return 1; }
+            std::fclose(f);
+            std::rename(tmp.c_str(), rccl_id_path.c_str());
+        } else {
+            bool got = false;
+            for (int tries = 0; tries < 600 && !got; ++tries) {
+                FILE *f = std::fopen(rccl_id_path.c_str(), "rb");
+                if (f) { got = std::fread(id, 1, sizeof id, f) == sizeof id; std::fclose(f); }
+                if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+            }
+            if (!got) { std::fprintf(stderr, "no RCCL id in %s after 60 s\n", rccl_id_path.c_str()); return 1; }
+        }
+        if ((rc = cwslg_rccl_init(ctx, id, rank, world)) != CWSLG_OK) die("rccl_init", rc);
+    }
+    for (size_t k = 0; k < rxs.size(); ++k) {
+        Rx &r = rxs[k];
+        if ((int)(k % (size_t)world) != rank) { r.eof = true; continue; }           // another GPU's band
         if ((rc = cwslg_receiver_open(ctx, r.spec.fs, r.spec.block, (int32_t)r.spec.lo, 0, &r.id)) != CWSLG_OK) die("receiver_open", rc);
+    }
     std::set<int> groups;
     for (size_t k = 0; k < chans.size(); ++k) {
         Chan &c = chans[k];
@@ -169,9 +221,14 @@ int main(int argc, char **argv)
         groups.insert(c.spec.group);
     }
 
+    // every rank fires every group's boundaries, also for groups it owns no decoder of: the rendezvous inside
+    // cwslg_slot_boundary is a collective, all ranks must make the same sequence of calls
+    if (world > 1) for (const cwslg_decoder_spec &d : cfg.decoders) groups.insert(d.group);
+    if (world > (int)rxs.size()) { std::fprintf(stderr, "--world %d exceeds the %zu receivers: a rank would own no band\n", world, rxs.size()); cwslg_destroy(ctx); return 1; }
+
     std::string log_path = out_dir + "/frames.jsonl";
     FILE *log = std::fopen(log_path.c_str(), "w");
-    if (!log) { std::fprintf(stderr, "cannot write %s\n", log_path.c_str()); return 1; }
+    if (!log) { std::fprintf(stderr, "cannot write %s\n", log_path.c_str()); cwslg_destroy(ctx); return 1; }
 
     // next boundary instant per group
     std::vector<std::pair<int, uint64_t>> next_edge;
@@ -220,10 +277,11 @@ int main(int argc, char **argv)
                     }
                 } else if (rc != CWSLG_ERR_NO_FRAME) die("fetch_ft4_sync", rc);
             }
-            char app[64], opts[1024];
+            char app[64] = "", opts[1024] = "";
             const std::string target = route == 1 ? std::string("<shmem-key>") : wav;
-            cwslg_decoder_command(c.spec.mode, route, cfg.numjt9threads, cfg.decodedepth, cfg.highest_decode_hz, cfg.wspr_cycles,
-                                  c.spec.period_s, target.c_str(), app, sizeof app, opts, sizeof opts);
+            if (cwslg_decoder_command(c.spec.mode, route, cfg.numjt9threads, cfg.decodedepth, cfg.highest_decode_hz, cfg.wspr_cycles,
+                                      c.spec.period_s, target.c_str(), app, sizeof app, opts, sizeof opts) != CWSLG_OK)
+                app[0] = opts[0] = 0;                             // "Mode ... not handled": no command to report
             std::fprintf(log, "{\"t_start\": %" PRIu64 ", \"freq_hz\": %u, \"mode\": \"%s\", \"n_valid\": %zu, \"factor\": %.9g, \"candidates\": %d, \"ft4_refined\": %d, "
                               "\"route\": \"%s\", \"wav\": \"%s\", \"app\": \"%s\", \"opts\": \"%s\"}\n",
                          t0, c.spec.freq_hz, c.spec.mode, nv, factor, ncand, nref, route == 1 ? "shmem" : "wavefile",
@@ -235,6 +293,7 @@ int main(int argc, char **argv)
 
     for (Rx &r : rxs) {
         r.queue.reset(new BlockQueue);
+        if (r.eof) { r.queue->finish(); continue; }            // not this rank's band
         r.queue->cap = 3 * (size_t)(r.spec.fs / r.spec.block + 1);             // Receiver.hpp:132
         Rx *pr = &r;
         r.reader = std::thread([pr] {

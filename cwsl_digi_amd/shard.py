@@ -27,6 +27,15 @@ def slot_boundary_rendezvous(frames_this_rank, device=None):
     Works with any initialised backend ("nccl" = RCCL on ROCm, "gloo" on CPU)."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return int(frames_this_rank)
-    t = torch.tensor([int(frames_this_rank)], dtype=torch.int32, device=device or "cpu")
+    if device is None:                     # RCCL reduces device tensors, gloo host tensors
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(frames_this_rank)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t.item())
+
+
+def install_rendezvous(ctx, device=None):
+    """Put the rendezvous behind the C ABI: cwslg_slot_boundary() itself then waits for its own stream, calls this
+    all-reduce and records the job-wide frame count (stats()["rendezvous_frames"]) -- the host program, Python or
+    C++, only ever calls slot_boundary."""
+    ctx.set_boundary_rendezvous(lambda group, epoch_s, frames: slot_boundary_rendezvous(frames, device))

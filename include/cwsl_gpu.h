@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CWSLG_ABI_VERSION 1
+#define CWSLG_ABI_VERSION 2
 
 /* ---- status codes ---- */
 #define CWSLG_OK                  0
@@ -154,6 +154,25 @@ int cwslg_slot_boundary(cwslg_ctx *ctx, int group, uint64_t epoch_s);
 int cwslg_slot_boundary_channel(cwslg_ctx *ctx, int ch_id, uint64_t epoch_s);
 int cwslg_synchronize(cwslg_ctx *ctx);
 
+/* ---- multi-GPU: the slot-boundary rendezvous ----
+ * Channels never exchange data (Instance.cpp:260-276 reads its receiver's IQ and nothing else), so decoders shard over
+ * one process per GPU -- by receiver first, as CWSL_DIGI.cpp:115-129 creates one Receiver per band -- with no data-path
+ * collective.  What the reference's shared SyncPredicates give it for free (CWSL_DIGI_Types.hpp:83-143: every Instance
+ * of a period family sees the same store(true)) becomes one tiny collective here: when a rendezvous is installed,
+ * cwslg_slot_boundary() -- after it has queued finalise (+ sync) for its own channels and waited for its stream --
+ * calls it with the number of frames this process emitted for the epoch and receives the total over all processes, so
+ * every GPU publishes the epoch together.  The callback runs on the calling thread with the context unlocked; it must
+ * not call back into the same context.  Return 0 or a negative CWSLG_ERR_*; the total is kept in the stats. */
+typedef int (*cwslg_rendezvous_fn)(void *user, int group, uint64_t epoch_s, uint64_t frames_local, uint64_t *frames_total);
+int cwslg_set_boundary_rendezvous(cwslg_ctx *ctx, cwslg_rendezvous_fn fn, void *user);
+/* Built-in rendezvous for C/C++ hosts: a 1-element uint64 sum all-reduce on RCCL over xGMI, enqueued on the context
+ * stream.  librccl is opened on first use (a process that already carries one, e.g. torch's, shares it).
+ * cwslg_rccl_unique_id fills the 128-byte ncclUniqueId on rank 0; the host program hands it to the other ranks by any
+ * means (cwsl_gpu_skimmer: a file); every rank then calls cwslg_rccl_init, which installs the rendezvous. */
+#define CWSLG_RCCL_ID_BYTES 128
+int cwslg_rccl_unique_id(void *id_out);
+int cwslg_rccl_init(cwslg_ctx *ctx, const void *id, int rank, int world);
+
 /* ---- results: replaces decoderPool->push(ItemToDecode(audio_i16, ...)) (Instance.cpp:244-245) ----
  * Copies the last finalised frame of the channel: frame_len = 12000*(period+5) int16 samples with the
  * reference's zero tail; *n_valid = samples actually demodulated in the slot; *start_epoch = the frame's
@@ -270,6 +289,9 @@ typedef struct {
     double   demod_ms;             /* HIP-event time of demod kernels on the context stream   */
     double   finalize_ms;
     double   sync_ms;
+    uint64_t phasor_regrows;       /* checkpoint tables extended because a channel kept discarding frames */
+    uint64_t rendezvous_calls;     /* slot boundaries that went through the multi-GPU rendezvous          */
+    uint64_t rendezvous_frames;    /* frames over ALL processes at the last rendezvous                    */
 } cwslg_stats;
 int cwslg_get_stats(cwslg_ctx *ctx, cwslg_stats *out);
 int cwslg_reset_stats(cwslg_ctx *ctx);

@@ -1,0 +1,97 @@
+"""GPU: the slot-boundary rendezvous BEHIND the C ABI (include/cwsl_gpu.h, multi_gpu.inc).
+
+1. Two processes, each owning a real Context on the one GPU of the test box, shard 6 FT8 slots 3 + 3; the rendezvous
+   installed through cwslg_set_boundary_rendezvous is carried by gloo (on a multi-GPU node the same hook carries RCCL:
+   bench.py installs torch.distributed's "nccl" all-reduce, a C++ host calls cwslg_rccl_init).  Every
+   cwslg_slot_boundary call then returns the job-wide frame count in the stats, and the frames of each shard are what
+   an unsharded run produces (compared through a checksum gathered over the process group).
+2. The built-in RCCL form with world size 1: librccl is opened, ncclCommInitRank / ncclAllReduce run on the context
+   stream (one rank is all this box can host; N ranks differ only in the communicator's size)."""
+import os
+import socket
+import zlib
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+FS, BLK = 192000, 2048
+TOTAL, N = 6, 64 * BLK
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _slot_freq(gs):
+    return -90000 + (gs * 4373) % 176000
+
+
+def _run_slots(ctx, slot_ids):
+    chans = []
+    for gs in slot_ids:
+        f = _slot_freq(gs)
+        rx = ctx.receiver_open(FS, BLK, 0, ring_blocks=N // BLK + 8)
+        ch = ctx.channel_open(rx, f, "FT8")
+        chans.append((gs, rx, ch))
+    ctx.slot_boundary("FT8", 1)                       # discarded partial slot: rendezvous carries 0 frames
+    first = ctx.stats()["rendezvous_frames"]
+    for gs, rx, ch in chans:
+        f = _slot_freq(gs)
+        ctx.push_synth(rx, 0xC0FFEE ^ gs, N, BLK, tones_hz=[f + 650.0, f + 1490.0], amp=2e4)
+    ctx.slot_boundary("FT8", 16)
+    crcs = {gs: zlib.crc32(ctx.fetch_frame(ch)["i16"].tobytes()) for gs, rx, ch in chans}
+    return first, ctx.stats(), crcs
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cwsl_digi_amd as P
+    from cwsl_digi_amd import shard
+    with P.Context(0) as ctx:                         # both ranks on GPU 0: the test box has one
+        shard.install_rendezvous(ctx)
+        mine = list(shard.slots_of_rank(TOTAL, rank, world))
+        first, st, crcs = _run_slots(ctx, mine)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, crcs)
+    q.put((rank, first, st["rendezvous_calls"], st["rendezvous_frames"], st["frames_emitted"], gathered))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_rendezvous_through_the_c_abi():
+    world = 2
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    ps = [mpc.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(120)
+        assert p.exitcode == 0
+    import cwsl_digi_amd as P
+    with P.Context(0) as ctx:                         # unsharded reference run in this process
+        _, st, full = _run_slots(ctx, range(TOTAL))
+        assert st["rendezvous_calls"] == 0            # no hook installed: single-GPU behaviour unchanged
+    for rank, first, calls, total, emitted, gathered in res:
+        assert first == 0 and calls == 2
+        assert emitted == TOTAL // world and total == TOTAL     # own frames vs job-wide frames of the epoch
+        merged = {}
+        for part in gathered:
+            merged.update(part)
+        assert merged == full                          # shard r's frames == the unsharded run's, slot for slot
+
+
+def test_builtin_rccl_rendezvous_world_1():
+    import cwsl_digi_amd as P
+    uid = P.rccl_unique_id()
+    assert len(uid) == 128
+    with P.Context(0) as ctx:
+        ctx.rccl_init(uid, 0, 1)
+        first, st, crcs = _run_slots(ctx, range(3))
+        assert first == 0 and st["rendezvous_calls"] == 2 and st["rendezvous_frames"] == 3 == st["frames_emitted"]

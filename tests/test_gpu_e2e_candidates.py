@@ -1,0 +1,55 @@
+"""GPU: candidate lists END TO END from IQ -- the product chain against the reference chain, sharing nothing but the IQ.
+
+    reference chain: IQ -> SSBD/framing/prepareAudio/int16 (oracle.Channel, pinned to the compiled reference headers)
+                        -> sync restatement on THAT frame
+    product chain:   IQ -> cwslg_push_iq ... cwslg_fetch_candidates (+ cwslg_fetch_ft4_sync)
+
+Exact mode (cwslg_set_exact): the int16 frames are bit-identical, hence so is every list -- asserted.
+Default (throughput) mode: the float audio differs from the reference chain's by <= 4e-7 of frame peak, so the int16
+frames differ by 1 LSB at ~0.1 % of the samples (rounding ties); the sync arithmetic is float32 on those frames, so the
+lists can only be compared within a tolerance.  Asserted here (measured values: profiles/r2_e2e_candidates.json,
+DESIGN.md section 6d): the same (bin, lag) keys except keys whose sync sits within 1e-3 of a cut (syncmin, or the last
+rank kept), shared keys' sync within 1e-3 relative -- the north_star's float tolerance is 1e-5 on AUDIO; a ratio of
+sums of |X|^2 over 21 symbols of +-1 LSB-perturbed int16 moves more than the audio does.
+"""
+import numpy as np
+import pytest
+
+import e2e_candidates as E
+
+pytestmark = pytest.mark.gpu
+N_SLOTS = 8
+
+
+@pytest.fixture(scope="module")
+def chains(oracle):
+    out = {}
+    for mode, seed0 in (("FT8", 4100), ("FT4", 4200)):
+        slots = E.make_slots(oracle, mode, N_SLOTS, seed0)
+        out[mode] = (slots, E.run_oracle(oracle, mode, slots))
+    return out
+
+
+@pytest.mark.parametrize("mode", ["FT8", "FT4"])
+def test_exact_mode_lists_bit_identical_end_to_end(ctx, chains, mode):
+    slots, ref = chains[mode]
+    gpu = E.run_gpu(ctx, mode, slots, exact=True)
+    rep = E.compare(mode, gpu, ref, 1.5 if mode == "FT8" else 1.2)
+    assert rep["int16_mismatches"] == [0] * N_SLOTS
+    assert rep["identical_lists"] == N_SLOTS and min(rep["n_cands"]) >= 3
+    if mode == "FT4":
+        assert rep["ft4_records_identical"] == N_SLOTS
+
+
+@pytest.mark.parametrize("mode", ["FT8", "FT4"])
+def test_default_mode_lists_within_tolerance_end_to_end(ctx, chains, mode):
+    slots, ref = chains[mode]
+    gpu = E.run_gpu(ctx, mode, slots, exact=False)
+    rep = E.compare(mode, gpu, ref, 1.5 if mode == "FT8" else 1.2)
+    print(rep)
+    n = 240000 if mode == "FT8" else 150000
+    assert max(rep["int16_mismatches"]) <= 0.005 * n            # +-1 LSB ties only (tests/conftest.py::assert_int16_match)
+    assert rep["only_one_side_not_marginal"] == 0                # same candidates, except at a cut
+    assert rep["worst_rel_sync"] <= 1e-3
+    if mode == "FT4":
+        assert rep["ft4_worst_f1_hz"] <= 1.0 and rep["ft4_worst_dt_s"] <= 2.0 / 666.67

@@ -1,0 +1,117 @@
+"""GPU: the BASELINE.json configurations at FULL size (the driver's `-m gpu` run sees them, not only the builder).
+
+configs[1]  64 FT8 slots x 15 s on one GPU
+configs[2]  768 FT8 + 256 FT4 slots, two slot clocks (FT4 fires twice per FT8 slot), sync stage on
+configs[4]  128 WSPR + 128 FST4W-120 slots x 120 s (47 GB of IQ resident)
+north_star  4096 FT8 slots x 15 s resident on ONE MI355X (94 GB of IQ)
+Every slot's IQ comes from the device-side synthetic source, which is bit-identical to the oracle's generator, so a few
+slots spread over the range are re-derived on the CPU and checked in full: float audio within 1e-5 of frame peak,
+int16 equal up to +-1 LSB rounding ties, FT8/FT4 candidate lists bit-identical to the restatement run on the GPU frame.
+Size-independent properties cover ALL slots: frame counts, valid-sample counts, a finite non-zero scale factor.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_frames_match, assert_int16_match
+
+pytestmark = pytest.mark.gpu
+FS, BLK = 192000, 2048
+PERIOD = {"FT8": 15, "FT4": 7.5, "WSPR": 120, "FST4W-120": 120}
+GROUP = {"FT8": "FT8", "FT4": "FT4", "WSPR": "S120", "FST4W-120": "S120"}
+
+
+def _freq(gs):
+    return -90000 + (gs * 4373) % 176000
+
+
+def _tones(f, gs):
+    return [f + 600.0 + 37.0 * (gs % 11), f + 1500.0, f + 2450.0 - 13.0 * (gs % 7)]
+
+
+def _run(ctx, oracle, modes, check, sync=False):
+    """modes: list of mode names, one per slot.  One step = the longest period present; shorter modes fire their own
+    boundaries inside it (FT4: two frames per FT8 slot)."""
+    longest = max(PERIOD[m] for m in modes)
+    n_long = int(longest * FS) // BLK * BLK
+    if sync:
+        ctx.enable_sync(True, 1.5, 200, 200, 3000)
+    slots = []
+    for gs, mode in enumerate(modes):
+        f = _freq(gs)
+        rx = ctx.receiver_open(FS, BLK, 0, ring_blocks=n_long // BLK + 4)
+        ctx.push_synth(rx, 0xC0FFEE ^ gs, n_long, BLK, tones_hz=_tones(f, gs), amp=2.0e4)    # resident before any channel exists
+        ch = ctx.channel_open(rx, f, mode)
+        slots.append((rx, ch, mode, f, gs))
+    for g in sorted({GROUP[m] for m in modes}):
+        ctx.slot_boundary(g, 100)                              # every clock fires at t = 0: partial-slot frames, discarded
+    # one long period of IQ, committed in the pieces the shortest clock needs
+    shortest = min(PERIOD[m] for m in modes)
+    parts = int(round(longest / shortest))
+    piece = n_long // parts // BLK * BLK
+    frames = {}
+    for part in range(parts):
+        ctx.ring_commit_all(piece, BLK)
+        for g in sorted({GROUP[m] for m in modes}):
+            per = min(PERIOD[m] for m in modes if GROUP[m] == g)
+            if (part + 1) % int(round(per / shortest)) == 0:
+                ctx.slot_boundary(g, 100 + int((part + 1) * shortest))
+        if part == 0:
+            for k in check:
+                rx, ch, mode, f, gs = slots[k]
+                if PERIOD[mode] == shortest and parts > 1:
+                    frames[(k, 0)] = (ctx.fetch_frame(ch), ctx.fetch_audio_f32(ch), ctx.fetch_candidates(ch, 200) if sync else None)
+    ctx.synchronize()
+    st = ctx.stats()
+    n_emit = sum(int(round(longest / PERIOD[m])) for m in modes)
+    assert st["frames_emitted"] == n_emit and st["frames_discarded"] == len(modes) and st["blocks_dropped"] == 0
+    # every slot: a whole frame of the right length came out
+    for rx, ch, mode, f, gs in slots:
+        g = ctx.fetch_frame(ch)
+        per_samples = piece * int(round(PERIOD[mode] / shortest))
+        assert g is not None and g["n_valid"] == per_samples // 16 and len(g["i16"]) == int(12000 * (PERIOD[mode] + 5))
+        assert np.isfinite(g["factor"]) and 0 < g["factor"] < 1e3
+    # a few slots in full against the oracle
+    worst = 0.0
+    for k in check:
+        rx, ch, mode, f, gs = slots[k]
+        reps = int(round(longest / PERIOD[mode]))
+        per_samples = piece * int(round(PERIOD[mode] / shortest))
+        iq = oracle.synth_iq(0xC0FFEE ^ gs, n_long, FS, tones_hz=_tones(f, gs), amp=2.0e4)
+        oc = oracle.Channel(mode, FS, BLK, f)
+        assert oc.boundary(100) is None
+        for rep in range(reps):
+            oc.push_many(iq[rep * per_samples:(rep + 1) * per_samples])
+            r = oc.boundary(100 + int((rep + 1) * PERIOD[mode]), want_f32=True)
+            if rep == reps - 1:
+                got = (ctx.fetch_frame(ch), ctx.fetch_audio_f32(ch), ctx.fetch_candidates(ch, 200) if sync and mode in ("FT8", "FT4") else None)
+            elif (k, rep) in frames:
+                got = frames[(k, rep)]
+            else:
+                continue
+            g, (a, nv), cands = got
+            assert g["t_start"] == r["t_start"] and nv == per_samples // 16
+            worst = max(worst, assert_frames_match(a, r["f32"]))
+            assert_int16_match(g["i16"], r["i16"], r["f32"] * r["factor"])
+            if cands is not None:
+                ref = oracle.ft8_sync(g["i16"], 200, 3000, 1.5, 200) if mode == "FT8" else oracle.ft4_candidates(g["i16"], 200.0, 3000.0, 1.2, 200)
+                bits = lambda c: (c[0], c[1], np.float32(c[2]).view(np.uint32), np.float32(c[3]).view(np.uint32))
+                assert [bits(c) for c in cands] == [bits(c) for c in ref]
+    return worst
+
+
+def test_config1_64_ft8_slots(ctx, oracle):
+    _run(ctx, oracle, ["FT8"] * 64, check=[0, 21, 42, 63])
+
+
+def test_config2_768_ft8_256_ft4_with_sync(ctx, oracle):
+    modes = ["FT8"] * 768 + ["FT4"] * 256
+    _run(ctx, oracle, modes, check=[0, 401, 767, 768, 900, 1023], sync=True)
+
+
+def test_config4_128_wspr_128_fst4w(ctx, oracle):
+    modes = ["WSPR" if s % 2 == 0 else "FST4W-120" for s in range(256)]
+    _run(ctx, oracle, modes, check=[0, 85, 170, 255])
+
+
+def test_north_star_4096_ft8_slots_on_one_gpu(ctx, oracle):
+    _run(ctx, oracle, ["FT8"] * 4096, check=[0, 1365, 2730, 4095], sync=True)

@@ -78,3 +78,58 @@ def test_concurrent_push_boundary_fetch(ctx, oracle):
     ctx.slot_boundary("FT8", 10 ** 6)
     st = ctx.stats()
     assert st["demod_samples"] == n_rx * blocks * BLK      # every pushed sample was demodulated exactly once
+
+
+def test_repeated_discards_keep_the_phasor_running(ctx, oracle):
+    """Boundaries stamped 0 discard their frame WITHOUT restarting the demodulator (Instance.cpp:224-227 `continue`
+    skips :251), so the phasor recurrence and the filter history run on from channel creation for as many slots as
+    that lasts.  Three discarded 7.5 s slots put the block count past the checkpoint table sized at open (two frames):
+    the table is extended (stats: phasor_regrows) and the first emitted frame still equals the oracle driven with the
+    same pushes and boundaries."""
+    n = 1440000 // BLK * BLK                       # one FT4 slot of whole blocks
+    f = 31000
+    iq = oracle.synth_iq(77, 4 * n, FS, tones_hz=[f + 900.0, f + 2222.0], amp=1.2e4)
+    rx = ctx.receiver_open(FS, BLK, 0)
+    ch = ctx.channel_open(rx, f, "FT4")
+    oc = oracle.Channel("FT4", FS, BLK, f)
+    epochs = [0, 0, 0, 7, 15]                      # frames started at epoch 0 are discarded when they end
+    ctx.slot_boundary("FT4", epochs[0]); assert oc.boundary(epochs[0]) is None
+    for part in range(4):
+        seg = iq[part * n:(part + 1) * n]
+        for k in range(0, n, 100 * BLK):
+            ctx.push_iq(rx, seg[k:k + 100 * BLK])
+        oc.push_many(seg)
+        ctx.slot_boundary("FT4", epochs[part + 1])
+        r = oc.boundary(epochs[part + 1], want_f32=True)
+        g = ctx.fetch_frame(ch)
+        if part < 3:
+            assert r is None and g is None         # discarded on both sides
+        else:
+            a, nv = ctx.fetch_audio_f32(ch)
+            assert g["t_start"] == r["t_start"] == 7 and nv == n // 16
+            assert_frames_match(a, r["f32"])
+    st = ctx.stats()
+    assert st["frames_discarded"] == 4 and st["frames_emitted"] == 1 and st["phasor_regrows"] >= 1
+
+
+def test_late_first_boundary_saturates_then_recovers(ctx, oracle):
+    """No boundary for longer than period + 5 s after open: the frame fills up, later blocks are dropped ("af buffer
+    full", Instance.cpp:268-271), the late boundary discards the partial-slot frame, and the next slot is demodulated
+    from a valid checkpoint range (no read past the phasor table) -- its frame is finite and spectrally right."""
+    n = 2000 * BLK                                  # 21.3 s > FT4's 12.5 s frame
+    f = -12000
+    rx = ctx.receiver_open(FS, BLK, 0)
+    ch = ctx.channel_open(rx, f, "FT4")
+    for k in range(0, n, 250 * BLK):
+        ctx.push_synth(rx, 5, 250 * BLK, BLK, tones_hz=[f + 1000.0], amp=1e4)
+    assert ctx.stats()["blocks_dropped"] > 0
+    ctx.slot_boundary("FT4", 0)                     # late first boundary: discard
+    assert ctx.fetch_frame(ch) is None
+    ctx.push_synth(rx, 5, 600 * BLK, BLK, tones_hz=[f + 1000.0], amp=1e4)
+    ctx.slot_boundary("FT4", 8)                     # frame started at epoch 0: discarded as well, demodulator keeps running
+    ctx.push_synth(rx, 5, 600 * BLK, BLK, tones_hz=[f + 1000.0], amp=1e4)
+    ctx.slot_boundary("FT4", 16)
+    a, nv = ctx.fetch_audio_f32(ch)
+    assert nv == 600 * BLK // 16 and np.isfinite(a).all()
+    spec = np.abs(np.fft.rfft(a[2000:2000 + 48000].astype(np.float64)))
+    assert abs(int(np.argmax(spec)) * 12000.0 / 48000 - 1000.0) < 1.0      # the 1 kHz tone, at the right audio pitch

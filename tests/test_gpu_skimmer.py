@@ -140,7 +140,7 @@ def test_skimmer_udp_source(tmp_path, oracle):
     port = 47000 + os.getpid() % 1000
     start_ms = 1_790_000_000_000 // 15000 * 15000 + 13_000
     proc = subprocess.Popen([B.build_skimmer(), "--config", str(cfg), "--out", str(out_dir), "--start-ms", str(start_ms), "--exact",
-                             "--wav", "always", "--rx", f"udp={port},fs={fs},block={block},lo={lo}"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                             "--wav", "always", "--rx", f"udp={port},fs={fs},block={block},lo={lo},idle=2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     first = proc.stderr.readline()                                            # "ready: ..." once the context exists and the port is bound
     assert first.startswith("ready"), first + proc.stderr.read()
     s = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
