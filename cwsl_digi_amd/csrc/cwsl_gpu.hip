@@ -153,6 +153,7 @@ struct cwslg_ctx {
     SyncShared sync_shared;
     Ft4Tables ft4_tables{};
     bool ft4_dft_valu = false;         // CWSLG_FT4_DFT=valu
+    int sync_variant = 0;              // CWSLG_SYNC_VARIANT: bit mask of measured alternatives in the sync stage (0 = defaults)
     // multi-GPU slot-boundary rendezvous (multi_gpu.inc)
     cwslg_rendezvous_fn rdv_fn = nullptr;
     void *rdv_user = nullptr;
@@ -650,6 +651,7 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
     if (const char *v = std::getenv("CWSLG_DEMOD_VARIANT")) c->demod_variant = std::atoi(v);
     if (const char *v = std::getenv("CWSLG_FT4_DFT")) c->ft4_dft_valu = std::strcmp(v, "valu") == 0;
     if (const char *v = std::getenv("CWSLG_ITEM_ORDER")) c->order_override = std::atoi(v);
+    if (const char *v = std::getenv("CWSLG_SYNC_VARIANT")) c->sync_variant = std::atoi(v);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
     if (hipHostMalloc((void **)&c->h_stage, 2 * kStageHalf, hipHostMallocDefault) != hipSuccess) return CWSLG_ERR_NOMEM;
     hipEventCreateWithFlags(&c->stage_ev[0], hipEventDisableTiming);

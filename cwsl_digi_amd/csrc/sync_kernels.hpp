@@ -369,6 +369,236 @@ __global__ __launch_bounds__(256) void symbol_spectra_kernel(const SyncWork *__r
 }
 
 // ---------------------------------------------------------------------------------------------
+// symbol_spectra_v2_kernel: the same transform (same operations, same order: bit-identical rows), two LDS round trips
+// shorter.  Round-2 counters of the first version at 4096 slots: VALU 65 % and LDS 50 % busy, 807 VALU instructions per
+// wave, 1236 LDS-array cycles per transform of which ~70 % are STORES (a ds_write_b64 costs 4-6 cycles against a read's
+// 2).  So:
+//   * the int16 window goes straight from global memory into stage 1's registers (lane = column b reads its eight
+//     packed inputs 128a + b as eight coalesced 4-byte loads): no s_x image, no barrier in front of stage 1;
+//   * the last radix-2 stage (len = 128) is not written back: one thread takes the butterfly PAIR
+//       P1 = (row r, k = q)   and   P2 = (row NA - r, k = 63 - q)        [row 0: P2 = (0, 64 - q)]
+//     whose four results are exactly the operands of the real-input unpack of four bins
+//       K = NA q + r          A = u1', B = conj v2'        K = NA (63 - q) + NA - r      A = u2', B = conj v1'
+//       K = NA (q + 64) + r   A = v1', B = conj u2'        K = NA (127 - q) + NA - r     A = v2', B = conj u1'
+//     (Z[c + NA d] = y[c][d], X[K] pairs Z[K] with Z[NZ - K]); bins >= nbins are skipped.  That removes 15 KB of stores and
+//     15 KB of loads per transform, the loop over residues and one barrier.
+// Needs nbins <= NIN (the power row is staged in LDS); wider searches use the first version.
+template <int HALF, int NA, int AMAX>
+__device__ __forceinline__ void spectra_stage1_regs(const float2 (&z)[AMAX], float2 (*s_y)[SY_PITCH], const SyncTables &tb,
+                                                    const Stage1Tw<NA> &twp, int b)
+{
+    constexpr int NPAIR = NA / 2, SPLIT = NPAIR / 2;
+    constexpr int C0 = HALF ? SPLIT + 1 : 1, C1 = HALF ? NPAIR : SPLIT;
+    const float2 *tw = twp.v;
+    if (HALF == 0) {
+        float2 s0 = z[0];
+#pragma unroll
+        for (int a = 1; a < AMAX; ++a) { s0.x = s0.x + z[a].x; s0.y = s0.y + z[a].y; }
+        s_y[0][b] = s0;                                  // W_NZ^0 = 1: no multiply
+    }
+#pragma unroll
+    for (int c = C0; c <= C1; ++c) {
+        float P = 0.f, Q = 0.f, R = 0.f, S = 0.f;
+#pragma unroll
+        for (int a = 1; a < AMAX; ++a) {
+            const int idx = (a * c) % NA;
+            const float wr = (idx <= NA / 2) ? tb.war[idx] : tb.war[NA - idx];
+            const float wi = (idx <= NA / 2) ? tb.wai[idx] : -tb.wai[NA - idx];
+            P = __builtin_fmaf(z[a].x, wr, P);
+            Q = __builtin_fmaf(z[a].y, wi, Q);
+            R = __builtin_fmaf(z[a].x, wi, R);
+            S = __builtin_fmaf(z[a].y, wr, S);
+        }
+        const float2 yc = make_float2(z[0].x + (P - Q), z[0].y + (R + S));
+        const float2 yn = make_float2(z[0].x + (P + Q), z[0].y + (S - R));
+        s_y[c][b] = cmul_f(yc, tw[2 * (c - C0)]);
+        s_y[NA - c][b] = cmul_f(yn, tw[2 * (c - C0) + 1]);
+    }
+}
+
+// |X[K]|^2 from Z[K] = A and Z[NZ - K] = B (spec v2 stage 3)
+__device__ __forceinline__ float unpack_power(float2 A, float2 B, float2 wk)
+{
+    B.y = -B.y;
+    const float er = (A.x + B.x) * 0.5f, ei = (A.y + B.y) * 0.5f;
+    const float2 o = make_float2((A.x - B.x) * 0.5f, (A.y - B.y) * 0.5f);
+    const float2 t = cmul_f(o, wk);
+    const float xr = er + t.y, xi = ei - t.x;
+    return __builtin_fmaf(xr, xr, xi * xi);
+}
+
+constexpr int SPEC_JPER = 12;           // symbol steps per workgroup (FT8: 372 = 31 x 12)
+template <int NA, int NIN, int STEP, bool WINDOW>
+__global__ __launch_bounds__(256, 4) void symbol_spectra_v2_kernel(const SyncWork *__restrict__ works, SyncTables tb, int nbins, int nsteps)
+{
+    constexpr int NZ = NA * 128;
+    constexpr int NPACK = NIN / 2;
+    constexpr int NGRP = NA * 16;
+    constexpr int AMAX = (NPACK + 127) / 128;             // 8 (FT8), 9 (FT4)
+    constexpr int NH = NA / 2;                            // row pairs (r, NA - r), r = 1..NH; row 0 pairs with itself
+    constexpr int NITEM = (NH + 1) * 64, IPT = (NITEM + 255) / 256;
+    static_assert(NGRP <= 256, "geometry");
+    __shared__ __attribute__((aligned(16))) float s_pw[NIN + 16];
+    __shared__ float2 s_y[NA][SY_PITCH];
+    __shared__ float2 s_w128[64];
+    const SyncWork *w = works + blockIdx.y;
+    const int j0 = blockIdx.x * SPEC_JPER;
+    const int jend = min(j0 + SPEC_JPER, nsteps);
+    const int tid_ = threadIdx.x;
+    const int b_ = tid_ & 127;
+    const float fac = 1.0f / 300.0f;
+    // Barriers are lds_barrier() (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also wait for vmcnt(0), i.e. for
+    // the prefetched window, at the first barrier behind its issue.
+    // this lane's packed inputs z[a] = x[2m] + i x[2m+1], m = 128 a + b_: one aligned 4-byte load each.  The workgroup walks
+    // SPEC_JPER consecutive symbol steps and always has the NEXT step's eight loads in flight while it transforms the
+    // current one: the first version's workgroups all sat through a full memory latency before any arithmetic
+    // (6 resident workgroups per CU, lifetime = latency + arithmetic: VALU 65 % busy); now only the first step of a
+    // workgroup does.
+    const CWSLG_GLOBAL unsigned *d32 = as_global(reinterpret_cast<const unsigned *>(w->frame)) + b_;
+    unsigned raw[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) raw[a] = (128 * a + b_ < NPACK) ? d32[(STEP / 2) * j0 + 128 * a] : 0u;
+    float2 wn[WINDOW ? AMAX : 1];
+    if (WINDOW) {
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) {
+            const int m = 128 * a + b_;
+            wn[WINDOW ? a : 0] = *reinterpret_cast<const float2 *>(tb.win + 2 * ((m < NPACK) ? m : 0));
+        }
+    }
+    Stage1Tw<NA> tw1;
+    if (tid_ < 128) stage1_load_tw<0, NA>(tb.w1920, b_, tw1);
+    else stage1_load_tw<1, NA>(tb.w1920, b_, tw1);
+    // the unpack twiddles W_2NZ^K of this thread's items (bins K1, K2 of each; the two upper bins of an item are rare for
+    // FT8's default range and fetched on demand)
+    float2 w3[IPT][2];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const int it = tid_ + 256 * i;
+        const int r = it >> 6, q = it & 63;
+        const int K1 = NA * q + r;
+        const int K2 = (r == 0) ? NA * ((64 - q) & 63) : NA * (63 - q) + NA - r;
+        const bool live = it < NITEM && !(r == 0 && q > 32);
+        w3[i][0] = (live && K1 < nbins) ? tb.w3840[K1] : make_float2(0.f, 0.f);
+        w3[i][1] = (live && K2 < nbins) ? tb.w3840[K2] : make_float2(0.f, 0.f);
+    }
+    if (tid_ >= 64 && tid_ < 128) s_w128[tid_ - 64] = tb.w128[tid_ - 64];
+    // every loop-invariant load (twiddles, window) is waited for HERE, with the builtin the compiler's wait-count pass
+    // understands: otherwise it keeps conservative vmcnt waits for them inside the loop (the first iteration could still
+    // need them), and from the second iteration on those waits drain the prefetch in the middle of stage 1
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0), expcnt and lgkmcnt untouched
+
+    for (int j = j0; j < jend; ++j) {
+    // an opaque copy of the thread index: otherwise every LDS address of the body is hoisted out of the loop and held in
+    // registers across it (168 VGPRs, 3 workgroups per CU)
+    int t = tid_;
+    asm volatile("" : "+v"(t));
+    const int tid = t, b = t & 127;
+    float2 z[AMAX];
+#pragma unroll
+    for (int a = 0; a < AMAX; ++a) {
+        float lo = fac * (float)(short)(raw[a] & 0xFFFFu);
+        float hi = fac * (float)(short)(raw[a] >> 16);
+        if (WINDOW) { lo = lo * wn[WINDOW ? a : 0].x; hi = hi * wn[WINDOW ? a : 0].y; }
+        z[a] = (128 * a + b < NPACK) ? make_float2(lo, hi) : make_float2(0.f, 0.f);
+    }
+    // the PREVIOUS step's power row leaves now (16 B per lane): issued ahead of the prefetch, its stores have a whole
+    // transform to retire before the top of the next iteration waits for vmcnt(0)
+    if (j > j0) {
+        CWSLG_GLOBAL v4f *out4 = reinterpret_cast<CWSLG_GLOBAL v4f *>(as_global_rw(w->spectra) + (size_t)(j - 1) * nbins);
+        for (int k4 = tid; 4 * k4 < nbins; k4 += 256) out4[k4] = *reinterpret_cast<const v4f *>(s_pw + 4 * k4);
+    }
+    if (j + 1 < jend) {                                   // wave-uniform: the next step's window, in flight during this transform
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) raw[a] = (128 * a + b < NPACK) ? d32[(STEP / 2) * (j + 1) + 128 * a] : 0u;
+    }
+
+    // stage 1 (wave-uniform split of the conjugate pairs of outputs between waves 0-1 and waves 2-3)
+    if (tid < 128) spectra_stage1_regs<0, NA, AMAX>(z, s_y, tb, tw1, b);
+    else spectra_stage1_regs<1, NA, AMAX>(z, s_y, tb, tw1, b);
+    lds_barrier();
+
+    // stage 2, pass A: DIT stages len = 2,4,8 (see the first version)
+    {
+        const int c = tid >> 4, g = tid & 15;
+        const int gb = (int)(__brev((unsigned)g) >> 28);
+        float2 e[8];
+        if (tid < NGRP) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int k3 = ((k & 1) << 2) | (k & 2) | ((k >> 2) & 1);
+                e[k] = s_y[c][16 * k3 + gb];
+            }
+        }
+        lds_barrier();                     // everyone has gathered: the image may now be rewritten
+        if (tid < NGRP) {
+            bfly_one(e[0], e[1]); bfly_one(e[2], e[3]); bfly_one(e[4], e[5]); bfly_one(e[6], e[7]);
+            bfly_one(e[0], e[2]); bfly_mj(e[1], e[3]); bfly_one(e[4], e[6]); bfly_mj(e[5], e[7]);
+            bfly_one(e[0], e[4]); bfly(e[1], e[5], s_w128[16]); bfly_mj(e[2], e[6]); bfly(e[3], e[7], s_w128[48]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s_y[c][sy_col(8 * g + k)] = e[k];
+        }
+    }
+    lds_barrier();
+    // pass B: stages len = 16,32,64
+    if (tid < NGRP) {
+        const int c = tid >> 4, g = tid & 15;
+        const int blk = g >> 3, r = g & 7;
+        float2 e[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) e[q] = s_y[c][sy_col(64 * blk + r + 8 * q)];
+        {
+            const float2 w0 = s_w128[r * 8];
+            bfly(e[0], e[1], w0); bfly(e[2], e[3], w0); bfly(e[4], e[5], w0); bfly(e[6], e[7], w0);
+        }
+        {
+            const float2 w0 = s_w128[r * 4], w1 = s_w128[(r + 8) * 4];
+            bfly(e[0], e[2], w0); bfly(e[1], e[3], w1); bfly(e[4], e[6], w0); bfly(e[5], e[7], w1);
+        }
+        {
+            bfly(e[0], e[4], s_w128[r * 2]); bfly(e[1], e[5], s_w128[(r + 8) * 2]);
+            bfly(e[2], e[6], s_w128[(r + 16) * 2]); bfly(e[3], e[7], s_w128[(r + 24) * 2]);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s_y[c][sy_col(64 * blk + r + 8 * q)] = e[q];
+    }
+    lds_barrier();
+
+    // last stage (len = 128) fused with the unpack: see the header of this kernel
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const int it = tid + 256 * i;
+        const int r = it >> 6, q = it & 63;                // r is wave-uniform
+        if (it >= NITEM || (r == 0 && q > 32)) continue;
+        const int r2 = (r == 0) ? 0 : NA - r;
+        const int k2 = (r == 0) ? ((64 - q) & 63) : 63 - q;
+        float2 u1 = s_y[r][sy_col(q)], v1 = s_y[r][sy_col(q + 64)];
+        float2 u2 = s_y[r2][sy_col(k2)], v2 = s_y[r2][sy_col(k2 + 64)];
+        bfly(u1, v1, s_w128[q]);
+        bfly(u2, v2, s_w128[k2]);
+        if (r == 0 && q == 0) {                             // Z[0] and Z[NZ/2] pair with themselves
+            s_pw[0] = unpack_power(u1, u1, w3[i][0]);
+            if (NA * 64 < nbins) s_pw[NA * 64] = unpack_power(v1, v1, tb.w3840[NA * 64]);
+            if (NZ < nbins) s_pw[NZ] = unpack_power(u1, u1, tb.w3840[NZ]);
+            continue;
+        }
+        const int K1 = NA * q + r, K2 = NA * k2 + r2;
+        const int K3 = K1 + NA * 64, K4 = K2 + NA * 64;
+        if (K1 < nbins) s_pw[K1] = unpack_power(u1, v2, w3[i][0]);
+        if (K2 < nbins) s_pw[K2] = unpack_power(u2, v1, w3[i][1]);
+        if (K3 < nbins) s_pw[K3] = unpack_power(v1, u2, tb.w3840[K3]);
+        if (K4 < nbins) s_pw[K4] = unpack_power(v2, u1, tb.w3840[K4]);
+    }
+    for (int k = NZ + 1 + tid; k < nbins; k += 256) s_pw[k] = 0.0f;          // padding beyond the Nyquist bin
+    lds_barrier();
+    }   // next symbol step: s_y is rewritten after this barrier, s_pw only after four more
+    if (jend > j0) {
+        CWSLG_GLOBAL v4f *out4 = reinterpret_cast<CWSLG_GLOBAL v4f *>(as_global_rw(w->spectra) + (size_t)(jend - 1) * nbins);
+        for (int k4 = tid_; 4 * k4 < nbins; k4 += 256) out4[k4] = *reinterpret_cast<const v4f *>(s_pw + 4 * k4);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Costas correlation + lag peak search.  grid (ceil((ib-ia+1)/32), n_channels), 256 threads.
 // LDS: the band's 44 spectrum rows [44][376] (66 KB) + per-bin 7-tone sums for the 2 bins in flight => 2 WG/CU.
 // Per bin: a wave pair, lane = lag (125 lags), 42 conflict-free LDS reads per lane; the +-10 and +-62 peak
@@ -538,6 +768,152 @@ __global__ __launch_bounds__(SYNC2D_NT) void ft8_sync2d_kernel(const SyncWork *_
 }
 
 // ---------------------------------------------------------------------------------------------
+// ft8_sync2d_v2_kernel: the same search, same sums in the same order (bit-identical results), restructured after the
+// round-1 counters (LDS 53 % busy with 28 % of it bank conflicts, 2232 VALU instructions per wave):
+//   * band image s_s[44][378], column = symbol step m + 2, with REAL zero columns for m = -2, -1, 0 and m = 373..375:
+//     a term the restatement skips is read from a clamped address that holds +0.0 (adding +0.0 to a non-negative sum is
+//     exact), so the 56 per-lane selects of the first version are gone;
+//   * staging: wave w takes steps w, w+8, ...; lanes 0..43 load the band's 44 bins of one step (one 176-byte run) and write
+//     them down a column: row pitch 378 = 26 (mod 32) puts the 32 lanes of a write group on 16 banks (2-way: free for
+//     ds_write_b32) where pitch 376 put them on 4 (8-way); no per-element division by the row count;
+//   * peak searches: float wavefront maximum by DPP (4 steps inside the 16-lane rows, 4 readlanes across them), then a
+//     ballot picks the FIRST lane holding it -- `first || sy > best` of the restatement, including its -0 == +0 -- instead
+//     of two reductions over 64-bit (value, lag) keys.
+constexpr int S2_PITCH = 378, S2_COL0 = 2;
+constexpr int DPP_ROW_MIRROR = 0x140;
+
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+    v = fmaxf(v, dpp_get<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_get<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_get<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_get<DPP_ROW_MIRROR>(v));                   // every lane of a 16-lane row holds the row maximum
+    const int vi = __float_as_int(v);                           // readlane moves bits: the builtin is typed int
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+// first lane (lowest lag) whose value equals the wavefront maximum; lanes that do not take part pass -inf
+__device__ __forceinline__ void wave_first_max(float v, int lag, float &best, int &best_lag)
+{
+    const float m = wave_max_f32(v);
+    const unsigned long long hit = __builtin_amdgcn_ballot_w64(v == m);
+    const int src = hit ? (int)__builtin_ctzll(hit) : 0;
+    best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+    best_lag = __builtin_amdgcn_readlane(lag, src);
+}
+
+__device__ __forceinline__ float sync_finish(float ta, float tb, float tc, float t0a, float t0b, float t0c)
+{
+    float t = ta + tb + tc;
+    float t0 = t0a + t0b + t0c;
+    t0 = (t0 - t) / 6.0f;
+    const float sync_abc = t / t0;
+    t = tb + tc;
+    t0 = t0b + t0c;
+    t0 = (t0 - t) / 6.0f;
+    const float sync_bc = t / t0;
+    float sy = (sync_abc > sync_bc) ? sync_abc : sync_bc;
+    if (!(sy == sy)) sy = 0.0f;                        // 0/0 on all-zero windows: defined as 0 (as the oracle)
+    return sy;
+}
+
+__global__ __launch_bounds__(SYNC2D_NT, 4) void ft8_sync2d_v2_kernel(const SyncWork *__restrict__ works, int ia, int ib, int nbins)
+{
+    constexpr int ROWS = SYNC_BAND + 12, NW = SYNC2D_NT / 64;
+    constexpr int UN = (FT8_NHSYM + NW - 1) / NW;                              // symbol steps per wave: 47
+    __shared__ __attribute__((aligned(16))) float s_s[ROWS][S2_PITCH];       // s_s[r][m + 2] = s(i0 + r, m)
+    __shared__ __attribute__((aligned(16))) float s_c0[NW][S2_PITCH];
+    const SyncWork *w = works + blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i0 = ia + blockIdx.x * SYNC_BAND;
+    {   // every load of the wave is issued before the first LDS write: one memory latency per band (with batches of 8 the
+        // workgroup paid six in a row, and only two workgroups fit a CU to cover for each other)
+        const CWSLG_GLOBAL float *sp = as_global(w->spectra) + i0 + lane;
+        const bool on = lane < ROWS && i0 + lane < nbins;
+        float v[UN];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const int m = wv + NW * q;
+            v[q] = (on && m < FT8_NHSYM) ? sp[(size_t)m * nbins] : 0.0f;
+        }
+        float *dst = &s_s[lane < ROWS ? lane : 0][S2_COL0 + 1 + wv];           // column of step m = 1 + (0-based step)
+#pragma unroll
+        for (int q = 0; q < UN; ++q)
+            if (lane < ROWS && wv + NW * q < FT8_NHSYM) dst[NW * q] = v[q];
+        if (tid < ROWS) {
+            float *row = s_s[tid];
+            row[0] = 0.0f; row[1] = 0.0f; row[2] = 0.0f;                        // m = -2, -1, 0
+            row[S2_COL0 + 373] = 0.0f; row[S2_COL0 + 374] = 0.0f; row[S2_COL0 + 375] = 0.0f;
+        }
+    }
+    __syncthreads();
+    // (A persistent form that walks several bands and keeps the next band's 47 loads per lane in registers was tried: the
+    // search itself needs ~100 VGPRs at this occupancy, the prefetch spills, and hipcc may not spill an in-flight load.)
+    float *c0 = s_c0[wv];
+    const int icos[7] = {3, 1, 4, 0, 6, 5, 2};
+    const int j = 2 * lane - FT8_JZ;                       // this lane's lag pair (j, j + 1); lane 63 has none
+    const bool ok0 = j <= FT8_JZ, ok1 = j + 1 <= FT8_JZ;
+    const bool near0 = j >= -10 && j <= 10, near1 = j + 1 >= -10 && j + 1 <= 10;
+    const float ninf = -__builtin_huge_valf();
+    // column offsets of the three Costas blocks for n = 0: m = j + 12 (+144, +288); later n add 4
+    const int ca0 = j + 12 + S2_COL0, cb0 = ca0 + 144, cc0 = ca0 + 288;
+    {
+        // one wave per bin from here on, each wave owns s_c0[wv]
+        for (int rr = wv; rr < SYNC_BAND; rr += NW) {
+            const int bin = i0 + rr;
+            if (bin > ib) break;                            // wave-uniform
+            // 7-tone sums of this bin for every symbol step (sequential k, as the restatement), two steps per lane and read
+            for (int mp = lane; mp < S2_PITCH / 2; mp += 64) {
+                float2 acc = make_float2(0.0f, 0.0f);
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    const float2 x = *reinterpret_cast<const float2 *>(&s_s[rr + 2 * k][2 * mp]);
+                    acc.x = acc.x + x.x;
+                    acc.y = acc.y + x.y;
+                }
+                *reinterpret_cast<float2 *>(c0 + 2 * mp) = acc;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float ta0 = 0, tb0 = 0, tc0 = 0, ua0 = 0, ub0 = 0, uc0 = 0;      // lag j:     t sums, t0 sums
+            float ta1 = 0, tb1 = 0, tc1 = 0, ua1 = 0, ub1 = 0, uc1 = 0;      // lag j + 1
+#pragma unroll
+            for (int n = 0; n < 7; ++n) {
+                const float *row = s_s[rr + 2 * icos[n]];
+                int ca = ca0 + 4 * n; ca = ca < 0 ? 0 : ca;                   // m < -2  -> the zero pair (m = -2, -1)
+                int cc = cc0 + 4 * n; cc = cc > S2_PITCH - 2 ? S2_PITCH - 2 : cc;      // m > 374 -> the zero pair (m = 374, 375)
+                const int cb = cb0 + 4 * n;
+                const float2 va = *reinterpret_cast<const float2 *>(row + ca), wa = *reinterpret_cast<const float2 *>(c0 + ca);
+                const float2 vb = *reinterpret_cast<const float2 *>(row + cb), wb = *reinterpret_cast<const float2 *>(c0 + cb);
+                const float2 vc = *reinterpret_cast<const float2 *>(row + cc), wc = *reinterpret_cast<const float2 *>(c0 + cc);
+                ta0 = ta0 + va.x; ua0 = ua0 + wa.x; ta1 = ta1 + va.y; ua1 = ua1 + wa.y;
+                tb0 = tb0 + vb.x; ub0 = ub0 + wb.x; tb1 = tb1 + vb.y; ub1 = ub1 + wb.y;
+                tc0 = tc0 + vc.x; uc0 = uc0 + wc.x; tc1 = tc1 + vc.y; uc1 = uc1 + wc.y;
+            }
+            const float sa = ok0 ? sync_finish(ta0, tb0, tc0, ua0, ub0, uc0) : ninf;
+            const float sb = ok1 ? sync_finish(ta1, tb1, tc1, ua1, ub1, uc1) : ninf;
+            // +-62: the lane's own first maximum (lag j before j + 1), then the wavefront's
+            const bool b2 = sb > sa;
+            float r2; int l2;
+            wave_first_max(b2 ? sb : sa, b2 ? j + 1 : j, r2, l2);
+            const float na = near0 ? sa : ninf, nb = near1 ? sb : ninf;
+            const bool b1 = nb > na;
+            float r1; int l1;
+            wave_first_max(b1 ? nb : na, b1 ? j + 1 : j, r1, l1);
+            if (lane == 0) {
+                w->red[bin] = r1;  w->jpeak[bin] = l1;
+                w->red2[bin] = r2; w->jpeak2[bin] = l2;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();               // c0 is rewritten by the next bin
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Bitonic sort of (value, index) keys, ascending, ties by ascending index.  n = 2048, 256 threads.
 __device__ __forceinline__ bool key_less(float va, int ia_, float vb, int ib_)
 {
@@ -547,11 +923,12 @@ __device__ __forceinline__ bool key_less(float va, int ia_, float vb, int ib_)
 }
 
 // n = 1024 or 2048 keys (power of two >= the number of real keys; the padding sorts to the end either way)
+template <int NT>
 __device__ void bitonic_sort_n(float *kv, int *ki, int n, int tid)
 {
     for (int size = 2; size <= n; size <<= 1) {
         for (int stride = size >> 1; stride >= 1; stride >>= 1) {
-            for (int t = tid; t < n / 2; t += 256) {
+            for (int t = tid; t < n / 2; t += NT) {
                 const int lo = 2 * t - (t & (stride - 1));
                 const int hi = lo + stride;
                 const bool up = (lo & size) == 0;
@@ -565,8 +942,11 @@ __device__ void bitonic_sort_n(float *kv, int *ki, int n, int tid)
     }
 }
 
-// grid (n_channels), 256 threads.
-__global__ __launch_bounds__(256) void ft8_candidates_kernel(const SyncWork *__restrict__ works, int ia, int ib,
+// grid (n_channels), NT threads.  The kernel is a chain of ~165 barrier-separated stages on <= 1024 keys: with 1024 threads every
+// stage is one pass (one compare-exchange per thread), so its length is the barrier count, not the key count (round 1 ran it
+// with 256 threads: 0.15 ms per 512 channels, now NT = 1024).
+template <int NT>
+__global__ __launch_bounds__(NT) void ft8_candidates_kernel(const SyncWork *__restrict__ works, int ia, int ib,
                                                               float syncmin, int maxcand)
 {
     __shared__ float s_kv[2048];
@@ -575,7 +955,7 @@ __global__ __launch_bounds__(256) void ft8_candidates_kernel(const SyncWork *__r
     __shared__ short s_jp[FT8_NH1 + 1], s_jp2[FT8_NH1 + 1];
     __shared__ short s_first[FT8_NH1 + 2], s_second[FT8_NH1 + 2];   // bin -> pre-candidate index (or -1)
     __shared__ int s_desc[SYNC_MAXPRE];                 // bins in descending red order
-    __shared__ int s_scan[256];
+    __shared__ int s_scan[NT];
     __shared__ unsigned s_scan_lo[1024];
     __shared__ int s_cbin[SYNC_MAXPRE], s_clag[SYNC_MAXPRE];
     __shared__ float s_csync[SYNC_MAXPRE], s_cf[SYNC_MAXPRE], s_ct[SYNC_MAXPRE];
@@ -585,34 +965,34 @@ __global__ __launch_bounds__(256) void ft8_candidates_kernel(const SyncWork *__r
     const int tid = threadIdx.x;
     const int iz = ib - ia + 1;
     const float df = 12000.0f / 3840.0f, tstep = 480.0f / 12000.0f;
-    for (int i = ia + tid; i <= ib; i += 256) {
+    for (int i = ia + tid; i <= ib; i += NT) {
         s_red[i] = w->red[i]; s_red2[i] = w->red2[i]; s_jp[i] = (short)w->jpeak[i]; s_jp2[i] = (short)w->jpeak2[i];
     }
-    for (int i = tid; i < FT8_NH1 + 2; i += 256) { s_first[i] = -1; s_second[i] = -1; }
+    for (int i = tid; i < FT8_NH1 + 2; i += NT) { s_first[i] = -1; s_second[i] = -1; }
     const int npct = (int)lroundf(0.40f * (float)iz);
     const int lim = min(SYNC_MAXPRE, iz);
     const int nsort = (iz <= 1024) ? 1024 : 2048;       // 200..3000 Hz is 897 bins: the smaller network (55 of 66 stages, half the pairs)
     __syncthreads();
     // --- percentile of red2
-    for (int k = tid; k < nsort; k += 256) { s_kv[k] = (k < iz) ? s_red2[ia + k] : __builtin_huge_valf(); s_ki[k] = (k < iz) ? ia + k : 0x7fffffff; }
+    for (int k = tid; k < nsort; k += NT) { s_kv[k] = (k < iz) ? s_red2[ia + k] : __builtin_huge_valf(); s_ki[k] = (k < iz) ? ia + k : 0x7fffffff; }
     __syncthreads();
-    bitonic_sort_n(s_kv, s_ki, nsort, tid);
+    bitonic_sort_n<NT>(s_kv, s_ki, nsort, tid);
     if (tid == 0 && npct >= 1) s_base[1] = s_red2[s_ki[npct - 1]];
     __syncthreads();
     // --- order of red (ascending); descending walk list
-    for (int k = tid; k < nsort; k += 256) { s_kv[k] = (k < iz) ? s_red[ia + k] : __builtin_huge_valf(); s_ki[k] = (k < iz) ? ia + k : 0x7fffffff; }
+    for (int k = tid; k < nsort; k += NT) { s_kv[k] = (k < iz) ? s_red[ia + k] : __builtin_huge_valf(); s_ki[k] = (k < iz) ? ia + k : 0x7fffffff; }
     __syncthreads();
-    bitonic_sort_n(s_kv, s_ki, nsort, tid);
+    bitonic_sort_n<NT>(s_kv, s_ki, nsort, tid);
     if (tid == 0 && npct >= 1) s_base[0] = s_red[s_ki[npct - 1]];
-    for (int r = tid; r < lim; r += 256) s_desc[r] = s_ki[iz - 1 - r];
+    for (int r = tid; r < lim; r += NT) s_desc[r] = s_ki[iz - 1 - r];
     __syncthreads();
     if (npct < 1) { if (tid == 0) *w->ncand = 0; return; }
     const float base = s_base[0], base2 = s_base[1];
-    for (int i = ia + tid; i <= ib; i += 256) { s_red[i] = s_red[i] / base; s_red2[i] = s_red2[i] / base2; }
+    for (int i = ia + tid; i <= ib; i += NT) { s_red[i] = s_red[i] / base; s_red2[i] = s_red2[i] / base2; }
     __syncthreads();
     // --- walk the bins in descending red; each appends its +-10 peak and, if at another lag, its +-62 peak,
     // until MAXPRECAND entries exist.  Parallel form: per-rank counts -> exclusive scan -> positions < MAXPRECAND.
-    constexpr int PER = (SYNC_MAXPRE + 255) / 256;      // ranks per thread (4)
+    constexpr int PER = (SYNC_MAXPRE + NT - 1) / NT;      // ranks per thread
     int cnt[PER], flags[PER];
     int local = 0;
 #pragma unroll
@@ -630,7 +1010,7 @@ __global__ __launch_bounds__(256) void ft8_candidates_kernel(const SyncWork *__r
     }
     s_scan[tid] = local;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {           // Hillis-Steele inclusive scan
+    for (int off = 1; off < NT; off <<= 1) {            // Hillis-Steele inclusive scan
         const int v = (tid >= off) ? s_scan[tid - off] : 0;
         __syncthreads();
         s_scan[tid] += v;
@@ -648,10 +1028,10 @@ __global__ __launch_bounds__(256) void ft8_candidates_kernel(const SyncWork *__r
             if (flags[q] & 2) ++pos;
         }
     }
-    if (tid == 255) s_n = min(s_scan[255], SYNC_MAXPRE);
+    if (tid == NT - 1) s_n = min(s_scan[NT - 1], SYNC_MAXPRE);
     __syncthreads();
     const int ncand = s_n;
-    for (int i = tid; i < ncand; i += 256) { s_cf[i] = (float)s_cbin[i] * df; s_ct[i] = ((float)s_clag[i] - 0.5f) * tstep; }
+    for (int i = tid; i < ncand; i += NT) { s_cf[i] = (float)s_cbin[i] * df; s_ct[i] = ((float)s_clag[i] - 0.5f) * tstep; }
     __syncthreads();
     // --- near-duplicate suppression.  Upstream's sequential double loop
     //       for i: for j<i: if ||f_i|-|f_j|| < 4 Hz and |t_i-t_j| < 0.04 s: zero the weaker of the two (in place)
@@ -663,11 +1043,11 @@ __global__ __launch_bounds__(256) void ft8_candidates_kernel(const SyncWork *__r
     // dependency chains (a handful for real spectra, ncand in the worst case = the serial loop).
     short *s_done = reinterpret_cast<short *>(s_ki);          // the sort buffers are free now
     short *s_ready = s_done + SYNC_MAXPRE;
-    for (int i = tid; i < ncand; i += 256) s_done[i] = 0;
+    for (int i = tid; i < ncand; i += NT) s_done[i] = 0;
     __syncthreads();
     for (int round = 0; round <= ncand; ++round) {
         int pending = 0;
-        for (int i = tid; i < ncand; i += 256) {
+        for (int i = tid; i < ncand; i += NT) {
             if (s_done[i]) { s_ready[i] = 0; continue; }
             const int n = s_cbin[i];
             bool ok = true;
@@ -683,7 +1063,7 @@ __global__ __launch_bounds__(256) void ft8_candidates_kernel(const SyncWork *__r
             pending = 1;
         }
         if (!__syncthreads_or(pending)) break;
-        for (int i = tid; i < ncand; i += 256) {
+        for (int i = tid; i < ncand; i += NT) {
             if (!s_ready[i]) continue;
             const int n = s_cbin[i];
             int part[6];
@@ -727,7 +1107,7 @@ __global__ __launch_bounds__(256) void ft8_candidates_kernel(const SyncWork *__r
     // Bitonic sort of 64-bit keys (inverted order-preserving sync bits | bin | lag | index) in the two sort buffers.
     unsigned *s_hi = reinterpret_cast<unsigned *>(s_kv);
     unsigned *s_lo = reinterpret_cast<unsigned *>(s_scan_lo);
-    for (int i = tid; i < 1024; i += 256) {
+    for (int i = tid; i < 1024; i += NT) {
         unsigned hi = 0xFFFFFFFFu, lo = 0xFFFFFFFFu;
         if (i < ncand && s_csync[i] >= syncmin) {
             unsigned u = __float_as_uint(s_csync[i]);
@@ -740,7 +1120,7 @@ __global__ __launch_bounds__(256) void ft8_candidates_kernel(const SyncWork *__r
     __syncthreads();
     for (int size = 2; size <= 1024; size <<= 1) {
         for (int stride = size >> 1; stride >= 1; stride >>= 1) {
-            for (int t = tid; t < 512; t += 256) {
+            for (int t = tid; t < 512; t += NT) {
                 const int l0 = 2 * t - (t & (stride - 1));
                 const int h0 = l0 + stride;
                 const bool up = (l0 & size) == 0;
@@ -753,7 +1133,7 @@ __global__ __launch_bounds__(256) void ft8_candidates_kernel(const SyncWork *__r
         }
     }
     int nout = 0;
-    for (int r = tid; r < 1024; r += 256) {
+    for (int r = tid; r < 1024; r += NT) {
         if (s_hi[r] == 0xFFFFFFFFu && s_lo[r] == 0xFFFFFFFFu) continue;
         ++nout;
         if (r < maxcand) {

@@ -33,13 +33,17 @@ def _run(ctx, oracle, modes, check, sync=False):
     boundaries inside it (FT4: two frames per FT8 slot)."""
     longest = max(PERIOD[m] for m in modes)
     n_long = int(longest * FS) // BLK * BLK
+    cap = n_long + 4 * BLK
     if sync:
         ctx.enable_sync(True, 1.5, 200, 200, 3000)
     slots = []
     for gs, mode in enumerate(modes):
         f = _freq(gs)
-        rx = ctx.receiver_open(FS, BLK, 0, ring_blocks=n_long // BLK + 4)
-        ctx.push_synth(rx, 0xC0FFEE ^ gs, n_long, BLK, tones_hz=_tones(f, gs), amp=2.0e4)    # resident before any channel exists
+        rx = ctx.receiver_open(FS, BLK, 0, ring_blocks=cap // BLK)
+        # the whole ring is filled before any channel exists (ring index = sample index of the generator); the timed part
+        # only commits what is already resident, so the stream the channel sees is ring[0:n_long]
+        ctx.push_synth(rx, 0xC0FFEE ^ gs, cap // 2, BLK, tones_hz=_tones(f, gs), amp=2.0e4)
+        ctx.push_synth(rx, 0xC0FFEE ^ gs, cap - cap // 2, BLK, tones_hz=_tones(f, gs), amp=2.0e4)
         ch = ctx.channel_open(rx, f, mode)
         slots.append((rx, ch, mode, f, gs))
     for g in sorted({GROUP[m] for m in modes}):

@@ -118,7 +118,7 @@ def test_late_first_boundary_saturates_then_recovers(ctx, oracle):
     from a valid checkpoint range (no read past the phasor table) -- its frame is finite and spectrally right."""
     n = 2000 * BLK                                  # 21.3 s > FT4's 12.5 s frame
     f = -12000
-    rx = ctx.receiver_open(FS, BLK, 0)
+    rx = ctx.receiver_open(FS, BLK, 0, ring_blocks=1300)
     ch = ctx.channel_open(rx, f, "FT4")
     for k in range(0, n, 250 * BLK):
         ctx.push_synth(rx, 5, 250 * BLK, BLK, tones_hz=[f + 1000.0], amp=1e4)
