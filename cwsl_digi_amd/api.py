@@ -86,6 +86,14 @@ class Ft4Sync(C.Structure):
                 ("ibest", C.c_int32), ("idf", C.c_int32), ("seg", C.c_int32), ("cand", C.c_int32)]
 
 
+class WsprCandidate(C.Structure):
+    _fields_ = [("freq_hz", C.c_float), ("snr_db", C.c_float), ("drift", C.c_float), ("sync", C.c_float), ("shift", C.c_int32)]
+
+
+class Fst4wCandidate(C.Structure):
+    _fields_ = [("freq_hz", C.c_float), ("snr", C.c_float), ("bin", C.c_int32), ("pad_", C.c_int32)]
+
+
 class Stats(C.Structure):
     _fields_ = [("demod_launches", C.c_uint64), ("demod_samples", C.c_uint64),
                 ("finalize_launches", C.c_uint64), ("sync_launches", C.c_uint64), ("frames_emitted", C.c_uint64),
@@ -107,6 +115,7 @@ ABI_SYMBOLS = [
     "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_parse_decoder_line", "cwslg_channel_open_line", "cwslg_channel_open", "cwslg_channel_close", "cwslg_channel_tune",
     "cwslg_channel_info", "cwslg_process", "cwslg_slot_boundary", "cwslg_slot_boundary_channel",
     "cwslg_set_boundary_rendezvous", "cwslg_rccl_unique_id", "cwslg_rccl_init",
+    "cwslg_enable_long_sync", "cwslg_fetch_wspr_candidates", "cwslg_fetch_fst4w_candidates", "cwslg_long_sync_debug_fetch",
     "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_write_wav", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
     "cwslg_enable_sync", "cwslg_fetch_candidates", "cwslg_set_ft4_syncmin", "cwslg_enable_ft4_coherent", "cwslg_fetch_ft4_sync", "cwslg_sync_debug_fetch", "cwslg_get_stats", "cwslg_reset_stats",
     "cwslg_set_timing", "cwslg_stream", "cwslg_channel_constants", "cwslg_phasor_checkpoint_stride", "cwslg_channel_phasor_checkpoints",
@@ -152,6 +161,10 @@ def load_library(build_if_missing=True):
     L.cwslg_set_boundary_rendezvous.argtypes = [vp, RENDEZVOUS_FN, vp]
     L.cwslg_rccl_unique_id.argtypes = [vp]
     L.cwslg_rccl_init.argtypes = [vp, vp, i32, i32]
+    L.cwslg_enable_long_sync.argtypes = [vp, i32, i32, i32, f32]
+    L.cwslg_fetch_wspr_candidates.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
+    L.cwslg_fetch_fst4w_candidates.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
+    L.cwslg_long_sync_debug_fetch.argtypes = [vp, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.cwslg_receiver_open.argtypes = [vp, u32, u32, C.c_int32, u32, C.POINTER(i32)]
     L.cwslg_receiver_close.argtypes = [vp, i32]
     L.cwslg_push_iq.argtypes = [vp, i32, vp, u32]
@@ -473,6 +486,44 @@ class Context:
         self._chk(rc)
         return [dict(f0_hz=b.f0_hz, f1_hz=b.f1_hz, dt_s=b.dt_s, sync=b.sync, ibest=b.ibest, idf=b.idf, seg=b.seg, cand=b.cand)
                 for b in buf[:n.value]]
+
+    def enable_long_sync(self, on=True, nfa_hz=1400, nfb_hz=1600, minsync=1.2):
+        """Candidate search of the 120 s modes (WSPR: wsprd's front end; FST4W-120: get_candidates_fst4 over nfa..nfb)."""
+        self._chk(self.L.cwslg_enable_long_sync(self.h, 1 if on else 0, nfa_hz, nfb_hz, minsync))
+
+    def fetch_wspr_candidates(self, ch, max_cand=200):
+        """-> None until a frame was searched, else [(freq_hz, snr_db, drift, sync, shift)]."""
+        buf = (WsprCandidate * max_cand)()
+        n = C.c_int()
+        rc = self.L.cwslg_fetch_wspr_candidates(self.h, ch, buf, max_cand, C.byref(n))
+        if rc == ERR_NO_FRAME:
+            return None
+        self._chk(rc)
+        return [(b.freq_hz, b.snr_db, b.drift, b.sync, b.shift) for b in buf[:n.value]]
+
+    def fetch_fst4w_candidates(self, ch, max_cand=100):
+        """-> None until a frame was searched, else [(freq_hz, snr, bin)]."""
+        buf = (Fst4wCandidate * max_cand)()
+        n = C.c_int()
+        rc = self.L.cwslg_fetch_fst4w_candidates(self.h, ch, buf, max_cand, C.byref(n))
+        if rc == ERR_NO_FRAME:
+            return None
+        self._chk(rc)
+        return [(b.freq_hz, b.snr, b.bin) for b in buf[:n.value]]
+
+    def long_sync_debug(self, ch, what):
+        """what: 'iq' complex64[46080], 'ps' float32[512, 359] (wsprd's ps[j][i]), 'smspec' float32[411] (WSPR);
+        's2' float32[nnw], 'band' complex64[nband] (FST4W)."""
+        sel = {"iq": 0, "ps": 1, "smspec": 2, "s2": 3, "band": 4}[what]
+        buf = np.empty(2 * 46080 if sel == 0 else (359 * 512 if sel == 1 else (411 if sel == 2 else 65600)), np.float32)
+        n = C.c_size_t()
+        self._chk(self.L.cwslg_long_sync_debug_fetch(self.h, ch, sel, buf.ctypes.data, buf.nbytes, C.byref(n)))
+        out = buf[:n.value]
+        if sel in (0, 4):
+            return out.view(np.complex64)
+        if sel == 1:
+            return np.ascontiguousarray(out.reshape(359, 512).T)
+        return out
 
     def set_ft4_syncmin(self, syncmin=1.2):
         self._chk(self.L.cwslg_set_ft4_syncmin(self.h, syncmin))

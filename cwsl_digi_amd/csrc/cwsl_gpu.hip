@@ -32,6 +32,7 @@
 #include "host/spot_parse.hpp"
 #include "sync_kernels.hpp"
 #include "ft4sync_kernels.hpp"
+#include "longsync_kernels.hpp"
 
 namespace cwslg {
 
@@ -61,6 +62,25 @@ struct PhasorTable {
     float2 inc{};
 };
 
+struct LongConfig {
+    bool enabled = false;
+    int nfa_hz = 1400, nfb_hz = 1600;          // jt9 -W ... -L 1400 -H 1600 (DecoderPool.hpp:1033)
+    float minsync = 1.2f;                       // fst4_decode's minsync for T/R periods above 15 s
+};
+
+struct LongShared {                             // device tables of the 120 s modes' search
+    struct Plan { float2 *wa = nullptr, *wn = nullptr, *wb = nullptr; } p45, p125;
+    float2 *d_wspr_T = nullptr, *d_f4w_T = nullptr, *d_w512 = nullptr;
+    float *d_win512 = nullptr;
+    unsigned char *d_pr3 = nullptr;
+    int f4w_jlo = 0, f4w_nband = 0;
+};
+
+struct LongChannelBuffers {
+    char *d_block = nullptr;
+    LongWork w{};
+};
+
 struct Channel {
     bool open = false;
     int rx = -1;
@@ -70,6 +90,8 @@ struct Channel {
     int group = 0;
     bool wspr_scale = false;           // mode == "WSPR" exactly (Instance.cpp:320)
     bool sync_ft8 = false, sync_ft4 = false;
+    bool sync_wspr = false, sync_fst4w = false;    // 120 s modes with a candidate search (longsync_kernels.hpp)
+    LongChannelBuffers longbuf;
     size_t frame_len = 0;
     // device storage (one allocation)
     char *d_block = nullptr;
@@ -153,6 +175,8 @@ struct cwslg_ctx {
     SyncShared sync_shared;
     Ft4Tables ft4_tables{};
     bool ft4_dft_valu = false;         // CWSLG_FT4_DFT=valu
+    LongConfig long_cfg;
+    LongShared long_shared;
     int sync_variant = 0;              // CWSLG_SYNC_VARIANT: bit mask of measured alternatives in the sync stage (0 = defaults)
     // multi-GPU slot-boundary rendezvous (multi_gpu.inc)
     cwslg_rendezvous_fn rdv_fn = nullptr;
@@ -183,6 +207,7 @@ int fail(cwslg_ctx *c, int code, const char *fmt, ...)
     } while (0)
 
 int sync_launch(cwslg_ctx *c, const std::vector<int> &emitted);
+int long_sync_launch(cwslg_ctx *c, const std::vector<int> &emitted);
 
 WorkBuf *acquire_workbuf(cwslg_ctx *c, size_t bytes)
 {
@@ -594,6 +619,10 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s,
         rc = sync_launch(c, emitted);
         if (rc) return rc;
     }
+    if (c->long_cfg.enabled && !emitted.empty()) {
+        rc = long_sync_launch(c, emitted);
+        if (rc) return rc;
+    }
     return CWSLG_OK;
 }
 
@@ -603,6 +632,8 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s,
 #include "sync_host.inc"
 // multi-GPU rendezvous: callback hook + the built-in RCCL form
 #include "multi_gpu.inc"
+// candidate search of the 120 s modes (WSPR, FST4W-120)
+#include "longsync_host.inc"
 
 // =============================================================================================
 extern "C" {
@@ -677,6 +708,7 @@ void cwslg_destroy(cwslg_ctx *c)
     for (Channel &ch : c->chans) {
         if (ch.d_block) hipFree(ch.d_block);
         sync_free_channel(ch.syncbuf);
+        if (ch.longbuf.d_block) { (void)hipFree(ch.longbuf.d_block); ch.longbuf = LongChannelBuffers(); }
     }
     for (Receiver &rx : c->rxs) if (rx.d_ring) hipFree(rx.d_ring);
     for (auto &kv : c->d_taps) hipFree(kv.second);
@@ -690,6 +722,7 @@ void cwslg_destroy(cwslg_ctx *c)
     for (auto &p : c->ev_pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     rccl_release(c);
     sync_free_shared(c->sync_shared);
+    long_free_shared(c->long_shared);
     if (c->d_sincos) hipFree(c->d_sincos);
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->stage_ev[0]) hipEventDestroy(c->stage_ev[0]);
@@ -760,6 +793,7 @@ int cwslg_receiver_close(cwslg_ctx *c, int rx_id)
         if (!ch.open) continue;
         if (ch.d_block) hipFree(ch.d_block);
         sync_free_channel(ch.syncbuf);
+        if (ch.longbuf.d_block) { (void)hipFree(ch.longbuf.d_block); ch.longbuf = LongChannelBuffers(); }
         auto it = c->phasors.find(ch.phasor_key);
         if (it != c->phasors.end() && --it->second.refs == 0) { hipFree(it->second.d_ckpt); c->phasors.erase(it); }
         ch = Channel();
@@ -944,6 +978,8 @@ int cwslg_channel_open(cwslg_ctx *c, int rx_id, int32_t demod_hz, int usb, const
     ch.wspr_scale = (ch.mode == "WSPR");
     ch.sync_ft8 = (ch.mode == "FT8");
     ch.sync_ft4 = (ch.mode == "FT4");
+    ch.sync_wspr = (ch.mode == "WSPR");
+    ch.sync_fst4w = (ch.mode == "FST4W-120");
     ch.frame_len = frame_length(*mi);
     ch.k = make_constants(rx.fs, kSsbBw, f_hz, usb != 0);
     // one device allocation: 2 float frames | int16 frame | peaks | factor | tone
@@ -1097,6 +1133,7 @@ int cwslg_channel_close(cwslg_ctx *c, int ch_id)
     rx.channels.erase(std::remove(rx.channels.begin(), rx.channels.end(), ch_id), rx.channels.end());
     hipFree(ch.d_block);
     sync_free_channel(ch.syncbuf);
+        if (ch.longbuf.d_block) { (void)hipFree(ch.longbuf.d_block); ch.longbuf = LongChannelBuffers(); }
     auto it = c->phasors.find(ch.phasor_key);
     if (it != c->phasors.end() && --it->second.refs == 0) { hipFree(it->second.d_ckpt); c->phasors.erase(it); }
     ch = Channel();

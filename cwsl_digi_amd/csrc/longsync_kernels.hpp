@@ -1,0 +1,486 @@
+// longsync_kernels.hpp -- candidate search of the 120 s modes on gfx950 (BASELINE.json configs[4]).
+//
+// *** PARITY UNPINNED by the reference ***: CWSL_DIGI hands WSPR frames to WSJT-X's `wsprd -C .. -o 5 -d` and FST4W-120 frames to
+// `jt9 -W -p 120 .. -L 1400 -H 1600 -F 200` (source/DecoderPool.hpp:1019-1033); WSJT-X is not vendored.  These kernels implement
+// the candidate-finding front ends of those programs (wsprd.c: FFT-based /32 down-conversion to 375 Hz, 512-point half-symbol
+// spectra, smoothed-spectrum peak pick, coarse sync-vector search; get_candidates_fst4.f90: comb-summed band spectrum, 30th
+// percentile, CLEAN peak pick) with the arithmetic specification of oracle/longsync_oracle.c, operation for operation, so the
+// candidate lists are BIT-IDENTICAL to that restatement (tests/test_gpu_longsync.py).
+//
+// Both modes need a band of a >1.4 M-point real FFT.  It is evaluated as a polyphase band DFT (same numbers, 1/30 of the work):
+//     X[k] = sum_{a<R} W_N^(a k) Y_a[k mod M],     Y_a = M-point DFT of x[R b + a]            (WSPR: R 32, M 46080; FST4W: R 45, M 32000)
+// two real sequences share one complex M-point transform, which is "spec B" (N = NA x NB; WSPR 45 x 1024, FST4W 125 x 256):
+//   fftb_stage1_kernel   dense NA-point DFTs down the columns as four ascending fmaf chains per output + twiddle W_N^(b c);
+//                        a 64-column tile of the input is staged in LDS once and shared by the four waves (outputs c = wave mod 4)
+//   fftb_stage2_kernel   one workgroup per row: NB-point radix-2 DIT in LDS
+// Output convention: Z[c + NA d] = y[c][d], kept as y (row-major [NA][NB]); consumers do the index arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cwslg {
+
+constexpr int WSPR_NPTS = 1368000, WSPR_NFFT1 = 1474560, WSPR_M = 46080, WSPR_R = 32, WSPR_NFFTS = 359, WSPR_MAXCAND = 200;
+constexpr int WSPR_IQ_LEN = 46336;          // 358*128 + 512: the spectra read past 46080, where wsprd's calloc'ed buffers hold zeros
+constexpr int F4W_NMAX = 1440000, F4W_NSPS = 8200, F4W_M = 32000, F4W_R = 45, F4W_MAXCAND = 100, F4W_NNW = 65600;
+
+struct FftbTables {                          // device pointers
+    const float2 *wa, *wn, *wb;              // NA | N | NB/2
+};
+
+struct alignas(16) LongWork {                // one per channel per launch
+    const int16_t *frame;
+    int frame_len;
+    int pad_;
+    float2 *z;                               // [T][M]   packed input, later scratch
+    float2 *y;                               // [T][NA][NB]
+    float2 *aux;                             // WSPR: zinv [M] | yinv [M] ; FST4W: band [nband]
+    float2 *iq;                              // WSPR: [WSPR_IQ_LEN]
+    float *ps, *sq;                          // WSPR: [359][512] time-major
+    float *vec;                              // WSPR: smspec[411] ; FST4W: s2[F4W_NNW]
+    void *cand;                              // WsprCand[200] / Fst4wCand[100]
+    int *ncand;
+};
+
+struct WsprCand { float freq_hz, snr_db, drift, sync; int shift; };
+struct Fst4wCand { float freq_hz, snr; int bin, pad_; };
+
+__device__ __forceinline__ float2 lcmul(float2 v, float2 w)           // spec B's complex product
+{
+    return make_float2(__builtin_fmaf(v.x, w.x, -(v.y * w.y)), __builtin_fmaf(v.x, w.y, v.y * w.x));
+}
+
+// ---------------------------------------------------------------------------------------------
+// spec B stage 1.  grid (NB / 64, transforms, channels), 256 threads.
+template <int NA, int NB>
+__global__ __launch_bounds__(256) void fftb_stage1_kernel(const LongWork *__restrict__ works, FftbTables tb, int which_in, int which_out)
+{
+    __shared__ float2 s_z[NA][64];
+    __shared__ float2 s_wa[NA];
+    const LongWork *w = works + blockIdx.z;
+    const int t = blockIdx.y, b0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float2 *zin = (which_in == 0 ? w->z : w->aux) + (size_t)t * (NA * NB);
+    float2 *yout = (which_out == 0 ? w->y : w->aux + NA * NB) + (size_t)t * (NA * NB);
+    for (int a = wv; a < NA; a += 4) s_z[a][lane] = zin[(size_t)NB * a + b0 + lane];
+    for (int k = tid; k < NA; k += 256) s_wa[k] = tb.wa[k];
+    __syncthreads();
+    const int b = b0 + lane;
+    for (int c = wv; c < NA; c += 4) {                   // c is wave-uniform: the twiddle reads below are LDS broadcasts
+        float P = 0.f, Q = 0.f, R = 0.f, S = 0.f;
+        int idx = 0;
+#pragma unroll 5
+        for (int a = 0; a < NA; ++a) {
+            const float2 wa = s_wa[idx];
+            const float2 x = s_z[a][lane];
+            P = __builtin_fmaf(x.x, wa.x, P);
+            Q = __builtin_fmaf(x.y, wa.y, Q);
+            R = __builtin_fmaf(x.x, wa.y, R);
+            S = __builtin_fmaf(x.y, wa.x, S);
+            idx += c;
+            if (idx >= NA) idx -= NA;
+        }
+        yout[(size_t)c * NB + b] = lcmul(make_float2(P - Q, R + S), tb.wn[b * c]);
+    }
+}
+
+// spec B stage 2.  grid (NA, transforms, channels), 256 threads.  In place on y (row c).
+template <int NA, int NB>
+__global__ __launch_bounds__(256) void fftb_stage2_kernel(const LongWork *__restrict__ works, FftbTables tb, int which)
+{
+    constexpr int LOGB = (NB == 1024) ? 10 : (NB == 512 ? 9 : (NB == 256 ? 8 : 7));
+    static_assert((1 << LOGB) == NB, "NB");
+    __shared__ float2 s_r[NB];
+    __shared__ float2 s_w[NB / 2];
+    const LongWork *w = works + blockIdx.z;
+    float2 *row = (which == 0 ? w->y : w->aux + NA * NB) + ((size_t)blockIdx.y * NA + blockIdx.x) * NB;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < NB / 2; k += 256) s_w[k] = tb.wb[k];
+    for (int b = tid; b < NB; b += 256) s_r[__brev((unsigned)b) >> (32 - LOGB)] = row[b];
+    __syncthreads();
+    for (int len = 2; len <= NB; len <<= 1) {
+        const int half = len >> 1, step = NB / len;
+        for (int q = tid; q < NB / 2; q += 256) {
+            const int k = q & (half - 1), base = (q - k) * 2;
+            const float2 u = s_r[base + k], v = s_r[base + k + half];
+            const float2 tt = lcmul(v, s_w[k * step]);
+            s_r[base + k] = make_float2(u.x + tt.x, u.y + tt.y);
+            s_r[base + k + half] = make_float2(u.x - tt.x, u.y - tt.y);
+        }
+        __syncthreads();
+    }
+    for (int b = tid; b < NB; b += 256) row[b] = s_r[b];
+}
+
+// Z[k] of transform t out of the row-major stage-2 output
+template <int NA, int NB>
+__device__ __forceinline__ float2 fftb_at(const float2 *y, int t, int k)
+{
+    return y[(size_t)t * (NA * NB) + (size_t)(k % NA) * NB + k / NA];
+}
+
+// ---------------------------------------------------------------------------------------------
+// WSPR.  What wsprd reads as sample n of the file the reference writes: a 46-byte header of which wsprd skips 44, so sample 0
+// is the upper half of the data-length field and sample n is frame[n - 1] (longsync_oracle.c:wspr_sample).
+__device__ __forceinline__ float wspr_sample(const int16_t *frame, int frame_len, int n)
+{
+    if (n >= WSPR_NPTS) return 0.0f;
+    int v;
+    if (n == 0) v = (int)(short)(((unsigned)frame_len * 2u) >> 16);
+    else v = (n - 1 < frame_len) ? (int)frame[n - 1] : 0;
+    return (float)v * (1.0f / 32768.0f);
+}
+
+// grid (M / 256, 16, channels)
+__global__ __launch_bounds__(256) void wspr_pack_kernel(const LongWork *__restrict__ works)
+{
+    const LongWork *w = works + blockIdx.z;
+    const int p = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
+    w->z[(size_t)p * WSPR_M + b] = make_float2(wspr_sample(w->frame, w->frame_len, WSPR_R * b + p),
+                                               wspr_sample(w->frame, w->frame_len, WSPR_R * b + p + WSPR_R / 2));
+}
+
+// fftin[i] = sum_{a<32} Y_a[i] T_a[i] (a ascending), stored conjugated as the input of the inverse transform.
+// grid (M / 256, channels).  T: [32][M].
+__global__ __launch_bounds__(256) void wspr_combine_kernel(const LongWork *__restrict__ works, const float2 *__restrict__ T)
+{
+    const LongWork *w = works + blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int m = (WSPR_M - i) % WSPR_M;
+    float2 A[16], B[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) { A[p] = fftb_at<45, 1024>(w->y, p, i); B[p] = fftb_at<45, 1024>(w->y, p, m); }
+    float fr = 0.0f, fi = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {                                   // a = p: Y = (Z[i] + conj Z[M-i]) / 2
+        const float2 Y = make_float2((A[p].x + B[p].x) * 0.5f, (A[p].y - B[p].y) * 0.5f);
+        const float2 tt = lcmul(Y, T[(size_t)p * WSPR_M + i]);
+        fr = fr + tt.x; fi = fi + tt.y;
+    }
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {                                   // a = p + 16: Y = (Z[i] - conj Z[M-i]) / 2i
+        const float2 Y = make_float2((A[p].y + B[p].y) * 0.5f, (B[p].x - A[p].x) * 0.5f);
+        const float2 tt = lcmul(Y, T[(size_t)(p + 16) * WSPR_M + i]);
+        fr = fr + tt.x; fi = fi + tt.y;
+    }
+    w->aux[i] = make_float2(fr, -fi);
+}
+
+// idat/qdat = conj(inverse output) / 1000 (double division, as `fftout/1000.0`), zero tail.  grid (IQ_LEN / 256, channels)
+__global__ __launch_bounds__(256) void wspr_iq_kernel(const LongWork *__restrict__ works)
+{
+    const LongWork *w = works + blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= WSPR_IQ_LEN) return;
+    float2 o = make_float2(0.f, 0.f);
+    if (i < WSPR_M) {
+        const float2 zc = (w->aux + WSPR_M)[(size_t)(i % 45) * 1024 + i / 45];
+        o = make_float2((float)((double)zc.x / 1000.0), (float)((double)(-zc.y) / 1000.0));
+    }
+    w->iq[i] = o;
+}
+
+// 359 windowed 512-point spectra.  grid (359, channels), 256 threads.  ps/sq stored time-major [i][j].
+__global__ __launch_bounds__(256) void wspr_spectra_kernel(const LongWork *__restrict__ works, const float2 *__restrict__ w512,
+                                                            const float *__restrict__ win)
+{
+    __shared__ float2 s_r[512];
+    __shared__ float2 s_w[256];
+    const LongWork *w = works + blockIdx.y;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    s_w[tid] = w512[tid];
+    for (int j = tid; j < 512; j += 256) {
+        const float2 v = w->iq[i * 128 + j];
+        const float wj = win[j];
+        s_r[__brev((unsigned)j) >> 23] = make_float2(v.x * wj, v.y * wj);
+    }
+    __syncthreads();
+    for (int len = 2; len <= 512; len <<= 1) {
+        const int half = len >> 1, step = 512 / len;
+        const int k = tid & (half - 1), base = (tid - k) * 2;
+        const float2 u = s_r[base + k], v = s_r[base + k + half];
+        const float2 tt = lcmul(v, s_w[k * step]);
+        s_r[base + k] = make_float2(u.x + tt.x, u.y + tt.y);
+        s_r[base + k + half] = make_float2(u.x - tt.x, u.y - tt.y);
+        __syncthreads();
+    }
+    for (int j = tid; j < 512; j += 256) {
+        const float2 v = s_r[(j + 256) & 511];
+        const float p = v.x * v.x + v.y * v.y;
+        w->ps[(size_t)i * 512 + j] = p;
+        w->sq[(size_t)i * 512 + j] = sqrtf(p);
+    }
+}
+
+__device__ __forceinline__ double long_log10_fixed(double x)          // = orc_log10_fixed (oracle/sync_oracle.c)
+{
+    if (!(x > 0.0)) return -1.0e300;
+    int e = 0;
+    double m = x;
+    while (m >= 1.4142135623730951) { m = m * 0.5; ++e; }
+    while (m < 0.7071067811865476) { m = m * 2.0; --e; }
+    const double t = (m - 1.0) / (m + 1.0), t2 = t * t;
+    double s = 0.0;
+    for (int k = 21; k >= 1; k -= 2) s = s * t2 + 1.0 / (double)k;
+    const double ln_m = 2.0 * t * s;
+    return ((double)e * 0.6931471805599453 + ln_m) * 0.4342944819032518;
+}
+
+// psavg -> smspec -> noise percentile -> peaks -> snr -> +-110 Hz -> order by snr (stable, descending).  grid (channels), 512 threads.
+__global__ __launch_bounds__(512) void wspr_peaks_kernel(const LongWork *__restrict__ works)
+{
+    __shared__ float s_avg[512], s_sm[416];
+    __shared__ float s_noise;
+    __shared__ int s_flag[416], s_pos[416];
+    __shared__ float s_f[WSPR_MAXCAND], s_snr[WSPR_MAXCAND];
+    __shared__ int s_n;
+    const LongWork *w = works + blockIdx.x;
+    const int tid = threadIdx.x;
+    {
+        float s = 0.0f;
+        for (int i = 0; i < WSPR_NFFTS; ++i) s = s + w->ps[(size_t)i * 512 + tid];
+        s_avg[tid] = s;
+    }
+    __syncthreads();
+    if (tid < 411) {
+        float s = 0.0f;
+#pragma unroll
+        for (int j = -3; j <= 3; ++j) s = s + s_avg[256 - 205 + tid + j];
+        s_sm[tid] = s;
+    }
+    __syncthreads();
+    if (tid < 411) {                                     // the 123rd smallest: the value whose rank interval contains 122
+        const float v = s_sm[tid];
+        int less = 0, eq = 0;
+        for (int x = 0; x < 411; ++x) { const float o = s_sm[x]; less += (o < v) ? 1 : 0; eq += (o == v) ? 1 : 0; }
+        if (less <= 122 && 122 < less + eq) s_noise = v;
+    }
+    __syncthreads();
+    const float noise = s_noise;
+    const float min_snr = 0.15848932f;                   // (float)pow(10.0, -0.8)
+    float sm = 0.0f;
+    if (tid < 411) {
+        sm = (float)((double)(s_sm[tid] / noise) - 1.0);
+        if (sm < min_snr) sm = (float)(0.1 * (double)min_snr);
+    }
+    __syncthreads();
+    if (tid < 411) { s_sm[tid] = sm; w->vec[tid] = sm; }
+    __syncthreads();
+    const float df = 0.732421875f;                       // 375/256/2
+    int flag = 0;
+    if (tid >= 1 && tid < 410) flag = (s_sm[tid] > s_sm[tid - 1] && s_sm[tid] > s_sm[tid + 1]) ? 1 : 0;
+    if (tid < 416) s_flag[tid] = flag;
+    __syncthreads();
+    if (tid == 0) {                                      // 411 flags: a serial compaction is short, and keeps "npk < 200" literal
+        int npk = 0;
+        for (int j = 1; j < 410; ++j) { s_pos[j] = -1; if (s_flag[j] && npk < WSPR_MAXCAND) s_pos[j] = npk++; }
+        s_n = npk;
+    }
+    __syncthreads();
+    if (tid >= 1 && tid < 410 && s_pos[tid] >= 0) {
+        s_f[s_pos[tid]] = (float)(tid - 205) * df;
+        s_snr[s_pos[tid]] = (float)(10.0 * long_log10_fixed((double)s_sm[tid]) - (double)26.3f);
+    }
+    __syncthreads();
+    if (tid == 0) {                                      // keep |freq| <= 110 Hz, in order
+        int n2 = 0;
+        for (int j = 0; j < s_n; ++j)
+            if (s_f[j] >= -110.0f && s_f[j] <= 110.0f) { s_f[n2] = s_f[j]; s_snr[n2] = s_snr[j]; ++n2; }
+        s_n = n2;
+    }
+    __syncthreads();
+    const int npk = s_n;
+    // wsprd's bubble sort (swap when snr[k] < snr[k+1]) is a stable descending sort: rank = #greater + #equal-and-earlier
+    if (tid < npk) {
+        const float v = s_snr[tid];
+        int rank = 0;
+        for (int x = 0; x < npk; ++x) { const float o = s_snr[x]; rank += (o > v || (o == v && x < tid)) ? 1 : 0; }
+        WsprCand c;
+        c.freq_hz = s_f[tid]; c.snr_db = v; c.drift = 0.0f; c.sync = 0.0f; c.shift = 0;
+        reinterpret_cast<WsprCand *>(w->cand)[rank] = c;
+    }
+    if (tid == 0) *w->ncand = npk;
+}
+
+// Coarse (freq, shift, drift) search of one candidate.  grid (WSPR_MAXCAND, channels), 256 threads: 5 x 32 x 9 = 1440 combinations,
+// each a sequential sum over the 162 sync-vector symbols; first maximum in (ifr, k0, idrift) order wins.
+__global__ __launch_bounds__(256) void wspr_coarse_kernel(const LongWork *__restrict__ works, const unsigned char *__restrict__ pr3)
+{
+    __shared__ unsigned long long s_key[256];
+    __shared__ float s_sgn[162];
+    const LongWork *w = works + blockIdx.y;
+    const int j = blockIdx.x, tid = threadIdx.x;
+    if (j >= *w->ncand) return;
+    WsprCand *cand = reinterpret_cast<WsprCand *>(w->cand) + j;
+    if (tid < 162) s_sgn[tid] = (float)(2 * (int)pr3[tid] - 1);
+    __syncthreads();
+    const float df = 0.732421875f;
+    const int if0 = (int)(cand->freq_hz / df + 256.0f);
+    const float *sq = w->sq;
+    unsigned long long best = 0ull;
+    for (int combo = tid; combo < 1440; combo += 256) {
+        const int idrift = combo % 9 - 4, k0 = (combo / 9) % 32 - 10, ifr = if0 - 2 + combo / 288;
+        float ss = 0.0f, pw = 0.0f;
+        for (int k = 0; k < 162; ++k) {
+            const int ifd = (int)((double)ifr + ((double)(float)k - 81.0) / 81.0 * (double)(float)idrift / (2.0 * (double)df));
+            const int kindex = k0 + 2 * k;
+            if (kindex < WSPR_NFFTS) {
+                // wsprd's ps[r][kindex] on the contiguous [512][359] array: a negative kindex is the end of row r - 1
+                float p[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int flat = (ifd - 3 + 2 * q) * WSPR_NFFTS + kindex;
+                    const int jj = flat / WSPR_NFFTS, ii = flat - jj * WSPR_NFFTS;
+                    p[q] = sq[(size_t)ii * 512 + jj];
+                }
+                ss = ss + s_sgn[k] * ((p[1] + p[3]) - (p[0] + p[2]));
+                pw = pw + p[0] + p[1] + p[2] + p[3];
+            }
+        }
+        const float sync1 = ss / pw;
+        if (sync1 > -1e30f) {                            // also false for NaN: such a combination never becomes the maximum
+            unsigned u = __float_as_uint(sync1);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            const unsigned long long key = ((unsigned long long)u << 32) | (unsigned)(0xFFFF - combo);   // ties: the earlier combination
+            best = key > best ? key : best;
+        }
+    }
+    s_key[tid] = best;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) { const unsigned long long o = s_key[tid + off]; if (o > s_key[tid]) s_key[tid] = o; }
+        __syncthreads();
+    }
+    if (tid == 0 && s_key[0] != 0ull) {
+        const unsigned long long key = s_key[0];
+        const int combo = 0xFFFF - (int)(key & 0xFFFFu);
+        unsigned u = (unsigned)(key >> 32);
+        u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+        const int idrift = combo % 9 - 4, k0 = (combo / 9) % 32 - 10, ifr = if0 - 2 + combo / 288;
+        cand->shift = 128 * (k0 + 1);
+        cand->drift = (float)idrift;
+        cand->freq_hz = (float)(ifr - 256) * df;
+        cand->sync = __uint_as_float(u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FST4W-120.  grid (M / 256, 23, channels): z[p][b] = x[45 b + p] + i x[45 b + p + 22]; p = 22 carries a = 44 alone.
+__global__ __launch_bounds__(256) void fst4w_pack_kernel(const LongWork *__restrict__ works)
+{
+    const LongWork *w = works + blockIdx.z;
+    const int p = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
+    const int a1 = (p < 22) ? p : 44;
+    const int n1 = F4W_R * b + a1, n2 = F4W_R * b + p + 22;
+    const float x1 = (n1 < w->frame_len && n1 < F4W_NMAX) ? (float)w->frame[n1] : 0.0f;
+    const float x2 = (p < 22 && n2 < w->frame_len && n2 < F4W_NMAX) ? (float)w->frame[n2] : 0.0f;
+    w->z[(size_t)p * F4W_M + b] = make_float2(x1, x2);
+}
+
+// c_bigfft(j) for j = jlo .. jlo + nband - 1.  grid (ceil(nband / 256), channels).  T: [45][nband].
+__global__ __launch_bounds__(256) void fst4w_band_kernel(const LongWork *__restrict__ works, const float2 *__restrict__ T, int jlo, int nband)
+{
+    const LongWork *w = works + blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nband) return;
+    const int i = (jlo + q) % F4W_M, m = (F4W_M - i) % F4W_M;
+    float fr = 0.0f, fi = 0.0f;
+    for (int a = 0; a < F4W_R; ++a) {
+        const int p = (a < 22) ? a : (a < 44 ? a - 22 : 22);
+        const float2 A = fftb_at<125, 256>(w->y, p, i), B = fftb_at<125, 256>(w->y, p, m);
+        const bool second = a >= 22 && a < 44;
+        const float2 Y = second ? make_float2((A.y + B.y) * 0.5f, (B.x - A.x) * 0.5f) : make_float2((A.x + B.x) * 0.5f, (A.y - B.y) * 0.5f);
+        const float2 tt = lcmul(Y, T[(size_t)a * nband + q]);
+        fr = fr + tt.x; fi = fi + tt.y;
+    }
+    w->aux[q] = make_float2(fr, fi);
+}
+
+struct Fst4wParams { int ina, inb, ia, ib, ndh, jlo, nnw; float df1, df2, minsync; };
+
+// s(i), s2(i), percentile, CLEAN peak pick.  grid (channels), 512 threads; the band is at most a few hundred comb bins wide.
+__global__ __launch_bounds__(512) void fst4w_cand_kernel(const LongWork *__restrict__ works, Fst4wParams P)
+{
+    constexpr int MAXW = 1024;                           // comb bins in the search window (1400..1600 Hz: 275)
+    __shared__ float s_s[MAXW + 8], s_s2[MAXW + 8];
+    __shared__ float s_base;
+    __shared__ unsigned long long s_key[512];
+    const LongWork *w = works + blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lo = P.ina - 4, width = P.inb - P.ina + 9;  // local index l = i - lo, with 4 bins of zero margin each side
+    for (int l = tid; l < MAXW + 8; l += 512) { s_s[l] = 0.0f; s_s2[l] = 0.0f; }
+    __syncthreads();
+    for (int i = P.ina + tid; i <= P.inb; i += 512) {
+        const int j0 = (int)lroundf((float)i * P.df2 / P.df1);
+        float acc = 0.0f;
+        for (int j = j0 - P.ndh; j <= j0 + P.ndh; ++j) {
+            const float2 v = w->aux[j - P.jlo];
+            acc = acc + v.x * v.x + v.y * v.y;
+        }
+        s_s[i - lo] = acc;
+    }
+    __syncthreads();
+    int ina = P.ina, inb = P.inb;
+    if (ina < 4) ina = 4;                                // max(ina, 1 + 3 hmod)
+    if (inb > P.nnw - 3) inb = P.nnw - 3;
+    for (int i = ina + tid; i <= inb; i += 512) s_s2[i - lo] = s_s[i - 3 - lo] + s_s[i - 1 - lo] + s_s[i + 1 - lo] + s_s[i + 3 - lo];
+    __syncthreads();
+    const int plo = ina + 3, npts = inb - ina + 1 - 6;
+    if (npts < 1) { if (tid == 0) *w->ncand = 0; return; }
+    int jp = (int)lroundf((float)npts * 0.01f * 30.0f);
+    if (jp < 1) jp = 1;
+    if (jp > npts) jp = npts;
+    for (int e = tid; e < npts; e += 512) {
+        const float v = s_s2[plo + e - lo];
+        int less = 0, eq = 0;
+        for (int x = 0; x < npts; ++x) { const float o = s_s2[plo + x - lo]; less += (o < v) ? 1 : 0; eq += (o == v) ? 1 : 0; }
+        if (less <= jp - 1 && jp - 1 < less + eq) s_base = v;
+    }
+    __syncthreads();
+    const float base = s_base;
+    for (int l = tid; l < width; l += 512) s_s2[l] = s_s2[l] / base;
+    __syncthreads();
+    for (int i = tid; i < P.nnw; i += 512) {             // the normalised comb spectrum, for the parity tests
+        const int l = i - lo;
+        w->vec[i] = (l >= 0 && l < width) ? s_s2[l] : 0.0f;
+    }
+    int ia = P.ia, ib = P.ib;
+    if (ia < 3) ia = 3;
+    if (ib > P.nnw - 2) ib = P.nnw - 2;
+    const float xdb[7] = {0.25f, 0.50f, 0.75f, 1.0f, 0.75f, 0.50f, 0.25f};
+    Fst4wCand *out = reinterpret_cast<Fst4wCand *>(w->cand);
+    int ncand = 0;
+    while (ncand < F4W_MAXCAND) {
+        unsigned long long best = 0ull;
+        for (int i = ia + tid; i <= ib; i += 512) {
+            unsigned u = __float_as_uint(s_s2[i - lo]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+            const unsigned long long key = ((unsigned long long)u << 32) | (unsigned)(0xFFFFFF - i);      // maxloc: first maximum
+            best = key > best ? key : best;
+        }
+        s_key[tid] = best;
+        __syncthreads();
+        for (int off = 256; off >= 1; off >>= 1) {
+            if (tid < off) { const unsigned long long o = s_key[tid + off]; if (o > s_key[tid]) s_key[tid] = o; }
+            __syncthreads();
+        }
+        const unsigned long long key = s_key[0];
+        __syncthreads();
+        const int ip = 0xFFFFFF - (int)(key & 0xFFFFFFu);
+        const float pval = s_s2[ip - lo];
+        if (pval < P.minsync) break;
+        if (tid < 7) {
+            const int k = ip + 2 * (tid - 3);
+            if (k >= ia && k <= ib) {
+                const float v = s_s2[k - lo] - 0.9f * pval * xdb[tid];
+                s_s2[k - lo] = (v > 0.0f) ? v : 0.0f;
+            }
+        }
+        if (tid == 0) { Fst4wCand c; c.freq_hz = P.df2 * (float)ip; c.snr = pval; c.bin = ip; c.pad_ = 0; out[ncand] = c; }
+        ++ncand;
+        __syncthreads();
+    }
+    if (tid == 0) *w->ncand = ncand;
+}
+
+} // namespace cwslg

@@ -276,6 +276,39 @@ int cwslg_set_ft4_syncmin(cwslg_ctx *ctx, float syncmin);
  * 5 = frame spectrum (complex float[36289]), 6 = unit-power baseband of candidate 0 (complex float[4032]). */
 int cwslg_sync_debug_fetch(cwslg_ctx *ctx, int ch_id, int what, void *dst, size_t cap_bytes, size_t *n_items, int *row_len);
 
+/* ---- candidate search of the 120 s modes (BASELINE.json configs[4]) ----
+ * PARITY UNPINNED like the FT8/FT4 stage: the reference hands WSPR frames to `wsprd -C <cycles> -o 5 -d <wav>` and FST4W-120
+ * frames to `jt9 -W -p 120 ... -L 1400 -H 1600 -F 200 <wav>` (DecoderPool.hpp:1019-1033); what runs here is the candidate-finding
+ * front end of those programs as restated in oracle/longsync_oracle.c.  When enabled, cwslg_slot_boundary() runs it on every
+ * WSPR / FST4W-120 frame it finalises.
+ *   WSPR:  wsprd.c main(): FFT-based /32 down-conversion to 375 Hz around 1500 Hz, 359 half-symbol 512-point spectra, smoothed
+ *          spectrum / noise percentile / local maxima within +-110 Hz ordered by snr, then per candidate the coarse
+ *          (frequency, shift, drift) search on the 162-symbol sync vector.  freq_hz is relative to 1500 Hz audio; shift is in
+ *          375 Hz samples from the start of the file (wsprd prints DT = shift/375 - 2 s).
+ *   FST4W: get_candidates_fst4.f90: comb-summed power spectrum over [nfa, nfb], 30th-percentile normalisation, CLEAN peak pick
+ *          above minsync (at most 100), in order of discovery (strongest first). */
+typedef struct {
+    float   freq_hz;
+    float   snr_db;
+    float   drift;
+    float   sync;
+    int32_t shift;
+} cwslg_wspr_candidate;
+typedef struct {
+    float   freq_hz;
+    float   snr;            /* peak of the normalised comb spectrum ("rough estimate of SNR") */
+    int32_t bin;            /* index on the baud/2 grid */
+    int32_t pad_;
+} cwslg_fst4w_candidate;
+int cwslg_enable_long_sync(cwslg_ctx *ctx, int enable, int fst4w_nfa_hz, int fst4w_nfb_hz, float fst4w_minsync);
+int cwslg_fetch_wspr_candidates(cwslg_ctx *ctx, int ch_id, cwslg_wspr_candidate *dst, int max, int *n);
+int cwslg_fetch_fst4w_candidates(cwslg_ctx *ctx, int ch_id, cwslg_fst4w_candidate *dst, int max, int *n);
+/* Intermediate results for parity tests.  WSPR channels: what = 0 the 375 Hz baseband (complex float[46080]), 1 the spectra
+ * (float[359][512], time-major: wsprd's ps[j][i] is element [i][j]), 2 the normalised smoothed spectrum (float[411]).
+ * FST4W channels: 3 the normalised comb spectrum s2 (float, indexed by the baud/2 bin), 4 the band of the long transform
+ * (complex float, first bin = nint(ina*df2/df1) - ndh). */
+int cwslg_long_sync_debug_fetch(cwslg_ctx *ctx, int ch_id, int what, void *dst, size_t cap_bytes, size_t *n_items);
+
 /* ---- introspection for bench / tests ---- */
 typedef struct {
     uint64_t demod_launches;       /* demod kernel launches                                   */

@@ -587,3 +587,59 @@ def ft4_candidates(frame_i16, fa_hz=200.0, fb_hz=4000.0, syncmin=1.2, maxcand=20
 def bench_cpu_reference(threads, slots, fs=192000, iq_len=2048, n_per_slot=2880000):
     """Wall seconds of the REFERENCE's own SSBD<float> loop (oracle/_ref) for `threads` channels x `slots` slots."""
     return float(ref().ref_bench_cpu(threads, slots, fs, iq_len, n_per_slot))
+
+
+# ---------------------------------------------------------------------------------------------- 120 s modes (row a14)
+class _WsprCand(C.Structure):
+    _fields_ = [("freq_hz", C.c_float), ("snr_db", C.c_float), ("drift", C.c_float), ("sync", C.c_float), ("shift", C.c_int32)]
+
+
+class _Fst4wCand(C.Structure):
+    _fields_ = [("freq_hz", C.c_float), ("snr", C.c_float), ("bin", C.c_int32), ("pad_", C.c_int32)]
+
+
+def fftb(na, nb, x, inverse=False):
+    """spec B transform of na*nb complex points (longsync_oracle.c)."""
+    re = np.ascontiguousarray(x.real, dtype=np.float32).copy()
+    im = np.ascontiguousarray(x.imag, dtype=np.float32).copy()
+    L = lib()
+    L.orc_fftb.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    assert L.orc_fftb(na, nb, re.ctypes.data, im.ctypes.data, 1 if inverse else 0) == 0
+    return re + 1j * im
+
+
+def wspr_downsample(frame_i16):
+    fr = np.ascontiguousarray(frame_i16, dtype=np.int16)
+    i = np.empty(46080, np.float32); q = np.empty(46080, np.float32)
+    L = lib()
+    L.orc_wspr_downsample.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    assert L.orc_wspr_downsample(fr.ctypes.data, len(fr), i.ctypes.data, q.ctypes.data) == 0
+    return i, q
+
+
+def wspr_search(frame_i16, want_arrays=False):
+    """-> list of (freq_hz, snr_db, drift, sync, shift) [, dict(idat, qdat, ps[512,359], smspec[411])]."""
+    fr = np.ascontiguousarray(frame_i16, dtype=np.int16)
+    out = (_WsprCand * 200)()
+    arr = dict(idat=np.empty(46080, np.float32), qdat=np.empty(46080, np.float32), ps=np.empty((512, 359), np.float32),
+               smspec=np.empty(411, np.float32))
+    L = lib()
+    L.orc_wspr_search.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 4
+    n = L.orc_wspr_search(fr.ctypes.data, len(fr), out, 200, arr["idat"].ctypes.data, arr["qdat"].ctypes.data,
+                          arr["ps"].ctypes.data, arr["smspec"].ctypes.data)
+    assert n >= 0
+    cands = [(c.freq_hz, c.snr_db, c.drift, c.sync, c.shift) for c in out[:n]]
+    return (cands, arr) if want_arrays else cands
+
+
+def fst4w_candidates(frame_i16, nfa_hz=1400, nfb_hz=1600, minsync=1.2, want_arrays=False):
+    """-> list of (freq_hz, snr, bin) [, dict(s2[n], band[nband])]."""
+    fr = np.ascontiguousarray(frame_i16, dtype=np.int16)
+    out = (_Fst4wCand * 100)()
+    s2 = np.zeros(8192, np.float32); band = np.zeros(32000, np.float32)
+    L = lib()
+    L.orc_fst4w_candidates.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    n = L.orc_fst4w_candidates(fr.ctypes.data, len(fr), nfa_hz, nfb_hz, minsync, out, 100, s2.ctypes.data, len(s2), band.ctypes.data)
+    assert n >= 0
+    cands = [(c.freq_hz, c.snr, c.bin) for c in out[:n]]
+    return (cands, dict(s2=s2, band=band)) if want_arrays else cands
