@@ -69,7 +69,7 @@ struct LongConfig {
 };
 
 struct LongShared {                             // device tables of the 120 s modes' search
-    struct Plan { float2 *wa = nullptr, *wn = nullptr, *wb = nullptr; } p45, p125;
+    struct Plan { float2 *wa = nullptr, *wn = nullptr, *wb = nullptr, *wfull = nullptr; } p45, p125;
     float2 *d_wspr_T = nullptr, *d_f4w_T = nullptr, *d_w512 = nullptr;
     float *d_win512 = nullptr;
     unsigned char *d_pr3 = nullptr;

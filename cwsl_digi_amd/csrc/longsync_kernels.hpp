@@ -26,6 +26,7 @@ constexpr int F4W_NMAX = 1440000, F4W_NSPS = 8200, F4W_M = 32000, F4W_R = 45, F4
 
 struct FftbTables {                          // device pointers
     const float2 *wa, *wn, *wb;              // NA | N | NB/2
+    const float2 *wfull;                     // [NA][NA]: wfull[c][a] = wa[(a c) mod NA], the stage-1 matrix row by row
 };
 
 struct alignas(16) LongWork {                // one per channel per launch
@@ -51,36 +52,70 @@ __device__ __forceinline__ float2 lcmul(float2 v, float2 w)           // spec B'
 }
 
 // ---------------------------------------------------------------------------------------------
-// spec B stage 1.  grid (NB / 64, transforms, channels), 256 threads.
+// spec B stage 1.  grid (NB / 64, transforms, channels), FFTB_S1_NT threads (8 waves: with the 64 KB tile of NA = 125 two workgroups
+// fit a CU, and the scalar twiddle loads need the 4 waves per SIMD to hide their latency).
+constexpr int FFTB_S1_NT = 512;
 template <int NA, int NB>
-__global__ __launch_bounds__(256) void fftb_stage1_kernel(const LongWork *__restrict__ works, FftbTables tb, int which_in, int which_out)
+__global__ __launch_bounds__(FFTB_S1_NT, 4) void fftb_stage1_kernel(const LongWork *__restrict__ works, FftbTables tb, const float2 *__restrict__ wfull,
+                                                          int which_in, int which_out)
 {
     __shared__ float2 s_z[NA][64];
-    __shared__ float2 s_wa[NA];
     const LongWork *w = works + blockIdx.z;
     const int t = blockIdx.y, b0 = blockIdx.x * 64;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float2 *zin = (which_in == 0 ? w->z : w->aux) + (size_t)t * (NA * NB);
     float2 *yout = (which_out == 0 ? w->y : w->aux + NA * NB) + (size_t)t * (NA * NB);
-    for (int a = wv; a < NA; a += 4) s_z[a][lane] = zin[(size_t)NB * a + b0 + lane];
-    for (int k = tid; k < NA; k += 256) s_wa[k] = tb.wa[k];
+    {   // the wave's share of the tile: every load issued before the first LDS write (a load-wait-store loop paid one memory
+        // latency per row: 32 in a row for NA = 125)
+        constexpr int NWV = FFTB_S1_NT / 64;
+        constexpr int PER = (NA + NWV - 1) / NWV;
+        const CWSLG_GLOBAL v2f *zg = as_global(reinterpret_cast<const v2f *>(zin)) + b0 + lane;
+        float2 tmp[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int a = wv + NWV * q;
+            tmp[q] = make_float2(0.f, 0.f);
+            if (a < NA) { const v2f v = zg[(size_t)NB * a]; tmp[q] = make_float2(v.x, v.y); }
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int a = wv + NWV * q;
+            if (a < NA) s_z[a][lane] = tmp[q];
+        }
+    }
     __syncthreads();
     const int b = b0 + lane;
-    for (int c = wv; c < NA; c += 4) {                   // c is wave-uniform: the twiddle reads below are LDS broadcasts
-        float P = 0.f, Q = 0.f, R = 0.f, S = 0.f;
-        int idx = 0;
-#pragma unroll 5
-        for (int a = 0; a < NA; ++a) {
-            const float2 wa = s_wa[idx];
-            const float2 x = s_z[a][lane];
-            P = __builtin_fmaf(x.x, wa.x, P);
-            Q = __builtin_fmaf(x.y, wa.y, Q);
-            R = __builtin_fmaf(x.x, wa.y, R);
-            S = __builtin_fmaf(x.y, wa.x, S);
-            idx += c;
-            if (idx >= NA) idx -= NA;
+    // Five outputs per pass over the column (one LDS read of the input feeds 20 fmaf); their twiddles W_NA^(a c) are read from
+    // the row-major matrix wfull[c][a] with wave-uniform addresses, i.e. by the scalar unit into SGPR operands of the fmaf.
+    // (First version: (a c) mod NA tracked in scalar registers + an LDS broadcast read per 4 fmaf -- as many SALU and LDS
+    // instructions as fmaf, 4.2 ms per 128 FST4W frames against a VALU time of 0.7 ms.)  Each output's chain is still its own
+    // four accumulators walked in ascending a, so the bits do not change.
+    constexpr int CB = 5;
+    static_assert(NA % CB == 0 && NA % 5 == 0, "NA is a multiple of the output block and of the unroll");
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    for (int cg = wvu; cg < NA / CB; cg += FFTB_S1_NT / 64) {
+        const int c0 = cg * CB;
+        const float2 *__restrict__ wrow = wfull + (size_t)c0 * NA;    // a __restrict__ kernel argument: provably read-only, so scalar loads
+        float P[CB], Q[CB], R[CB], S[CB];
+#pragma unroll
+        for (int j = 0; j < CB; ++j) { P[j] = Q[j] = R[j] = S[j] = 0.f; }
+        for (int a0 = 0; a0 < NA; a0 += 5) {
+#pragma unroll
+            for (int u = 0; u < 5; ++u) {
+                const float2 x = s_z[a0 + u][lane];
+#pragma unroll
+                for (int j = 0; j < CB; ++j) {
+                    const float2 wa = wrow[j * NA + a0 + u];
+                    P[j] = __builtin_fmaf(x.x, wa.x, P[j]);
+                    Q[j] = __builtin_fmaf(x.y, wa.y, Q[j]);
+                    R[j] = __builtin_fmaf(x.x, wa.y, R[j]);
+                    S[j] = __builtin_fmaf(x.y, wa.x, S[j]);
+                }
+            }
         }
-        yout[(size_t)c * NB + b] = lcmul(make_float2(P - Q, R + S), tb.wn[b * c]);
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+            yout[(size_t)(c0 + j) * NB + b] = lcmul(make_float2(P[j] - Q[j], R[j] + S[j]), tb.wn[b * (c0 + j)]);
     }
 }
 
@@ -131,39 +166,58 @@ __device__ __forceinline__ float wspr_sample(const int16_t *frame, int frame_len
     return (float)v * (1.0f / 32768.0f);
 }
 
-// grid (M / 256, 16, channels)
+// grid (M / 256, channels): 256 consecutive b = 8192 consecutive samples, read once (coalesced), dealt out to the 16 packed
+// sequences through LDS (index n + n/32: the stride-32 reads of the deal fall on 32 different banks).
 __global__ __launch_bounds__(256) void wspr_pack_kernel(const LongWork *__restrict__ works)
 {
-    const LongWork *w = works + blockIdx.z;
-    const int p = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
-    w->z[(size_t)p * WSPR_M + b] = make_float2(wspr_sample(w->frame, w->frame_len, WSPR_R * b + p),
-                                               wspr_sample(w->frame, w->frame_len, WSPR_R * b + p + WSPR_R / 2));
+    __shared__ float s_x[WSPR_R * 256 + 256];
+    const LongWork *w = works + blockIdx.y;
+    const int b0 = blockIdx.x * 256, tid = threadIdx.x;
+    for (int k = 0; k < WSPR_R; ++k) {
+        const int n = 256 * k + tid;
+        s_x[n + (n >> 5)] = wspr_sample(w->frame, w->frame_len, WSPR_R * b0 + n);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int p = 0; p < WSPR_R / 2; ++p) {
+        const int n1 = WSPR_R * tid + p, n2 = n1 + WSPR_R / 2;
+        w->z[(size_t)p * WSPR_M + b0 + tid] = make_float2(s_x[n1 + (n1 >> 5)], s_x[n2 + (n2 >> 5)]);
+    }
 }
 
 // fftin[i] = sum_{a<32} Y_a[i] T_a[i] (a ascending), stored conjugated as the input of the inverse transform.
-// grid (M / 256, channels).  T: [32][M].
+// grid (45, channels), 256 threads: the workgroup owns the residue c = i mod 45, its threads walk d (i = c + 45 d), so Z_p[i] =
+// y[p][c][d] and its mirror Z_p[M - i] = y[p][45 - c][1023 - d] are read along rows (the first version gathered both across
+// rows: 32 scattered 8-byte loads per output).  T is stored in the same order: T[a][c][d].
 __global__ __launch_bounds__(256) void wspr_combine_kernel(const LongWork *__restrict__ works, const float2 *__restrict__ T)
 {
     const LongWork *w = works + blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int m = (WSPR_M - i) % WSPR_M;
-    float2 A[16], B[16];
+    const int c = blockIdx.x;
+    const int cm = (c == 0) ? 0 : 45 - c;
+    for (int d = threadIdx.x; d < 1024; d += 256) {
+        const int dm = (c == 0) ? ((1024 - d) & 1023) : 1023 - d;
+        float2 A[16], B[16];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) { A[p] = fftb_at<45, 1024>(w->y, p, i); B[p] = fftb_at<45, 1024>(w->y, p, m); }
-    float fr = 0.0f, fi = 0.0f;
+        for (int p = 0; p < 16; ++p) {
+            A[p] = w->y[(size_t)p * WSPR_M + (size_t)c * 1024 + d];
+            B[p] = w->y[(size_t)p * WSPR_M + (size_t)cm * 1024 + dm];
+        }
+        const float2 *Tc = T + (size_t)c * 1024 + d;
+        float fr = 0.0f, fi = 0.0f;
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {                                   // a = p: Y = (Z[i] + conj Z[M-i]) / 2
-        const float2 Y = make_float2((A[p].x + B[p].x) * 0.5f, (A[p].y - B[p].y) * 0.5f);
-        const float2 tt = lcmul(Y, T[(size_t)p * WSPR_M + i]);
-        fr = fr + tt.x; fi = fi + tt.y;
+        for (int p = 0; p < 16; ++p) {                               // a = p: Y = (Z[i] + conj Z[M-i]) / 2
+            const float2 Y = make_float2((A[p].x + B[p].x) * 0.5f, (A[p].y - B[p].y) * 0.5f);
+            const float2 tt = lcmul(Y, Tc[(size_t)p * WSPR_M]);
+            fr = fr + tt.x; fi = fi + tt.y;
+        }
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {                               // a = p + 16: Y = (Z[i] - conj Z[M-i]) / 2i
+            const float2 Y = make_float2((A[p].y + B[p].y) * 0.5f, (B[p].x - A[p].x) * 0.5f);
+            const float2 tt = lcmul(Y, Tc[(size_t)(p + 16) * WSPR_M]);
+            fr = fr + tt.x; fi = fi + tt.y;
+        }
+        w->aux[c + 45 * d] = make_float2(fr, -fi);
     }
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {                                   // a = p + 16: Y = (Z[i] - conj Z[M-i]) / 2i
-        const float2 Y = make_float2((A[p].y + B[p].y) * 0.5f, (B[p].x - A[p].x) * 0.5f);
-        const float2 tt = lcmul(Y, T[(size_t)(p + 16) * WSPR_M + i]);
-        fr = fr + tt.x; fi = fi + tt.y;
-    }
-    w->aux[i] = make_float2(fr, -fi);
 }
 
 // idat/qdat = conj(inverse output) / 1000 (double division, as `fftout/1000.0`), zero tail.  grid (IQ_LEN / 256, channels)
@@ -308,6 +362,7 @@ __global__ __launch_bounds__(256) void wspr_coarse_kernel(const LongWork *__rest
 {
     __shared__ unsigned long long s_key[256];
     __shared__ float s_sgn[162];
+    __shared__ float s_sq[WSPR_NFFTS * 20];
     const LongWork *w = works + blockIdx.y;
     const int j = blockIdx.x, tid = threadIdx.x;
     if (j >= *w->ncand) return;
@@ -316,7 +371,14 @@ __global__ __launch_bounds__(256) void wspr_coarse_kernel(const LongWork *__rest
     __syncthreads();
     const float df = 0.732421875f;
     const int if0 = (int)(cand->freq_hz / df + 256.0f);
-    const float *sq = w->sq;
+    // every read of the search lies in spectrum rows if0 - 9 .. if0 + 7 (ifr = if0 +- 2, drift +- 2.73 bins, the four tones at
+    // ifd +- 1, +- 3, and one row lower when a negative kindex wraps): keep columns [if0 - 10, if0 + 10) of sq[i][.] in LDS
+    const int jb = if0 - 10;
+    for (int e = tid; e < WSPR_NFFTS * 20; e += 256) {
+        const int ii = e / 20, jc = e - ii * 20, jj = jb + jc;
+        s_sq[e] = (jj >= 0 && jj < 512) ? w->sq[(size_t)ii * 512 + jj] : 0.0f;
+    }
+    __syncthreads();
     unsigned long long best = 0ull;
     for (int combo = tid; combo < 1440; combo += 256) {
         const int idrift = combo % 9 - 4, k0 = (combo / 9) % 32 - 10, ifr = if0 - 2 + combo / 288;
@@ -329,9 +391,9 @@ __global__ __launch_bounds__(256) void wspr_coarse_kernel(const LongWork *__rest
                 float p[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int flat = (ifd - 3 + 2 * q) * WSPR_NFFTS + kindex;
-                    const int jj = flat / WSPR_NFFTS, ii = flat - jj * WSPR_NFFTS;
-                    p[q] = sq[(size_t)ii * 512 + jj];
+                    int jj = ifd - 3 + 2 * q, ii = kindex;
+                    if (ii < 0) { ii += WSPR_NFFTS; jj -= 1; }
+                    p[q] = s_sq[ii * 20 + (jj - jb)];
                 }
                 ss = ss + s_sgn[k] * ((p[1] + p[3]) - (p[0] + p[2]));
                 pw = pw + p[0] + p[1] + p[2] + p[3];
@@ -365,35 +427,50 @@ __global__ __launch_bounds__(256) void wspr_coarse_kernel(const LongWork *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// FST4W-120.  grid (M / 256, 23, channels): z[p][b] = x[45 b + p] + i x[45 b + p + 22]; p = 22 carries a = 44 alone.
+// FST4W-120.  z[p][b] = x[45 b + p] + i x[45 b + p + 22]; p = 22 carries a = 44 alone.  grid (M / 256, channels): 256 consecutive b =
+// 11520 consecutive samples read once, dealt out through LDS (stride 45 is odd: conflict-free).
 __global__ __launch_bounds__(256) void fst4w_pack_kernel(const LongWork *__restrict__ works)
 {
-    const LongWork *w = works + blockIdx.z;
-    const int p = blockIdx.y, b = blockIdx.x * 256 + threadIdx.x;
-    const int a1 = (p < 22) ? p : 44;
-    const int n1 = F4W_R * b + a1, n2 = F4W_R * b + p + 22;
-    const float x1 = (n1 < w->frame_len && n1 < F4W_NMAX) ? (float)w->frame[n1] : 0.0f;
-    const float x2 = (p < 22 && n2 < w->frame_len && n2 < F4W_NMAX) ? (float)w->frame[n2] : 0.0f;
-    w->z[(size_t)p * F4W_M + b] = make_float2(x1, x2);
+    __shared__ float s_x[F4W_R * 256];
+    const LongWork *w = works + blockIdx.y;
+    const int b0 = blockIdx.x * 256, tid = threadIdx.x;
+    for (int k = 0; k < F4W_R; ++k) {
+        const int n = F4W_R * b0 + 256 * k + tid;
+        s_x[256 * k + tid] = (n < w->frame_len && n < F4W_NMAX) ? (float)w->frame[n] : 0.0f;
+    }
+    __syncthreads();
+    for (int p = 0; p < 23; ++p) {
+        const float x1 = s_x[F4W_R * tid + (p < 22 ? p : 44)];
+        const float x2 = (p < 22) ? s_x[F4W_R * tid + p + 22] : 0.0f;
+        w->z[(size_t)p * F4W_M + b0 + tid] = make_float2(x1, x2);
+    }
 }
 
-// c_bigfft(j) for j = jlo .. jlo + nband - 1.  grid (ceil(nband / 256), channels).  T: [45][nband].
+// c_bigfft(k) for k = jlo .. jlo + nband - 1.  grid (125, channels), 256 threads: the workgroup owns the residue c = k mod 125 and
+// its threads walk d (k = c + 125 dd), so Y's two operands Z_p[i] = y[p][c][d] and Z_p[M - i] = y[p][125 - c][255 - d] are read
+// along rows (the first version gathered 90 scattered 8-byte values per output: 4.1 ms per 128 frames).  T is stored in the
+// same order: T[a][c][t], t = dd - dlo(c) < F4W_TP.
+constexpr int F4W_TP = 200;
 __global__ __launch_bounds__(256) void fst4w_band_kernel(const LongWork *__restrict__ works, const float2 *__restrict__ T, int jlo, int nband)
 {
     const LongWork *w = works + blockIdx.y;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= nband) return;
-    const int i = (jlo + q) % F4W_M, m = (F4W_M - i) % F4W_M;
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int dlo = (jlo - c + 124) / 125;                   // first dd with c + 125 dd >= jlo  (jlo > 125)
+    const int k = c + 125 * (dlo + t);
+    if (t >= F4W_TP || k >= jlo + nband) return;
+    const int d = (dlo + t) & 255;
+    const int cm = (c == 0) ? 0 : 125 - c, dm = (c == 0) ? ((256 - d) & 255) : 255 - d;
+    const float2 *Tc = T + (size_t)c * F4W_TP + t;
     float fr = 0.0f, fi = 0.0f;
     for (int a = 0; a < F4W_R; ++a) {
         const int p = (a < 22) ? a : (a < 44 ? a - 22 : 22);
-        const float2 A = fftb_at<125, 256>(w->y, p, i), B = fftb_at<125, 256>(w->y, p, m);
+        const float2 A = w->y[(size_t)p * F4W_M + (size_t)c * 256 + d], B = w->y[(size_t)p * F4W_M + (size_t)cm * 256 + dm];
         const bool second = a >= 22 && a < 44;
         const float2 Y = second ? make_float2((A.y + B.y) * 0.5f, (B.x - A.x) * 0.5f) : make_float2((A.x + B.x) * 0.5f, (A.y - B.y) * 0.5f);
-        const float2 tt = lcmul(Y, T[(size_t)a * nband + q]);
+        const float2 tt = lcmul(Y, Tc[(size_t)a * (125 * F4W_TP)]);
         fr = fr + tt.x; fi = fi + tt.y;
     }
-    w->aux[q] = make_float2(fr, fi);
+    w->aux[k - jlo] = make_float2(fr, fi);
 }
 
 struct Fst4wParams { int ina, inb, ia, ib, ndh, jlo, nnw; float df1, df2, minsync; };

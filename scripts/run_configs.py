@@ -44,6 +44,7 @@ def main():
     cap = ring_blocks * IQ_LEN
     ctx = P.Context(0)
     ctx.enable_sync(True, 1.5, 200, 200, 3000)
+    ctx.enable_long_sync(True)              # WSPR / FST4W-120 candidate search (configs[4]: "candidate-list parity vs CPU")
     chans = []
     t0 = time.time()
     gs = 0
@@ -51,6 +52,8 @@ def main():
         for _ in range(count):
             f = slot_freq(gs)
             tones = [f + 700.0 + 31.0 * (gs % 13), f + 1500.0, f + 2300.0 - 17.0 * (gs % 5)]
+            if args.config == 5:            # carriers inside the 120 s modes' search windows (1500 +- 110 Hz; 1400..1600 Hz)
+                tones = [f + 1500.0 - 80.0 + 7.0 * (gs % 23), f + 1500.0 + 30.0 + 3.0 * (gs % 19), f + 2300.0 - 17.0 * (gs % 5)]
             rx = ctx.receiver_open(FS, IQ_LEN, 0, ring_blocks=ring_blocks)
             done = 0
             while done < cap:               # fill the ring in pieces (push_synth's count is 32 bit)
@@ -95,6 +98,8 @@ def main():
     laps = (args.warmup + args.steps) * sub          # commits of `part` samples since the ring was filled
     worst, mism, cand_checked, cand_equal = 0.0, 0, 0, 0
     ft4_checked = ft4_equal = ft4_records = 0
+    e2e_checked = e2e_same_keys = 0
+    e2e_worst = 0.0
     seen = {}
     for mode, rx, ch, f, tones, seed in chans:
         if seen.get(mode, 0) >= args.verify:
@@ -121,6 +126,23 @@ def main():
                 want = O.ft4_candidates(g["i16"], 200.0, 3000.0, 1.2, 200)
             cand_checked += 1
             cand_equal += int(list(got) == list(want) and len(want) > 0)
+        if mode in ("WSPR", "FST4W-120"):                  # stage parity: the restatement on the GPU's own int16 frame
+            bits = lambda t: [np.float32(x).view(np.uint32) if isinstance(x, float) else x for x in t]
+            if mode == "WSPR":
+                got, want = ctx.fetch_wspr_candidates(ch), O.wspr_search(g["i16"])
+            else:
+                got, want = ctx.fetch_fst4w_candidates(ch), O.fst4w_candidates(g["i16"])
+            cand_checked += 1
+            cand_equal += int([bits(t) for t in got] == [bits(t) for t in want] and len(want) > 0)
+            # and end to end from IQ: the reference chain's frame through the restatement vs the product's list
+            want_ref = O.wspr_search(ref["i16"]) if mode == "WSPR" else O.fst4w_candidates(ref["i16"])
+            e2e_checked += 1
+            e2e_same_keys += int([t[0] for t in got] == [t[0] for t in want_ref])
+            for a, b in zip(got, want_ref):
+                if a[0] == b[0]:
+                    k = 3 if mode == "WSPR" else 1
+                    e2e_worst = max(e2e_worst, abs(a[k] - b[k]) / max(abs(b[k]), 1e-30))
+        if mode in ("FT8", "FT4"):
             if mode == "FT4":                              # coherent stage: refined records of every candidate
                 ref4 = O.ft4_sync_all(g["i16"], want)
                 got4 = ctx.fetch_ft4_sync(ch)
@@ -137,6 +159,7 @@ def main():
         "sync_ms_per_boundary": st["sync_ms"] / max(1, st["sync_launches"]), "sync_launches": st["sync_launches"],
         "verify": {"slots_checked": sum(seen.values()), "max_rel_err": worst, "tolerance": 1e-5, "int16_mismatches_1lsb_ties": mism,
                    "candidate_lists_checked": cand_checked, "candidate_lists_identical": cand_equal,
+                   "long_mode_e2e_lists_checked": e2e_checked, "long_mode_e2e_same_frequencies": e2e_same_keys, "long_mode_e2e_worst_rel_sync": e2e_worst,
                    "ft4_refined_lists_checked": ft4_checked, "ft4_refined_lists_identical": ft4_equal, "ft4_refined_records": ft4_records},
         "hbm_resident_gb": n_slots * cap * 8 / 1e9, "setup_s": setup_s,
     }

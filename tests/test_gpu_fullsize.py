@@ -6,7 +6,7 @@ configs[4]  128 WSPR + 128 FST4W-120 slots x 120 s (47 GB of IQ resident)
 north_star  4096 FT8 slots x 15 s resident on ONE MI355X (94 GB of IQ)
 Every slot's IQ comes from the device-side synthetic source, which is bit-identical to the oracle's generator, so a few
 slots spread over the range are re-derived on the CPU and checked in full: float audio within 1e-5 of frame peak,
-int16 equal up to +-1 LSB rounding ties, FT8/FT4 candidate lists bit-identical to the restatement run on the GPU frame.
+int16 equal up to +-1 LSB rounding ties, FT8/FT4/WSPR/FST4W candidate lists bit-identical to the restatement run on the GPU frame.
 Size-independent properties cover ALL slots: frame counts, valid-sample counts, a finite non-zero scale factor.
 """
 import numpy as np
@@ -25,7 +25,26 @@ def _freq(gs):
 
 
 def _tones(f, gs):
-    return [f + 600.0 + 37.0 * (gs % 11), f + 1500.0, f + 2450.0 - 13.0 * (gs % 7)]
+    # one carrier inside the 120 s modes' search windows (1500 +- 110 Hz, 1400..1600 Hz), two elsewhere in the passband
+    return [f + 600.0 + 37.0 * (gs % 11), f + 1500.0 - 60.0 + 9.0 * (gs % 13), f + 2450.0 - 13.0 * (gs % 7)]
+
+
+def _fetch_cands(ctx, ch, mode):
+    if mode in ("FT8", "FT4"):
+        return ctx.fetch_candidates(ch, 200)
+    return ctx.fetch_wspr_candidates(ch) if mode == "WSPR" else ctx.fetch_fst4w_candidates(ch)
+
+
+def _oracle_cands(oracle, frame, mode):
+    if mode == "FT8":
+        return oracle.ft8_sync(frame, 200, 3000, 1.5, 200)
+    if mode == "FT4":
+        return oracle.ft4_candidates(frame, 200.0, 3000.0, 1.2, 200)
+    return oracle.wspr_search(frame) if mode == "WSPR" else oracle.fst4w_candidates(frame)
+
+
+def _bits(c):
+    return tuple(np.float32(x).view(np.uint32) if isinstance(x, float) else x for x in c)
 
 
 def _run(ctx, oracle, modes, check, sync=False):
@@ -36,6 +55,7 @@ def _run(ctx, oracle, modes, check, sync=False):
     cap = n_long + 4 * BLK
     if sync:
         ctx.enable_sync(True, 1.5, 200, 200, 3000)
+        ctx.enable_long_sync(True)
     slots = []
     for gs, mode in enumerate(modes):
         f = _freq(gs)
@@ -63,7 +83,7 @@ def _run(ctx, oracle, modes, check, sync=False):
             for k in check:
                 rx, ch, mode, f, gs = slots[k]
                 if PERIOD[mode] == shortest and parts > 1:
-                    frames[(k, 0)] = (ctx.fetch_frame(ch), ctx.fetch_audio_f32(ch), ctx.fetch_candidates(ch, 200) if sync else None)
+                    frames[(k, 0)] = (ctx.fetch_frame(ch), ctx.fetch_audio_f32(ch), _fetch_cands(ctx, ch, mode) if sync else None)
     ctx.synchronize()
     st = ctx.stats()
     n_emit = sum(int(round(longest / PERIOD[m])) for m in modes)
@@ -87,7 +107,7 @@ def _run(ctx, oracle, modes, check, sync=False):
             oc.push_many(iq[rep * per_samples:(rep + 1) * per_samples])
             r = oc.boundary(100 + int((rep + 1) * PERIOD[mode]), want_f32=True)
             if rep == reps - 1:
-                got = (ctx.fetch_frame(ch), ctx.fetch_audio_f32(ch), ctx.fetch_candidates(ch, 200) if sync and mode in ("FT8", "FT4") else None)
+                got = (ctx.fetch_frame(ch), ctx.fetch_audio_f32(ch), _fetch_cands(ctx, ch, mode) if sync else None)
             elif (k, rep) in frames:
                 got = frames[(k, rep)]
             else:
@@ -97,9 +117,8 @@ def _run(ctx, oracle, modes, check, sync=False):
             worst = max(worst, assert_frames_match(a, r["f32"]))
             assert_int16_match(g["i16"], r["i16"], r["f32"] * r["factor"])
             if cands is not None:
-                ref = oracle.ft8_sync(g["i16"], 200, 3000, 1.5, 200) if mode == "FT8" else oracle.ft4_candidates(g["i16"], 200.0, 3000.0, 1.2, 200)
-                bits = lambda c: (c[0], c[1], np.float32(c[2]).view(np.uint32), np.float32(c[3]).view(np.uint32))
-                assert [bits(c) for c in cands] == [bits(c) for c in ref]
+                ref = _oracle_cands(oracle, g["i16"], mode)
+                assert [_bits(c) for c in cands] == [_bits(c) for c in ref]
     return worst
 
 
@@ -114,7 +133,7 @@ def test_config2_768_ft8_256_ft4_with_sync(ctx, oracle):
 
 def test_config4_128_wspr_128_fst4w(ctx, oracle):
     modes = ["WSPR" if s % 2 == 0 else "FST4W-120" for s in range(256)]
-    _run(ctx, oracle, modes, check=[0, 85, 170, 255])
+    _run(ctx, oracle, modes, check=[0, 85, 170, 255], sync=True)      # incl. the WSPR / FST4W-120 candidate lists
 
 
 def test_north_star_4096_ft8_slots_on_one_gpu(ctx, oracle):
