@@ -38,6 +38,7 @@ namespace cwslg {
 
 // ---------------------------------------------------------------------------------------------
 constexpr int kTile = 256;             // outputs per demod workgroup
+constexpr int kTileExact = 240;        // ... of demod_exact2_kernel (four tiles per CU; 180 000 = 750 x 240)
 constexpr int kDemodThreads = 256;
 constexpr int kFinThreads = 256;
 constexpr int kCkptStride = cwslg::kCk;   // blocks between phasor checkpoints
@@ -318,14 +319,19 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
     std::memcpy(w->h, works.data(), works.size() * sizeof(ChanWork));
     HIPCHK(c, hipMemcpyAsync(w->d, w->h, works.size() * sizeof(ChanWork), hipMemcpyHostToDevice, c->stream));
-    const int tiles_n = (int)((max_blocks + kTile - 1) / kTile);
+    const bool exact2 = c->exact && c->demod_variant != 20;
+    const int tile = exact2 ? kTileExact : kTile;
+    const int tiles_n = (int)((max_blocks + tile - 1) / tile);
     const int tiles_x = tile_major ? -tiles_n : tiles_n;        // sign selects the work-item order (demod_kernels.hpp)
     const long long total = (long long)tiles_n * (long long)works.size();
     const long long per_xcd = (total + 7) / 8;
     hipEvent_t ea, eb;
     span_begin(c, 0, &ea, &eb);
-    if (c->exact) {
+    if (c->exact && c->demod_variant == 20) {      // CWSLG_DEMOD_VARIANT=20: the round-1 exact kernel, one output per thread (same bits)
         hipLaunchKernelGGL((demod_exact_kernel<D, kTile, kDemodThreads>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
+                           c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
+    } else if (c->exact) {
+        hipLaunchKernelGGL((demod_exact2_kernel<D, kTileExact, 128>), dim3((unsigned)(per_xcd * 8)), dim3(128), 0,
                            c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
     } else if (c->demod_variant == 1 || c->demod_variant == 2) {
         // persistent variants (measured alternatives): as many workgroups as are resident at once

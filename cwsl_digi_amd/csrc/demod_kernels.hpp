@@ -936,6 +936,156 @@ __global__ __launch_bounds__(NT) void demod_exact_kernel(const ChanWork *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// demod_exact2_kernel: the same arithmetic as demod_exact_kernel, operation for operation (bit-identical frames), arranged after
+// its counters (LDS array 86 % busy, 16 waves per CU, 7.7 ms per 512 slots = 19.7 % of HBM peak):
+//   * one thread computes TWO adjacent outputs o, o + 1.  Their 32-block windows share 31 blocks, so each block's 16 mixed
+//     samples are read from LDS once and used twice (tap block n for o, n - 1 for o + 1): half the LDS reads per output;
+//   * even and odd blocks live in separate LDS arrays of pitch D + 1: lane l reads block 2 l + n, i.e. entry l + n/2 of the
+//     array of parity n & 1 -- lane stride D + 1 complex (odd): conflict-free ds_read_b64;
+//   * the 16 taps of a block are fetched by VECTOR loads from a lane-invariant address (L1 broadcast) one step ahead: they are
+//     counted in vmcnt, so waiting for them does not drain the LDS reads in flight the way scalar loads (lgkmcnt) did in the
+//     round-1 attempt at this layout.
+// Tile = 240 outputs on 128 threads: 39.2 KB of LDS, so FOUR tiles = 8 waves fit a CU -- two waves per SIMD, which the VALU needs
+// to issue every 2 cycles (a lone wave issues every 4); with 256-output tiles (41.7 KB, 3 per CU) this kernel ran no faster than
+// the one-output form.
+// The un-fused order needs 150 VALU lane-operations per input sample against demod_kernel's 44, so its ceiling is ~40 % of the
+// HBM roofline at full VALU rate; this is the mode whose int16 frames -- and therefore candidate lists -- equal the reference
+// chain's bit for bit (tests/test_gpu_exact.py, tests/test_gpu_e2e_candidates.py).
+template <int D, int T, int NT>
+__global__ __launch_bounds__(NT, 4) void demod_exact2_kernel(const ChanWork *__restrict__ works,
+                                                              const float *__restrict__ taps,
+                                                              int tiles_x, int n_ch)
+{
+    using Geo = DemodGeom<D, T>;
+    constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
+    constexpr int NBH = (Geo::NBLK + 1) / 2 + 1;          // blocks per parity array (+1 slack)
+    constexpr int BP = D + 1;                             // block pitch in complex
+    static_assert(2 * NT >= T && T % 4 == 0 && D % 4 == 0, "two outputs per thread");
+    __shared__ float2 s_t[2][NBH * BP];
+    __shared__ float2 s_phase[Geo::NBLK + 4];             // the pipeline reads (never uses) two blocks past the tile
+
+    const int total = (tiles_x < 0 ? -tiles_x : tiles_x) * n_ch;
+    const int per_xcd = (total + 7) >> 3;
+    const int wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (wid >= min(((int)(blockIdx.x & 7) + 1) * per_xcd, total)) return;
+    const int tid = threadIdx.x;
+    TileCtx<D, T> cur;
+    int ich, itile;
+    item_to_ch_tile(wid, tiles_x, n_ch, ich, itile);
+    decode_item<D, T>(works + ich, itile, cur);
+    if (cur.n_out == 0) return;
+    v4f xs[NIT];
+    float2 ck;
+    v4f tn;
+    issue_tile_loads<D, T, NT>(cur, tid, xs, ck, tn);
+    // taps through the vector path: an address the compiler cannot prove uniform (it is: every lane adds 0)
+    int lane_zero = 0;
+    asm volatile("" : "+v"(lane_zero));
+    const CWSLG_GLOBAL v4f *tapv = as_global(reinterpret_cast<const v4f *>(taps)) + lane_zero;
+    v4f hnext[D / 4];
+#pragma unroll
+    for (int q = 0; q < D / 4; ++q) hnext[q] = tapv[q];   // tap block 0
+    {
+        for (int lt = tid; lt < Geo::NCK; lt += NT) {
+            const int cidx = cur.ck_first + lt;
+            if (cidx >= 0) {
+                const v2f t = as_global(reinterpret_cast<const v2f *>(cur.ckpt))[cidx];
+                float2 p = make_float2(t.x, t.y);
+                const int pbase = cur.pb0 + kCk * lt;
+#pragma unroll
+                for (int s = 0; s < kCk; ++s) {
+                    const int pb = pbase + s;
+                    if (pb >= 0 && pb < Geo::NBLK) s_phase[pb] = p;
+                    p = cmul_exact(p, cur.inc);
+                }
+            }
+        }
+    }
+    // t = in[m] * tone[m]  (SSBD.hpp:167), un-fused, into the parity arrays
+    {
+        const float2 tn0 = make_float2(tn.x, tn.y), tn1 = make_float2(tn.z, tn.w);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = 2 * tid + it * 2 * NT;
+            if (r < Geo::NSAMP) {
+                const v4f x = xs[it];
+                const float2 a = cmul_exact(make_float2(x.x, x.y), tn0);
+                const float2 b = cmul_exact(make_float2(x.z, x.w), tn1);
+                const int blk = r / D, m = r % D;
+                float2 *dst = &s_t[blk & 1][(blk >> 1) * BP + m];
+                dst[0] = a;
+                dst[1] = b;
+            }
+        }
+    }
+    __syncthreads();
+    const int o0 = 2 * tid;
+    if (o0 < T && o0 < cur.n_out) {
+        const int first_blk = cur.first_valid / D;           // tile blocks before this precede the demodulator's origin
+        float wr0 = 0.0f, wi0 = 0.0f, wr1 = 0.0f, wi1 = 0.0f; // the two workspace slots, zero after their last read-out (:178)
+        // Software pipeline, unrolled by six (two sample buffers x three tap buffers rotate by renaming): while step n is computed,
+        // the LDS reads of block n + 1 and the tap loads of block n + 1 are in flight.  (Occupancy is LDS-bound -- three tiles, six
+        // waves per CU -- so registers are plentiful and latency has to be hidden inside the wave.)
+        auto load_block = [&](int n, float2 (&t)[D], float2 &ph) {
+            const float2 *tp = &s_t[n & 1][(tid + (n >> 1)) * BP];
+#pragma unroll
+            for (int m = 0; m < D; ++m) t[m] = tp[m];
+            ph = s_phase[o0 + n];
+        };
+        auto load_taps = [&](int n, v4f (&h)[D / 4]) {
+#pragma unroll
+            for (int q = 0; q < D / 4; ++q) h[q] = tapv[(D / 4) * (n < 32 ? n : 31) + q];
+        };
+        auto accumulate = [&](const float2 (&t)[D], const v4f (&h)[D / 4], float2 ph, float &wr, float &wi) {
+            float sr = 0.0f, si = 0.0f;
+#pragma unroll
+            for (int m = 0; m < D; ++m) {
+                const float hm = h[m >> 2][m & 3];
+                sr = sr + t[m].x * hm;
+                si = si + t[m].y * hm;
+            }
+            const float2 pr = cmul_exact(make_float2(sr, si), ph);   // sum * phase (:170)
+            wr = wr + pr.x;
+            wi = wi + pr.y;
+        };
+        // step n: block o0 + n feeds output o0 with tap block n (n <= 31) and output o0 + 1 with tap block n - 1 (n >= 1)
+        auto step = [&](int n, const float2 (&t)[D], float2 ph, const v4f (&hn)[D / 4], const v4f (&hnm1)[D / 4]) {
+            if (o0 + n >= first_blk) {
+                if (n <= 31) accumulate(t, hn, ph, wr0, wi0);
+                if (n >= 1) accumulate(t, hnm1, ph, wr1, wi1);
+            }
+        };
+        // taps[n] lives in buffer n mod 3: at step n the current block is buffer n mod 3, the previous one (n - 1) mod 3, and the
+        // third is free for the prefetch of taps[n + 1]; the mixed samples ping-pong between tA and tB.
+        float2 tA[D], tB[D], phA, phB;
+        v4f h0[D / 4], h1[D / 4], h2[D / 4];
+#pragma unroll
+        for (int q = 0; q < D / 4; ++q) { h0[q] = hnext[q]; h2[q] = hnext[q]; }   // tap block 0 (fetched at the top); h2 is a placeholder for "block -1"
+        load_block(0, tA, phA);
+#pragma unroll 1
+        for (int n = 0; n < 33; n += 6) {                      // 33 steps = 5 x 6 + 3
+            load_taps(n + 1, h1); load_block(n + 1, tB, phB); step(n, tA, phA, h0, h2);
+            load_taps(n + 2, h2); load_block(n + 2, tA, phA); step(n + 1, tB, phB, h1, h0);
+            load_taps(n + 3, h0); load_block(n + 3, tB, phB); step(n + 2, tA, phA, h2, h1);
+            if (n + 3 > 32) break;
+            load_taps(n + 4, h1); load_block(n + 4, tA, phA); step(n + 3, tB, phB, h0, h2);
+            load_taps(n + 5, h2); load_block(n + 5, tB, phB); step(n + 4, tA, phA, h1, h0);
+            load_taps(n + 6, h0); load_block(n + 6, tA, phA); step(n + 5, tB, phB, h2, h1);
+        }
+        // Iterate(): out[k] for block index mod 4 (qs and T are multiples of 4; o0 is even)
+        const float v0 = (o0 & 2) ? -wr0 : wr0;
+        const float v1 = (o0 & 2) ? wi1 * cur.sign : -wi1 * cur.sign;
+        CWSLG_GLOBAL v2f *out2 = reinterpret_cast<CWSLG_GLOBAL v2f *>(as_global_rw(cur.out) + (size_t)cur.tile * T + o0);
+        v2f ov; ov.x = v0; ov.y = v1;
+        *out2 = ov;
+        float mx = fmaxf(fabsf(v0), fabsf(v1));
+#pragma unroll
+        for (int msk = 32; msk >= 1; msk >>= 1) mx = fmaxf(mx, __shfl_xor(mx, msk, 64));
+        if ((tid & 63) == 0) publish_peak(cur.peak, mx);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Slot finalise: prepareAudio + float->int16 (Instance.cpp:294-338, 238-241), bit-exact:
 //   factor = 32767.0f / (peak + 1.0f); factor *= scale;  buf[k] *= factor;  (int16)(buf[k] + 0.5f)
 // The peak is max|audio| (max(maxVal, |minVal|) == max|x| for every frame).
