@@ -427,9 +427,15 @@ __device__ __forceinline__ float unpack_power(float2 A, float2 B, float2 wk)
     return __builtin_fmaf(xr, xr, xi * xi);
 }
 
-constexpr int SPEC_JPER = 12;           // symbol steps per workgroup (FT8: 372 = 31 x 12)
+#ifndef CWSLG_SPEC_JPER
+#define CWSLG_SPEC_JPER 12
+#endif
+#ifndef CWSLG_SPEC_WAVES
+#define CWSLG_SPEC_WAVES 4
+#endif
+constexpr int SPEC_JPER = CWSLG_SPEC_JPER;   // symbol steps per workgroup (FT8: 372 = 31 x 12); -D overrides are for A/B builds only
 template <int NA, int NIN, int STEP, bool WINDOW>
-__global__ __launch_bounds__(256, 4) void symbol_spectra_v2_kernel(const SyncWork *__restrict__ works, SyncTables tb, int nbins, int nsteps)
+__global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kernel(const SyncWork *__restrict__ works, SyncTables tb, int nbins, int nsteps)
 {
     constexpr int NZ = NA * 128;
     constexpr int NPACK = NIN / 2;
@@ -857,23 +863,30 @@ __global__ __launch_bounds__(SYNC2D_NT, 4) void ft8_sync2d_v2_kernel(const SyncW
     const bool ok0 = j <= FT8_JZ, ok1 = j + 1 <= FT8_JZ;
     const bool near0 = j >= -10 && j <= 10, near1 = j + 1 >= -10 && j + 1 <= 10;
     const float ninf = -__builtin_huge_valf();
-    // column offsets of the three Costas blocks for n = 0: m = j + 12 (+144, +288); later n add 4
-    const int ca0 = j + 12 + S2_COL0, cb0 = ca0 + 144, cc0 = ca0 + 288;
+    // Column PAIRS: lag pair (j, j + 1) reads the columns (m + 2, m + 3), m = j + 12 + 4 n (+144, +288) even, i.e. float2 number
+    // lane - 24 + 2 n (+72, +144) of the row.  The images are indexed as float2 arrays throughout: indexed as float arrays with an
+    // even offset, hipcc cannot prove the 8-byte alignment and splits every access into two ds_read_b32 (round-2 counters: 39 % of
+    // the LDS cycles were bank conflicts from exactly that).
+    const int pa0 = lane - 24, pb0 = pa0 + 72, pc0 = pa0 + 144;
+    constexpr int PP = S2_PITCH / 2;                       // float2 per row
+    // (v2f is the built-in vector type: one <2 x float> load = one ds_read_b64; HIP's float2 is a struct whose copy hipcc scalarises)
+    const v2f *s_s2 = reinterpret_cast<const v2f *>(&s_s[0][0]);
+    v2f *c02 = reinterpret_cast<v2f *>(c0);
     {
         // one wave per bin from here on, each wave owns s_c0[wv]
         for (int rr = wv; rr < SYNC_BAND; rr += NW) {
             const int bin = i0 + rr;
             if (bin > ib) break;                            // wave-uniform
             // 7-tone sums of this bin for every symbol step (sequential k, as the restatement), two steps per lane and read
-            for (int mp = lane; mp < S2_PITCH / 2; mp += 64) {
-                float2 acc = make_float2(0.0f, 0.0f);
+            for (int mp = lane; mp < PP; mp += 64) {
+                v2f acc = {0.0f, 0.0f};
 #pragma unroll
                 for (int k = 0; k < 7; ++k) {
-                    const float2 x = *reinterpret_cast<const float2 *>(&s_s[rr + 2 * k][2 * mp]);
+                    const v2f x = s_s2[(rr + 2 * k) * PP + mp];
                     acc.x = acc.x + x.x;
                     acc.y = acc.y + x.y;
                 }
-                *reinterpret_cast<float2 *>(c0 + 2 * mp) = acc;
+                c02[mp] = acc;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -882,13 +895,13 @@ __global__ __launch_bounds__(SYNC2D_NT, 4) void ft8_sync2d_v2_kernel(const SyncW
             float ta1 = 0, tb1 = 0, tc1 = 0, ua1 = 0, ub1 = 0, uc1 = 0;      // lag j + 1
 #pragma unroll
             for (int n = 0; n < 7; ++n) {
-                const float *row = s_s[rr + 2 * icos[n]];
-                int ca = ca0 + 4 * n; ca = ca < 0 ? 0 : ca;                   // m < -2  -> the zero pair (m = -2, -1)
-                int cc = cc0 + 4 * n; cc = cc > S2_PITCH - 2 ? S2_PITCH - 2 : cc;      // m > 374 -> the zero pair (m = 374, 375)
-                const int cb = cb0 + 4 * n;
-                const float2 va = *reinterpret_cast<const float2 *>(row + ca), wa = *reinterpret_cast<const float2 *>(c0 + ca);
-                const float2 vb = *reinterpret_cast<const float2 *>(row + cb), wb = *reinterpret_cast<const float2 *>(c0 + cb);
-                const float2 vc = *reinterpret_cast<const float2 *>(row + cc), wc = *reinterpret_cast<const float2 *>(c0 + cc);
+                const v2f *row = s_s2 + (rr + 2 * icos[n]) * PP;
+                int pa = pa0 + 2 * n; pa = pa < 0 ? 0 : pa;                   // m < -2  -> the zero pair (m = -2, -1)
+                int pc = pc0 + 2 * n; pc = pc > PP - 1 ? PP - 1 : pc;         // m > 374 -> the zero pair (m = 374, 375)
+                const int pb = pb0 + 2 * n;
+                const v2f va = row[pa], wa = c02[pa];
+                const v2f vb = row[pb], wb = c02[pb];
+                const v2f vc = row[pc], wc = c02[pc];
                 ta0 = ta0 + va.x; ua0 = ua0 + wa.x; ta1 = ta1 + va.y; ua1 = ua1 + wa.y;
                 tb0 = tb0 + vb.x; ub0 = ub0 + wb.x; tb1 = tb1 + vb.y; ub1 = ub1 + wb.y;
                 tc0 = tc0 + vc.x; uc0 = uc0 + wc.x; tc1 = tc1 + vc.y; uc1 = uc1 + wc.y;
