@@ -42,11 +42,28 @@ constexpr int kTileExact = 240;        // ... of demod_exact2_kernel (four tiles
 constexpr int kDemodThreads = 256;
 constexpr int kFinThreads = 256;
 constexpr int kCkptStride = cwslg::kCk;   // blocks between phasor checkpoints
-constexpr size_t kStageHalf = 16u << 20;   // pinned staging: two halves of 16 MiB
+constexpr size_t kStageHalf = 4u << 20;    // pinned staging PER RECEIVER: two halves of 4 MiB, allocated at the receiver's first host push
 constexpr int kWorkBufs = 8;
+constexpr int kCopyStreams = 4;
+
+// Host-push staging of one receiver.  The reference has one thread per Receiver (Receiver.hpp:167); each of them gets its own
+// pinned double buffer here, filled OUTSIDE the context mutex, so that pushes of different receivers copy in parallel.
+struct RxStage {
+    std::mutex mu;                     // one push at a time per receiver
+    char *h = nullptr;                 // 2 * kStageHalf, pinned
+    size_t pos = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    ~RxStage()
+    {
+        if (h) (void)hipHostFree(h);
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    }
+};
 
 struct Receiver {
     bool open = false;
+    std::shared_ptr<RxStage> stage;
     uint32_t fs = 0, iq_len = 0, D = 0;
     int32_t lo_hz = 0;
     float2 *d_ring = nullptr;
@@ -158,11 +175,13 @@ struct cwslg_ctx {
     std::map<std::tuple<uint32_t, int32_t, int, size_t>, PhasorTable> phasors;
     std::vector<decltype(phasors)::key_type> phasor_todo;
     float2 *d_sincos = nullptr;
-    // staging for host pushes
-    char *h_stage = nullptr;
-    size_t stage_pos = 0;
-    hipEvent_t stage_ev[2] = {nullptr, nullptr};
-    bool stage_busy[2] = {false, false};
+    // host pushes: H2D copies run on their own stream, ordered against the demod kernels by two events
+    hipStream_t copy_stream[kCopyStreams] = {};    // receiver r copies on stream r mod kCopyStreams (several DMA engines side by side)
+    hipEvent_t copy_done[kCopyStreams] = {};       // recorded in process_locked: the demod launch waits for every copy enqueued so far
+    hipEvent_t demod_done = nullptr;   // recorded on stream after every demod launch: a later copy may overwrite ring history only after it
+    bool copies_pending[kCopyStreams] = {};
+    bool copy_on_main = true;          // H2D copies on the compute stream: measured 30 GB/s from one pusher thread against 21-28 GB/s on
+                                       // the dedicated copy streams (CWSLG_COPY_ON_MAIN=0 selects those: copies then overlap the kernels)
     // launch descriptors
     WorkBuf wb[kWorkBufs];
     int wb_next = 0;
@@ -447,6 +466,12 @@ int process_locked(cwslg_ctx *c)
     }
     rc = build_pending_phasors(c);
     if (rc) return rc;
+    for (int k = 0; k < kCopyStreams; ++k)
+        if (c->copies_pending[k]) {      // every host push enqueued so far lands before the kernels below read the rings
+            HIPCHK(c, hipEventRecord(c->copy_done[k], c->copy_stream[k]));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->copy_done[k], 0));
+            c->copies_pending[k] = false;
+        }
     // one launch per distinct sample rate; channels grouped by receiver so that a receiver's channels are neighbours
     std::map<uint32_t, std::vector<ChanWork>> by_fs;
     std::map<uint32_t, unsigned> max_blocks;
@@ -491,6 +516,7 @@ int process_locked(cwslg_ctx *c)
         else rc = fail(c, CWSLG_ERR_UNSUPPORTED, "sample rate %u unsupported", fs);
         if (rc) return rc;
     }
+    if (!by_fs.empty()) HIPCHK(c, hipEventRecord(c->demod_done, c->stream));
     return CWSLG_OK;
 }
 
@@ -689,10 +715,13 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
     if (const char *v = std::getenv("CWSLG_FT4_DFT")) c->ft4_dft_valu = std::strcmp(v, "valu") == 0;
     if (const char *v = std::getenv("CWSLG_ITEM_ORDER")) c->order_override = std::atoi(v);
     if (const char *v = std::getenv("CWSLG_SYNC_VARIANT")) c->sync_variant = std::atoi(v);
+    if (const char *v = std::getenv("CWSLG_COPY_ON_MAIN")) c->copy_on_main = std::atoi(v) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
-    if (hipHostMalloc((void **)&c->h_stage, 2 * kStageHalf, hipHostMallocDefault) != hipSuccess) return CWSLG_ERR_NOMEM;
-    hipEventCreateWithFlags(&c->stage_ev[0], hipEventDisableTiming);
-    hipEventCreateWithFlags(&c->stage_ev[1], hipEventDisableTiming);
+    for (int k = 0; k < kCopyStreams; ++k) {
+        if (hipStreamCreateWithFlags(&c->copy_stream[k], hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
+        hipEventCreateWithFlags(&c->copy_done[k], hipEventDisableTiming);
+    }
+    hipEventCreateWithFlags(&c->demod_done, hipEventDisableTiming);
     // tone table of the synthetic source (same construction as the oracle's)
     {
         std::vector<float2> tab(4096);
@@ -710,6 +739,7 @@ void cwslg_destroy(cwslg_ctx *c)
 {
     if (!c) return;
     hipSetDevice(c->device);
+    for (hipStream_t cs : c->copy_stream) if (cs) hipStreamSynchronize(cs);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (Channel &ch : c->chans) {
         if (ch.d_block) hipFree(ch.d_block);
@@ -730,9 +760,11 @@ void cwslg_destroy(cwslg_ctx *c)
     sync_free_shared(c->sync_shared);
     long_free_shared(c->long_shared);
     if (c->d_sincos) hipFree(c->d_sincos);
-    if (c->h_stage) hipHostFree(c->h_stage);
-    if (c->stage_ev[0]) hipEventDestroy(c->stage_ev[0]);
-    if (c->stage_ev[1]) hipEventDestroy(c->stage_ev[1]);
+    for (int k = 0; k < kCopyStreams; ++k) {
+        if (c->copy_stream[k]) { hipStreamSynchronize(c->copy_stream[k]); hipStreamDestroy(c->copy_stream[k]); }
+        if (c->copy_done[k]) hipEventDestroy(c->copy_done[k]);
+    }
+    if (c->demod_done) hipEventDestroy(c->demod_done);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -792,6 +824,7 @@ int cwslg_receiver_close(cwslg_ctx *c, int rx_id)
     std::lock_guard<std::mutex> g(c->mu);
     if (rx_id < 0 || rx_id >= (int)c->rxs.size() || !c->rxs[rx_id].open) return fail(c, CWSLG_ERR_ARG, "bad receiver id");
     hipSetDevice(c->device);
+    for (hipStream_t cs : c->copy_stream) HIPCHK(c, hipStreamSynchronize(cs));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     Receiver &rx = c->rxs[rx_id];
     for (int id : rx.channels) {        // Receiver::finish terminates its instances (Receiver.hpp:194-199)
@@ -821,58 +854,105 @@ static int push_prologue(cwslg_ctx *c, int rx_id, uint32_t n, Receiver **out)
     return CWSLG_OK;
 }
 
-static int push_iq_locked(cwslg_ctx *c, int rx_id, const float *iq, uint32_t n);
+static int push_iq_piece(cwslg_ctx *c, int rx_id, const float *iq, uint32_t n);
 
 int cwslg_push_iq(cwslg_ctx *c, int rx_id, const float *iq, uint32_t n)
 {
     if (!c || !iq) return CWSLG_ERR_ARG;
-    std::lock_guard<std::mutex> g(c->mu);
-    if (rx_id < 0 || rx_id >= (int)c->rxs.size() || !c->rxs[rx_id].open) return fail(c, CWSLG_ERR_ARG, "bad receiver id");
-    // a push larger than the ring is fed through it in ring-sized pieces (whole Receiver blocks)
-    const Receiver &r = c->rxs[rx_id];
-    const uint32_t piece = std::max<uint32_t>(r.iq_len, (r.cap / 2) / r.iq_len * r.iq_len);
+    uint32_t piece = 0;
+    std::shared_ptr<RxStage> stage;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        if (rx_id < 0 || rx_id >= (int)c->rxs.size() || !c->rxs[rx_id].open) return fail(c, CWSLG_ERR_ARG, "bad receiver id");
+        Receiver &r = c->rxs[rx_id];
+        // a push larger than the ring is fed through it in ring-sized pieces (whole Receiver blocks)
+        piece = std::max<uint32_t>(r.iq_len, (r.cap / 2) / r.iq_len * r.iq_len);
+        if (!r.stage) r.stage = std::make_shared<RxStage>();
+        stage = r.stage;
+    }
+    std::lock_guard<std::mutex> gp(stage->mu);            // the reference has ONE thread per Receiver; a second pusher waits here
     uint32_t done = 0;
     while (done < n) {
         const uint32_t m = std::min(piece, n - done);
-        int rc = push_iq_locked(c, rx_id, iq + 2 * (size_t)done, m);
+        int rc = push_iq_piece(c, rx_id, iq + 2 * (size_t)done, m);
         if (rc) return rc;
         done += m;
     }
     return CWSLG_OK;
 }
 
-static int push_iq_locked(cwslg_ctx *c, int rx_id, const float *iq, uint32_t n)
+// One piece (<= half the ring).  Three steps: (1) under the context mutex, make room in the ring and read the write position;
+// (2) with NO context lock, copy the caller's block (valid only during this call, like a ring slot of the reference) into this
+// receiver's pinned staging; (3) under the mutex again, enqueue the H2D copies on the copy stream and account the samples to the
+// receiver's channels.  Step 2 is the expensive one (a host memcpy at ~10 GB/s per thread) and runs in parallel across receivers.
+static int push_iq_piece(cwslg_ctx *c, int rx_id, const float *iq, uint32_t n)
 {
-    Receiver *rx = nullptr;
-    int rc = push_prologue(c, rx_id, n, &rx);
-    if (rc) return rc;
-    // host block -> pinned staging -> ring (the caller's block is only valid during this call)
+    std::shared_ptr<RxStage> stage;
+    uint64_t total0 = 0;
+    uint32_t cap = 0;
+    float2 *d_ring = nullptr;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        Receiver *rx = nullptr;
+        int rc = push_prologue(c, rx_id, n, &rx);
+        if (rc) return rc;
+        stage = rx->stage;
+        total0 = rx->total; cap = rx->cap; d_ring = rx->d_ring;
+    }
+    RxStage &st = *stage;
+    hipSetDevice(c->device);
+    if (!st.h) {
+        if (hipHostMalloc((void **)&st.h, 2 * kStageHalf, hipHostMallocDefault) != hipSuccess) return fail(c, CWSLG_ERR_NOMEM, "staging allocation failed");
+        hipEventCreateWithFlags(&st.ev[0], hipEventDisableTiming);
+        hipEventCreateWithFlags(&st.ev[1], hipEventDisableTiming);
+    }
+    struct Seg { size_t stage_off; uint32_t ring_pos, count; int leaves_half; };
+    std::vector<Seg> segs;
     uint32_t done = 0;
     while (done < n) {
         const size_t half_samples = kStageHalf / sizeof(float2);
-        const int half = (int)(c->stage_pos / kStageHalf);
-        const size_t off_in_half = c->stage_pos % kStageHalf;
-        size_t room = (kStageHalf - off_in_half) / sizeof(float2);
-        if (off_in_half == 0 && c->stage_busy[half]) {
-            HIPCHK(c, hipEventSynchronize(c->stage_ev[half]));
-            c->stage_busy[half] = false;
+        const int half = (int)(st.pos / kStageHalf);
+        const size_t off_in_half = st.pos % kStageHalf;
+        const size_t room = (kStageHalf - off_in_half) / sizeof(float2);
+        if (off_in_half == 0 && st.busy[half]) {
+            if (!segs.empty()) break;                       // flush what is staged before waiting for this half to drain
+            HIPCHK(c, hipEventSynchronize(st.ev[half]));
+            st.busy[half] = false;
         }
         uint32_t m = (uint32_t)std::min<size_t>({(size_t)(n - done), room, half_samples});
-        const uint32_t ring_pos = (uint32_t)((rx->total + done) % rx->cap);
-        m = std::min(m, rx->cap - ring_pos);           // split at the ring wrap
-        char *stg = c->h_stage + c->stage_pos;
-        std::memcpy(stg, iq + 2 * (size_t)done, (size_t)m * sizeof(float2));
-        HIPCHK(c, hipMemcpyAsync(rx->d_ring + ring_pos, stg, (size_t)m * sizeof(float2), hipMemcpyHostToDevice, c->stream));
-        c->stage_pos += (size_t)m * sizeof(float2);
-        if (c->stage_pos % kStageHalf == 0) {           // leaving a half: fence it
-            HIPCHK(c, hipEventRecord(c->stage_ev[half], c->stream));
-            c->stage_busy[half] = true;
-            if (c->stage_pos == 2 * kStageHalf) c->stage_pos = 0;
+        const uint32_t ring_pos = (uint32_t)((total0 + done) % cap);
+        m = std::min(m, cap - ring_pos);                    // split at the ring wrap
+        std::memcpy(st.h + st.pos, iq + 2 * (size_t)done, (size_t)m * sizeof(float2));
+        Seg sg{st.pos, ring_pos, m, -1};
+        st.pos += (size_t)m * sizeof(float2);
+        if (st.pos % kStageHalf == 0) {                     // leaving a half: fence it once its copy is enqueued
+            sg.leaves_half = half;
+            if (st.pos == 2 * kStageHalf) st.pos = 0;
         }
+        segs.push_back(sg);
         done += m;
     }
-    c->stats.h2d_bytes += (uint64_t)n * sizeof(float2);
-    account_push(c, *rx, n, rx->iq_len);
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        if (rx_id >= (int)c->rxs.size() || !c->rxs[rx_id].open || c->rxs[rx_id].d_ring != d_ring)
+            return fail(c, CWSLG_ERR_ARG, "receiver closed during a push");
+        Receiver &rx = c->rxs[rx_id];
+        // ring history that a queued demod launch still reads must not be overwritten under it
+        const int cs = rx_id % kCopyStreams;
+        hipStream_t cstr = c->copy_on_main ? c->stream : c->copy_stream[cs];
+        if (!c->copy_on_main) HIPCHK(c, hipStreamWaitEvent(cstr, c->demod_done, 0));
+        for (const Seg &sg : segs) {
+            HIPCHK(c, hipMemcpyAsync(d_ring + sg.ring_pos, st.h + sg.stage_off, (size_t)sg.count * sizeof(float2), hipMemcpyHostToDevice, cstr));
+            if (sg.leaves_half >= 0) {
+                HIPCHK(c, hipEventRecord(st.ev[sg.leaves_half], cstr));
+                st.busy[sg.leaves_half] = true;
+            }
+        }
+        if (!c->copy_on_main) c->copies_pending[cs] = true;
+        c->stats.h2d_bytes += (uint64_t)done * sizeof(float2);
+        account_push(c, rx, done, rx.iq_len);
+    }
+    if (done < n) return push_iq_piece(c, rx_id, iq + 2 * (size_t)done, n - done);      // the rest, after the busy half has drained
     return CWSLG_OK;
 }
 
@@ -1240,6 +1320,7 @@ int cwslg_synchronize(cwslg_ctx *c)
     if (!c) return CWSLG_ERR_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     hipSetDevice(c->device);
+    for (hipStream_t cs : c->copy_stream) HIPCHK(c, hipStreamSynchronize(cs));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     drain_spans(c);
     return CWSLG_OK;

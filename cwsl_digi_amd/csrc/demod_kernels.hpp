@@ -19,7 +19,7 @@
 //
 // Kernel layout (one workgroup = one tile of T outputs of one channel):
 //   phase 0  threads 0..NCK-1 rebuild the bit-exact float32 phasor for the tile's T+31 blocks from
-//            per-channel checkpoints (every 16 blocks) into LDS -- <=16 serial UNfused complex
+//            per-channel checkpoints (every kCk = 4 blocks) into LDS -- <=4 serial UNfused complex
 //            multiplies each, the same rounding sequence as SSBD.hpp:174.
 //   phase 1  coalesced 16-B loads of the IQ ring (HBM), complex mix, scatter of Re/Im into the two
 //            branch-major LDS planes P_0/P_1.
@@ -66,7 +66,7 @@ struct alignas(16) ChanWork {
     const float2 *ring;       // receiver IQ ring in HBM (interleaved re,im)
     float        *out;        // &frame[fill] : where the first pending output goes
     unsigned     *peak;       // max|audio| of the frame, as float bits (atomicMax)
-    const float2 *ckpt;       // phasor checkpoints: ckpt[c] = phase_{16c}
+    const float2 *ckpt;       // phasor checkpoints: ckpt[c] = phase_{kCk c}
     const float2 *tone;       // tone[D]
     unsigned      ring_cap;   // ring capacity in complex samples
     unsigned      n_blocks;   // pending outputs (= pending samples / D)
@@ -238,12 +238,12 @@ struct DemodGeom {
 //   MODE 2           persistent workgroups walking a run of work items like MODE 1 but WITHOUT the prefetch (loads issued
 //                    at the top of each item): saves the per-workgroup launch, descriptor and tap loads.
 //   MODE 0 (PERSIST = false)  one workgroup per (channel, tile) work item; 4 workgroups per CU hide each other's HBM latency.
-//                    This is the default: measured 3.05 ms per 512-slot launch.
+//                    This is the default: 2.53-2.60 ms per 512-slot launch (85 VGPRs, 40.3 KB of LDS).
 //   PERSIST = true   a persistent workgroup walks a run of work items and keeps the NEXT item's HBM loads in
-//                    flight (registers) while it computes the current one.  Kept as a measured alternative
-//                    (3.31 ms): the PMC profile shows the kernel is bounded by VALU issue (~58 %), LDS (~45 %)
-//                    and HBM (~67 % of the achievable rate) together rather than by exposed latency, and the
-//                    prefetch registers cost a workgroup of occupancy (163 VGPRs -> 3 per CU).
+//                    flight (in place: each load register is refilled right after phase 1 has consumed it, 128 VGPRs,
+//                    still 4 workgroups per CU) while it computes the current one.  Kept as a measured alternative
+//                    (2.89 against 2.75 ms on the same box): the kernel is bounded by VALU issue, LDS
+//                    and HBM together at a power-limited clock, not by exposed latency.
 // Barriers are raw `s_barrier` behind an `s_waitcnt lgkmcnt(0)`: __syncthreads() would also drain vmcnt, i.e.
 // wait for the prefetch.
 // Diagnostic build only (-DCWSLG_STAMP, scripts/gpu_stamps.py): per-workgroup s_memtime stamps at the phase seams,
