@@ -27,14 +27,27 @@ def sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
 
 
-def _stale():
-    if not os.path.isfile(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if os.path.isfile(os.path.join(CSRC, f))]
-    deps += [os.path.join(CSRC, "host", f) for f in os.listdir(os.path.join(CSRC, "host"))]
+HASHFILE = LIB + ".srchash"
+
+
+def _source_hash():
+    """sha256 over the contents of everything the library is built from (file mtimes do not survive a copy of the tree)."""
+    import hashlib
+    h = hashlib.sha256()
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if os.path.isfile(os.path.join(CSRC, f))]
+    deps += [os.path.join(CSRC, "host", f) for f in sorted(os.listdir(os.path.join(CSRC, "host")))]
     deps.append(os.path.join(HERE, "..", "include", "cwsl_gpu.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        h.update(open(d, "rb").read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()
+
+
+def _stale():
+    if not os.path.isfile(LIB) or not os.path.isfile(SKIMMER) or not os.path.isfile(HASHFILE):
+        return True
+    return open(HASHFILE).read().strip() != _source_hash()
 
 
 def build(force=False, verbose=False):
@@ -58,6 +71,8 @@ def build(force=False, verbose=False):
         try:
             subprocess.check_call(cmd)
             os.replace(tmp, LIB)
+            with open(HASHFILE, "w") as fh:
+                fh.write(_source_hash() + "\n")
         finally:
             if os.path.exists(tmp):
                 os.remove(tmp)

@@ -952,7 +952,7 @@ __global__ __launch_bounds__(NT) void demod_exact_kernel(const ChanWork *__restr
 // HBM roofline at full VALU rate; this is the mode whose int16 frames -- and therefore candidate lists -- equal the reference
 // chain's bit for bit (tests/test_gpu_exact.py, tests/test_gpu_e2e_candidates.py).
 template <int D, int T, int NT>
-__global__ __launch_bounds__(NT, 4) void demod_exact2_kernel(const ChanWork *__restrict__ works,
+__global__ __launch_bounds__(NT, 2) void demod_exact2_kernel(const ChanWork *__restrict__ works,
                                                               const float *__restrict__ taps,
                                                               int tiles_x, int n_ch)
 {
