@@ -133,3 +133,29 @@ def test_late_first_boundary_saturates_then_recovers(ctx, oracle):
     assert nv == 600 * BLK // 16 and np.isfinite(a).all()
     spec = np.abs(np.fft.rfft(a[2000:2000 + 48000].astype(np.float64)))
     assert abs(int(np.argmax(spec)) * 12000.0 / 48000 - 1000.0) < 1.0      # the 1 kHz tone, at the right audio pitch
+
+
+@pytest.mark.parametrize("mode", ["FST4W-1800", "FST4-900"])
+def test_longest_modes_allocate_and_frame(ctx, oracle, mode):
+    """The 900 s / 1800 s modes: frames of 12000*(period+5) samples (1800 s: 21.66 M int16 = 43 MB, two float frames of 87 MB and
+    87 MB of phasor checkpoints per channel).  A short slot is enough to exercise the allocation, the framing and the zero tail."""
+    import cwsl_digi_amd as P
+    n = 96 * BLK                                   # 1 s of IQ
+    f = 1500
+    iq = oracle.synth_iq(9, 2 * n, FS, tones_hz=[f + 1500.0], amp=1e4)
+    rx = ctx.receiver_open(FS, BLK, 0)
+    ch = ctx.channel_open(rx, f, mode)
+    oc = oracle.Channel(mode, FS, BLK, f)
+    g = P.group_of(mode)
+    ctx.push_iq(rx, iq[:n]); oc.push_many(iq[:n])
+    ctx.slot_boundary(g, 1800); assert oc.boundary(1800) is None and ctx.fetch_frame(ch) is None
+    ctx.push_iq(rx, iq[n:]); oc.push_many(iq[n:])
+    ctx.slot_boundary(g, 3600)
+    r = oc.boundary(3600, want_f32=True)
+    fr = ctx.fetch_frame(ch)
+    a, nv = ctx.fetch_audio_f32(ch)
+    assert len(fr["i16"]) == P.frame_len(mode) == 12000 * (int(mode.split("-")[1]) + 5) and nv == n // 16 and fr["t_start"] == 1800
+    assert_frames_match(a[:nv + 64], r["f32"][:nv + 64])
+    assert not fr["i16"][nv:].any()                # the reference's zero tail
+    d = np.abs(fr["i16"][:nv].astype(np.int32) - r["i16"][:nv].astype(np.int32))
+    assert d.max() <= 1
