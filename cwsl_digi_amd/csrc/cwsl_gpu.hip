@@ -197,6 +197,7 @@ struct cwslg_ctx {
     bool ft4_dft_valu = false;         // CWSLG_FT4_DFT=valu
     LongConfig long_cfg;
     LongShared long_shared;
+    int long_variant = 0;              // CWSLG_LONG_VARIANT: bit 0 = FST4W's 125 x 256 stage 1 on the VALU, bit 1 = WSPR's 45 x 1024 stage 1 on the matrix cores
     int sync_variant = 0;              // CWSLG_SYNC_VARIANT: bit mask of measured alternatives in the sync stage (0 = defaults)
     // multi-GPU slot-boundary rendezvous (multi_gpu.inc)
     cwslg_rendezvous_fn rdv_fn = nullptr;
@@ -715,6 +716,7 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
     if (const char *v = std::getenv("CWSLG_FT4_DFT")) c->ft4_dft_valu = std::strcmp(v, "valu") == 0;
     if (const char *v = std::getenv("CWSLG_ITEM_ORDER")) c->order_override = std::atoi(v);
     if (const char *v = std::getenv("CWSLG_SYNC_VARIANT")) c->sync_variant = std::atoi(v);
+    if (const char *v = std::getenv("CWSLG_LONG_VARIANT")) c->long_variant = std::atoi(v);
     if (const char *v = std::getenv("CWSLG_COPY_ON_MAIN")) c->copy_on_main = std::atoi(v) != 0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
     for (int k = 0; k < kCopyStreams; ++k) {

@@ -119,6 +119,59 @@ __global__ __launch_bounds__(FFTB_S1_NT, 4) void fftb_stage1_kernel(const LongWo
     }
 }
 
+// spec B stage 1 on the matrix cores.  grid (NB / 32, transforms, channels), 64 x ceil(NA / 32) threads: every wave owns one
+// 32 (outputs c) x 32 (columns b) tile.  The four chains of an output are dense products over a,
+//     P = Wr Zr,  Q = Wi Zi,  R = Wi Zr,  S = Wr Zi        (W[c][a] = WA[(a c) mod NA]),
+// and gfx950's f32 MFMA is bit for bit a k-ordered fmaf chain (cdna_hip_programming.md, 'FP32-input MFMA'; the FT4 stage's
+// ft4_dft567_mfma_kernel relies on the same fact): v_mfma_f32_32x32x2_f32 with k0 = (w[a], z[a]), k1 = (w[a+1], z[a+1]) extends
+// each chain by two terms in ascending a -- exactly the restatement's order.  NA is odd: the last step's k1 carries z = 0, which
+// adds exactly nothing.  Used for FST4W's 125 x 256: the VALU form (fftb_stage1_kernel, CWSLG_LONG_VARIANT bit 0) waits on
+// scalar-cache misses of its 125 KB twiddle matrix (2.05 ms per 128 frames; this kernel 1.08 ms); here the twiddle is one LDS read
+// and three integer operations per lane per FOUR matrix instructions (256 cycles of matrix pipe).  WSPR's 45 x 1024 stays on the
+// VALU form (0.63 against 1.14 ms: 45 rows waste 30 % of two 32-row tiles and its 16 KB matrix sits in the scalar cache).
+typedef float lf32x16 __attribute__((ext_vector_type(16)));
+template <int NA, int NB>
+__global__ __launch_bounds__(64 * ((NA + 31) / 32)) void fftb_stage1_mfma_kernel(const LongWork *__restrict__ works, FftbTables tb,
+                                                                               int which_in, int which_out)
+{
+    __shared__ float2 s_wa[NA];
+    const LongWork *w = works + blockIdx.z;
+    const int t = blockIdx.y, b0 = blockIdx.x * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float2 *zin = (which_in == 0 ? w->z : w->aux) + (size_t)t * (NA * NB);
+    float2 *yout = (which_out == 0 ? w->y : w->aux + NA * NB) + (size_t)t * (NA * NB);
+    for (int k = tid; k < NA; k += blockDim.x) s_wa[k] = tb.wa[k];
+    __syncthreads();
+    const int i = lane & 31, h = lane >> 5;
+    const int c0 = 32 * wv;
+    const int c = (c0 + i < NA) ? c0 + i : 0;              // rows past NA - 1 compute row 0 and are not stored
+    const int b = b0 + i;
+    const CWSLG_GLOBAL v2f *zg = as_global(reinterpret_cast<const v2f *>(zin)) + b;
+    lf32x16 P, Q, R, S;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { P[v] = 0.f; Q[v] = 0.f; R[v] = 0.f; S[v] = 0.f; }
+    int idx = (h * c) % NA;                               // ((a + h) c) mod NA at a = 0
+    const int step = (2 * c) % NA;
+#pragma unroll 2
+    for (int a = 0; a < NA; a += 2) {
+        v2f z = {0.f, 0.f};
+        if (a + h < NA) z = zg[(size_t)NB * (a + h)];       // lane (i, h): B[k = h][j = i] = z[a + h][b0 + i]
+        const float2 tw = s_wa[idx];                        //              A[i][k = h]     = W[c0 + i][a + h]
+        idx += step;
+        if (idx >= NA) idx -= NA;
+        P = __builtin_amdgcn_mfma_f32_32x32x2f32(tw.x, z.x, P, 0, 0, 0);
+        Q = __builtin_amdgcn_mfma_f32_32x32x2f32(tw.y, z.y, Q, 0, 0, 0);
+        R = __builtin_amdgcn_mfma_f32_32x32x2f32(tw.y, z.x, R, 0, 0, 0);
+        S = __builtin_amdgcn_mfma_f32_32x32x2f32(tw.x, z.y, S, 0, 0, 0);
+    }
+    // D[row][col]: col = lane & 31 (b), row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5) (c)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int cr = c0 + (v & 3) + 8 * (v >> 2) + 4 * h;
+        if (cr < NA) yout[(size_t)cr * NB + b] = lcmul(make_float2(P[v] - Q[v], R[v] + S[v]), tb.wn[b * cr]);
+    }
+}
+
 // spec B stage 2.  grid (NA, transforms, channels), 256 threads.  In place on y (row c).
 template <int NA, int NB>
 __global__ __launch_bounds__(256) void fftb_stage2_kernel(const LongWork *__restrict__ works, FftbTables tb, int which)
