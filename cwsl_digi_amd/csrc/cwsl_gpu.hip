@@ -197,6 +197,10 @@ struct cwslg_ctx {
     bool ft4_dft_valu = false;         // CWSLG_FT4_DFT=valu
     LongConfig long_cfg;
     LongShared long_shared;
+    // side stream: optionally (CWSLG_SYNC_VARIANT bit 3) carries the FT8 candidate kernel next to the following demod launch
+    hipStream_t side = nullptr;
+    hipEvent_t sync2d_done = nullptr, cand_done = nullptr, sync_tail = nullptr;
+    bool cand_pending = false;
     int long_variant = 0;              // CWSLG_LONG_VARIANT: bit 0 = FST4W's 125 x 256 stage 1 on the VALU, bit 1 = WSPR's 45 x 1024 stage 1 on the matrix cores
     int sync_variant = 0;              // CWSLG_SYNC_VARIANT: bit mask of measured alternatives in the sync stage (0 = defaults)
     // multi-GPU slot-boundary rendezvous (multi_gpu.inc)
@@ -271,6 +275,24 @@ void span_begin(cwslg_ctx *c, int kind, hipEvent_t *a, hipEvent_t *b)
 void span_end(cwslg_ctx *c, hipEvent_t b)
 {
     if (b) hipEventRecord(b, c->stream);
+}
+// a span on another stream of the context (both events on that stream)
+void span_begin_on(cwslg_ctx *c, int kind, hipStream_t st, hipEvent_t *a, hipEvent_t *b)
+{
+    *a = *b = nullptr;
+    if (!c->timing) return;
+    std::pair<hipEvent_t, hipEvent_t> p;
+    if (!c->ev_pool.empty()) { p = c->ev_pool.back(); c->ev_pool.pop_back(); }
+    else { hipEventCreate(&p.first); hipEventCreate(&p.second); }
+    *a = p.first; *b = p.second;
+    hipEventRecord(*a, st);
+    c->spans.push_back({*a, *b, kind});
+}
+// every stream of the context that can hold device work (host-visible results must wait for all of them)
+hipError_t sync_streams(cwslg_ctx *c)
+{
+    if (c->side) { hipError_t e = hipStreamSynchronize(c->side); if (e != hipSuccess) return e; }
+    return hipStreamSynchronize(c->stream);
 }
 // Only call with the stream idle (after hipStreamSynchronize).
 void drain_spans(cwslg_ctx *c)
@@ -457,7 +479,7 @@ int process_locked(cwslg_ctx *c)
             const size_t need = ckpt_need((ch.pend_lo - ch.origin_abs) / (int64_t)rx.D, ch.pend_n / rx.D);
             const size_t have = std::get<3>(ch.phasor_key);
             if (need <= have) continue;
-            HIPCHK(c, hipStreamSynchronize(c->stream));             // the old table may be in use by a queued launch
+            HIPCHK(c, sync_streams(c));             // the old table may be in use by a queued launch
             auto key = ch.phasor_key;
             std::get<3>(key) = std::max(need, 2 * have);
             rc = retarget_phasor(c, ch, key, make_float2(ch.k.inc.real(), ch.k.inc.imag()));
@@ -724,6 +746,10 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
         hipEventCreateWithFlags(&c->copy_done[k], hipEventDisableTiming);
     }
     hipEventCreateWithFlags(&c->demod_done, hipEventDisableTiming);
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
+    hipEventCreateWithFlags(&c->sync2d_done, hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->cand_done, hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->sync_tail, hipEventDisableTiming);
     // tone table of the synthetic source (same construction as the oracle's)
     {
         std::vector<float2> tab(4096);
@@ -742,6 +768,7 @@ void cwslg_destroy(cwslg_ctx *c)
     if (!c) return;
     hipSetDevice(c->device);
     for (hipStream_t cs : c->copy_stream) if (cs) hipStreamSynchronize(cs);
+    if (c->side) hipStreamSynchronize(c->side);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (Channel &ch : c->chans) {
         if (ch.d_block) hipFree(ch.d_block);
@@ -767,6 +794,8 @@ void cwslg_destroy(cwslg_ctx *c)
         if (c->copy_done[k]) hipEventDestroy(c->copy_done[k]);
     }
     if (c->demod_done) hipEventDestroy(c->demod_done);
+    if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    for (hipEvent_t e : {c->sync2d_done, c->cand_done, c->sync_tail}) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -827,7 +856,7 @@ int cwslg_receiver_close(cwslg_ctx *c, int rx_id)
     if (rx_id < 0 || rx_id >= (int)c->rxs.size() || !c->rxs[rx_id].open) return fail(c, CWSLG_ERR_ARG, "bad receiver id");
     hipSetDevice(c->device);
     for (hipStream_t cs : c->copy_stream) HIPCHK(c, hipStreamSynchronize(cs));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_streams(c));
     Receiver &rx = c->rxs[rx_id];
     for (int id : rx.channels) {        // Receiver::finish terminates its instances (Receiver.hpp:194-199)
         Channel &ch = c->chans[id];
@@ -1092,7 +1121,7 @@ int cwslg_channel_open(cwslg_ctx *c, int rx_id, int32_t demod_hz, int usb, const
     ch.d_tone = (float2 *)(ch.d_block + 2 * fbytes + ibytes + 256);
     HIPCHK_FREE(hipMemsetAsync(ch.d_block + 2 * fbytes + ibytes, 0, 256, c->stream));
     HIPCHK_FREE(hipMemcpyAsync(ch.d_tone, ch.k.tone.data(), ch.k.block * sizeof(float2), hipMemcpyHostToDevice, c->stream));
-    HIPCHK_FREE(hipStreamSynchronize(c->stream));   // k.tone is a temporary host vector: finish the copy now
+    HIPCHK_FREE(sync_streams(c));   // k.tone is a temporary host vector: finish the copy now
     // phasor checkpoints: cover the first frame, which continues across the discarded partial slot
     // (up to 2 frames of blocks since creation), plus one tile of slack
     const size_t n_ckpt = ckpt_need(2 * (long long)ch.frame_len, 0) + kTile / kCkptStride;
@@ -1215,7 +1244,7 @@ int cwslg_channel_close(cwslg_ctx *c, int ch_id)
     std::lock_guard<std::mutex> g(c->mu);
     if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
     hipSetDevice(c->device);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_streams(c));
     Channel &ch = c->chans[ch_id];
     Receiver &rx = c->rxs[ch.rx];
     rx.channels.erase(std::remove(rx.channels.begin(), rx.channels.end(), ch_id), rx.channels.end());
@@ -1242,7 +1271,7 @@ int cwslg_channel_tune(cwslg_ctx *c, int ch_id, int32_t demod_hz, int usb)
     int rc = check_tuning(rx.fs, kSsbBw, f_hz, usb != 0);
     if (rc) return fail(c, rc, "%s", cwslg_strerror(rc));                      // the channel keeps its old tuning, as after a throw
     if ((rc = process_locked(c)) != CWSLG_OK) return rc;                        // everything already pushed: old tone
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_streams(c));
     DemodConstants k = make_constants(rx.fs, kSsbBw, f_hz, usb != 0);
     const auto new_key = std::make_tuple(rx.fs, demod_hz, usb ? 1 : 0, std::get<3>(ch.phasor_key));
     if ((rc = retarget_phasor(c, ch, new_key, make_float2(k.inc.real(), k.inc.imag()))) != CWSLG_OK) return rc;
@@ -1250,7 +1279,7 @@ int cwslg_channel_tune(cwslg_ctx *c, int ch_id, int32_t demod_hz, int usb)
     ch.demod_hz = demod_hz;
     ch.usb = usb != 0;
     HIPCHK(c, hipMemcpyAsync(ch.d_tone, ch.k.tone.data(), ch.k.block * sizeof(float2), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_streams(c));
     ch.origin_abs = (int64_t)rx.total;                                          // workspace zeroed, phase (1,0): history restarts here
     ch.pend_lo = ch.origin_abs;
     return CWSLG_OK;
@@ -1296,7 +1325,7 @@ int cwslg_slot_boundary(cwslg_ctx *c, int group, uint64_t epoch_s)
         fn = c->rdv_fn;
         user = c->rdv_user;
         if (!fn) return CWSLG_OK;
-        HIPCHK(c, hipStreamSynchronize(c->stream));        // this GPU's frames of the epoch are final ...
+        HIPCHK(c, sync_streams(c));        // this GPU's frames of the epoch are final ...
         drain_spans(c);
     }
     uint64_t total = mine;                                  // ... and after the rendezvous so are every other GPU's
@@ -1323,7 +1352,7 @@ int cwslg_synchronize(cwslg_ctx *c)
     std::lock_guard<std::mutex> g(c->mu);
     hipSetDevice(c->device);
     for (hipStream_t cs : c->copy_stream) HIPCHK(c, hipStreamSynchronize(cs));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_streams(c));
     drain_spans(c);
     return CWSLG_OK;
 }
@@ -1341,7 +1370,7 @@ int cwslg_fetch_frame(cwslg_ctx *c, int ch_id, int16_t *dst, size_t cap, uint64_
         HIPCHK(c, hipMemcpyAsync(dst, ch.d_i16, ch.frame_len * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
     }
     if (factor) HIPCHK(c, hipMemcpyAsync(factor, ch.d_factor, sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_streams(c));
     drain_spans(c);
     if (start_epoch) *start_epoch = ch.frame_t0;
     if (n_valid) *n_valid = ch.frame_valid;
@@ -1442,7 +1471,7 @@ int cwslg_fill_decoder_block(cwslg_ctx *c, int ch_id, void *block, size_t block_
     const size_t nel = ch.frame_len < cwslg::handoff::kD2Samples ? ch.frame_len : cwslg::handoff::kD2Samples;   // :576-579
     hipSetDevice(c->device);
     HIPCHK(c, hipMemcpyAsync(blk + L.d2, ch.d_i16, nel * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));   // :588
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_streams(c));
     drain_spans(c);
     if (start_epoch) *start_epoch = ch.frame_t0;
     return CWSLG_OK;
@@ -1479,7 +1508,7 @@ int cwslg_fetch_audio_f32(cwslg_ctx *c, int ch_id, float *dst, size_t cap, size_
     if (cap < ch.frame_len) return fail(c, CWSLG_ERR_ARG, "destination holds %zu samples, frame has %zu", cap, ch.frame_len);
     hipSetDevice(c->device);
     HIPCHK(c, hipMemcpyAsync(dst, ch.d_frame[ch.frame_idx], ch.frame_valid * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, sync_streams(c));
     drain_spans(c);
     std::memset(dst + ch.frame_valid, 0, (ch.frame_len - ch.frame_valid) * sizeof(float));   // the reference's zero tail
     if (n_valid) *n_valid = ch.frame_valid;
@@ -1561,7 +1590,7 @@ int cwslg_channel_phasor_checkpoints(cwslg_ctx *c, int ch_id, float *dst_ri, siz
     if (dst_ri && n) {
         const size_t m = std::min(n, pt.n_ckpt);
         HIPCHK(c, hipMemcpyAsync(dst_ri, pt.d_ckpt, m * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, sync_streams(c));
     }
     return CWSLG_OK;
 }
