@@ -433,8 +433,27 @@ __device__ __forceinline__ float unpack_power(float2 A, float2 B, float2 wk)
 #ifndef CWSLG_SPEC_WAVES
 #define CWSLG_SPEC_WAVES 4
 #endif
+// arr[idx] for a per-lane idx in 0..7 of a by-value (scalar-register) table: a select chain, not a scratch array
+__device__ __forceinline__ float pick8(const float (&arr)[8], int idx)
+{
+    float v = arr[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v = (idx == k) ? arr[k] : v;
+    return v;
+}
+
 constexpr int SPEC_JPER = CWSLG_SPEC_JPER;   // symbol steps per workgroup (FT8: 372 = 31 x 12); -D overrides are for A/B builds only
-template <int NA, int NIN, int STEP, bool WINDOW>
+// S1MFMA: stage 1 on the matrix cores.  The 28 (FT8) / 16 (FT4) fmaf chains P, Q, R, S of a column and the running sum of output 0 are
+// rows of ONE 32 x 32 accumulator tile per wave (32 columns): row = chain + 8 * (pair mod 4) + 4 * (pair / 4).  Step a is a single
+// v_mfma_f32_32x32x2_f32 whose two k-slots carry (coefficient for Re z_a, Re z_a) and (coefficient for Im z_a, Im z_a); a chain that
+// does not use a slot has coefficient 0 there, which adds exactly nothing, and the matrix core accumulates k-slots in order as
+// correctly rounded fmaf -- so every chain is the restatement's, bit for bit (same tests).  The output mapping of the instruction puts
+// all four chains of a pair into ONE lane (lanes 0-31: pairs 1-4, lanes 32-63: pairs 5-7 and output 0), which therefore finishes its
+// outputs without any cross-lane traffic.  Stage 1 is 190 of the kernel's ~690 VALU instructions per wave and the matrix pipe is idle
+// otherwise -- but MEASURED SLOWER (sync stage 1.56 against 1.29 ms per 512 slots, same box): the seven matrix instructions of a wave
+// are one dependent chain (64 cycles each, half their multiplies by zero) and do not overlap the other waves' VALU work the way
+// the instruction counts suggest.  Kept as CWSLG_SYNC_VARIANT bit 4; the default is the VALU form.
+template <int NA, int NIN, int STEP, bool WINDOW, bool S1MFMA>
 __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kernel(const SyncWork *__restrict__ works, SyncTables tb, int nbins, int nsteps)
 {
     constexpr int NZ = NA * 128;
@@ -451,7 +470,8 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     const int j0 = blockIdx.x * SPEC_JPER;
     const int jend = min(j0 + SPEC_JPER, nsteps);
     const int tid_ = threadIdx.x;
-    const int b_ = tid_ & 127;
+    const int hh_ = S1MFMA ? ((tid_ >> 5) & 1) : 0;        // S1MFMA: which k-slot (Re / Im) and which half of the pairs this lane serves
+    const int b_ = S1MFMA ? 32 * (tid_ >> 6) + (tid_ & 31) : (tid_ & 127);
     const float fac = 1.0f / 300.0f;
     // Barriers are lds_barrier() (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also wait for vmcnt(0), i.e. for
     // the prefetched window, at the first barrier behind its issue.
@@ -473,8 +493,38 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         }
     }
     Stage1Tw<NA> tw1;
-    if (tid_ < 128) stage1_load_tw<0, NA>(tb.w1920, b_, tw1);
-    else stage1_load_tw<1, NA>(tb.w1920, b_, tw1);
+    float2 twm[8];                                        // S1MFMA: W_NZ^(b c), W_NZ^(b (NA - c)) of this lane's (up to) four pairs
+    float coefA[AMAX];                                    // S1MFMA: this lane's A operand of step a (row tid & 31, k-slot hh)
+    if (S1MFMA) {
+        constexpr int NPAIR = NA / 2;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c = 1 + p + 4 * hh_;
+            twm[2 * p] = (c <= NPAIR) ? tb.w1920[b_ * c] : make_float2(0.f, 0.f);
+            twm[2 * p + 1] = (c <= NPAIR) ? tb.w1920[b_ * (NA - c)] : make_float2(0.f, 0.f);
+        }
+        const int row = tid_ & 31;
+        const int q = row & 3, rc = 1 + (row >> 3) + 4 * ((row >> 2) & 1);      // chain (P, Q, R, S) and pair of this accumulator row
+        const bool s0row = (row >> 3) == 3 && ((row >> 2) & 1) == 1;             // rows 28..31: output 0 (28: Re, 29: Im)
+#pragma unroll
+        for (int a = 1; a < AMAX; ++a) {
+            float cf = 0.0f;
+            if (s0row) cf = (q == hh_ && q < 2) ? 1.0f : 0.0f;                   // fmaf(z, 1, acc) = acc + z exactly
+            else if (rc <= NPAIR) {
+                const int idx = (a * rc) % NA;
+                const int ix = (idx <= NA / 2) ? idx : NA - idx;
+                const float wr = pick8(tb.war, ix);
+                const float wi = (idx <= NA / 2) ? pick8(tb.wai, ix) : -pick8(tb.wai, ix);
+                // P = sum zr wr, Q = sum zi wi, R = sum zr wi, S = sum zi wr: slot 0 multiplies Re z, slot 1 Im z
+                cf = (q == 0) ? (hh_ ? 0.0f : wr) : (q == 1) ? (hh_ ? wi : 0.0f) : (q == 2) ? (hh_ ? 0.0f : wi) : (hh_ ? wr : 0.0f);
+            }
+            coefA[a] = cf;
+        }
+        coefA[0] = 0.0f;
+    } else {
+        if (tid_ < 128) stage1_load_tw<0, NA>(tb.w1920, b_, tw1);
+        else stage1_load_tw<1, NA>(tb.w1920, b_, tw1);
+    }
     // the unpack twiddles W_2NZ^K of this thread's items (bins K1, K2 of each; the two upper bins of an item are rare for
     // FT8's default range and fetched on demand)
     float2 w3[IPT][2];
@@ -499,14 +549,24 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     // registers across it (168 VGPRs, 3 workgroups per CU)
     int t = tid_;
     asm volatile("" : "+v"(t));
-    const int tid = t, b = t & 127;
+    const int tid = t, b = S1MFMA ? 32 * (t >> 6) + (t & 31) : (t & 127);
     float2 z[AMAX];
+    float zk[AMAX];                                       // S1MFMA: Re (lanes 0-31) or Im (lanes 32-63) of z_a, the B operand of step a
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) {
-        float lo = fac * (float)(short)(raw[a] & 0xFFFFu);
-        float hi = fac * (float)(short)(raw[a] >> 16);
-        if (WINDOW) { lo = lo * wn[WINDOW ? a : 0].x; hi = hi * wn[WINDOW ? a : 0].y; }
-        z[a] = (128 * a + b < NPACK) ? make_float2(lo, hi) : make_float2(0.f, 0.f);
+        const bool live = 128 * a + b < NPACK;
+        if (!S1MFMA || a == 0) {
+            float lo = fac * (float)(short)(raw[a] & 0xFFFFu);
+            float hi = fac * (float)(short)(raw[a] >> 16);
+            if (WINDOW) { lo = lo * wn[WINDOW ? a : 0].x; hi = hi * wn[WINDOW ? a : 0].y; }
+            z[a] = live ? make_float2(lo, hi) : make_float2(0.f, 0.f);
+            zk[a] = 0.0f;
+        } else {
+            float x = fac * (float)(short)(hh_ ? (raw[a] >> 16) : (raw[a] & 0xFFFFu));
+            if (WINDOW) x = x * (hh_ ? wn[WINDOW ? a : 0].y : wn[WINDOW ? a : 0].x);
+            zk[a] = live ? x : 0.0f;
+            z[a] = make_float2(0.f, 0.f);
+        }
     }
     // the PREVIOUS step's power row leaves now (16 B per lane): issued ahead of the prefetch, its stores have a whole
     // transform to retire before the top of the next iteration waits for vmcnt(0)
@@ -519,9 +579,34 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         for (int a = 0; a < AMAX; ++a) raw[a] = (128 * a + b < NPACK) ? d32[(STEP / 2) * (j + 1) + 128 * a] : 0u;
     }
 
-    // stage 1 (wave-uniform split of the conjugate pairs of outputs between waves 0-1 and waves 2-3)
-    if (tid < 128) spectra_stage1_regs<0, NA, AMAX>(z, s_y, tb, tw1, b);
-    else spectra_stage1_regs<1, NA, AMAX>(z, s_y, tb, tw1, b);
+    if (S1MFMA) {
+        constexpr int NPAIR = NA / 2;
+        typedef float f32x16 __attribute__((ext_vector_type(16)));
+        f32x16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+        if (hh_) { acc[12] = z[0].x; acc[13] = z[0].y; }      // output 0 = ((z0 + z1) + z2) + ... : its chain starts from z0
+#pragma unroll
+        for (int a = 1; a < AMAX; ++a)                      // lane (i, h): A[i][k = h] = coefA, B[k = h][j = i] = Re / Im of z_a of column b
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(coefA[a], zk[a], acc, 0, 0, 0);
+        // D[row][col = lane & 31], row = (v & 3) + 8 (v >> 2) + 4 hh: v = 4 p + chain, pair c = 1 + p + 4 hh
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int c = 1 + p + 4 * hh_;
+            if (c <= NPAIR) {
+                const float P = acc[4 * p], Q = acc[4 * p + 1], R = acc[4 * p + 2], S = acc[4 * p + 3];
+                const float2 yc = make_float2(z[0].x + (P - Q), z[0].y + (R + S));
+                const float2 yn = make_float2(z[0].x + (P + Q), z[0].y + (S - R));
+                s_y[c][b] = cmul_f(yc, twm[2 * p]);
+                s_y[NA - c][b] = cmul_f(yn, twm[2 * p + 1]);
+            }
+        }
+        if (hh_) s_y[0][b] = make_float2(acc[12], acc[13]);
+    } else {
+        // stage 1 (wave-uniform split of the conjugate pairs of outputs between waves 0-1 and waves 2-3)
+        if (tid < 128) spectra_stage1_regs<0, NA, AMAX>(z, s_y, tb, tw1, b);
+        else spectra_stage1_regs<1, NA, AMAX>(z, s_y, tb, tw1, b);
+    }
     lds_barrier();
 
     // stage 2, pass A: DIT stages len = 2,4,8 (see the first version)
