@@ -147,3 +147,25 @@ def test_skimmer_rejects_missing_decoders_and_uncovered_bands(tmp_path):
     cfg.write_text("[decoders]\ndecoder=28074000 FT8\n")
     out = subprocess.run([_skimmer(), "--config", str(cfg), "--rx", f"file={a},fs=192000,block=2048,lo=14100000", "--dry-run"], capture_output=True, text=True)
     assert out.returncode == 1 and "no receiver covers it" in out.stderr
+
+
+def test_skimmer_shards_decoders_by_receiver(tmp_path):
+    """One process per GPU: receiver k and every decoder on it belong to rank k mod world (a band's IQ goes to
+    exactly one GPU; the reference creates one Receiver per band, CWSL_DIGI.cpp:115-129).  --dry-run prints the rank's share."""
+    cfg = tmp_path / "config.ini"
+    cfg.write_text(CONFIG)
+    a = tmp_path / "a.c64"; a.write_bytes(b"")
+    base = [_skimmer(), "--config", str(cfg), "--rx", f"file={a},fs=192000,block=2048,lo=14100000",
+            "--rx", f"file={a},fs=96000,block=1024,lo=7060000", "--dry-run"]
+    whole = json.loads(subprocess.run(base, capture_output=True, text=True).stdout)["plan"]
+    shares = []
+    for rank in range(2):
+        out = subprocess.run(base + ["--world", "2", "--rank", str(rank), "--rccl-id", str(tmp_path / "id")], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr
+        plan = json.loads(out.stdout)["plan"]
+        assert plan and all(p["rx"] % 2 == rank for p in plan)
+        shares += plan
+    assert sorted(shares, key=lambda p: (p["rx"], p["freq_hz"])) == sorted(whole, key=lambda p: (p["rx"], p["freq_hz"]))
+    # a world larger than the number of receivers, a rank outside the world, or no id file: usage errors
+    for bad in (["--world", "2", "--rank", "2", "--rccl-id", "x"], ["--world", "2", "--rank", "0"]):
+        assert subprocess.run(base + bad, capture_output=True, text=True).returncode == 2
