@@ -80,3 +80,31 @@ def test_fst4w_stages_and_candidates_bit_exact(oracle, long_frames):
     baud = 12000.0 / 8200.0
     assert abs(got[0][0] - (1500.0 + 1.5 * baud)) <= baud
     assert any(abs(c[0] - (1451.0 + 1.5 * baud)) <= baud for c in got[:5])
+
+
+def test_short_slot_zero_tail(oracle):
+    """A 120 s slot that ended after 50 s: the frame's zero tail goes through both searches (wsprd reads 114 s, jt9 120 s of it);
+    lists still bit-identical to the restatement."""
+    import cwsl_digi_amd as P
+    n = 9600000 // BLK * BLK                                            # 50 s
+    rng = np.random.default_rng(8)
+    f_w, f_f = -30000, 55000
+    iq = oracle.synth_iq(78, n, FS)
+    iq = iq + wspr_iq(FS, n, f_w, 1500 - 20.0, 1.5, 700.0, rng) + fst4w_iq(FS, n, f_f, 1530.0, 0.7, 600.0, rng)
+    iq = iq.astype(np.complex64)
+    with P.Context(0) as ctx:
+        ctx.enable_long_sync(True)
+        rx = ctx.receiver_open(FS, BLK, 0)
+        cw, cf = ctx.channel_open(rx, f_w, "WSPR"), ctx.channel_open(rx, f_f, "FST4W-120")
+        ctx.slot_boundary("S120", 120)
+        for k in range(0, n, 256 * BLK):
+            ctx.push_iq(rx, iq[k:k + 256 * BLK])
+        ctx.slot_boundary("S120", 240)
+        fw, ff = ctx.fetch_frame(cw), ctx.fetch_frame(cf)
+        assert fw["n_valid"] == n // 16 and not fw["i16"][n // 16:].any()
+        gw, gf = ctx.fetch_wspr_candidates(cw), ctx.fetch_fst4w_candidates(cf)
+    rw, rf = oracle.wspr_search(fw["i16"]), oracle.fst4w_candidates(ff["i16"])
+    b = lambda t: [np.float32(x).view(np.uint32) if isinstance(x, float) else x for x in t]
+    assert [b(t) for t in gw] == [b(t) for t in rw] and len(rw) >= 1
+    assert [b(t) for t in gf] == [b(t) for t in rf] and len(rf) >= 1
+    assert any(abs(c[0] - (-20.0 + 2.197)) <= 1.5 for c in gw)
