@@ -945,7 +945,7 @@ __global__ __launch_bounds__(NT) void demod_exact_kernel(const ChanWork *__restr
 //   * the 16 taps of a block are fetched by VECTOR loads from a lane-invariant address (L1 broadcast) one step ahead: they are
 //     counted in vmcnt, so waiting for them does not drain the LDS reads in flight the way scalar loads (lgkmcnt) did in the
 //     round-1 attempt at this layout.
-// Tile = 240 outputs on 128 threads: 39.2 KB of LDS, so FOUR tiles = 8 waves fit a CU -- two waves per SIMD, which the VALU needs
+// Tile = 232 outputs on 128 threads (116 active): 39.5 KB of LDS, so FOUR tiles = 8 waves fit a CU -- two waves per SIMD, which the VALU needs
 // to issue every 2 cycles (a lone wave issues every 4); with 256-output tiles (41.7 KB, 3 per CU) this kernel ran no faster than
 // the one-output form.
 // The un-fused order needs 150 VALU lane-operations per input sample against demod_kernel's 44, so its ceiling is ~40 % of the
@@ -959,9 +959,11 @@ __global__ __launch_bounds__(NT, 2) void demod_exact2_kernel(const ChanWork *__r
     using Geo = DemodGeom<D, T>;
     constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
     constexpr int NBH = (Geo::NBLK + 1) / 2 + 1;          // blocks per parity array (+1 slack)
-    constexpr int BP = D + 1;                             // block pitch in complex
+    constexpr int BP = D + 2;                             // block pitch in complex: even (16-byte aligned pairs -> ds_read_b128), and lane
+                                                          // stride 2 (D + 2) dwords = 36 (mod 64) for D = 16: the 16 lanes of a b128 group hit 16
+                                                          // distinct 16-byte slots
     static_assert(2 * NT >= T && T % 4 == 0 && D % 4 == 0, "two outputs per thread");
-    __shared__ float2 s_t[2][NBH * BP];
+    __shared__ __attribute__((aligned(16))) float2 s_t[2][NBH * BP];
     __shared__ float2 s_phase[Geo::NBLK + 4];             // the pipeline reads (never uses) two blocks past the tile
 
     const int total = (tiles_x < 0 ? -tiles_x : tiles_x) * n_ch;
@@ -1012,9 +1014,8 @@ __global__ __launch_bounds__(NT, 2) void demod_exact2_kernel(const ChanWork *__r
                 const float2 a = cmul_exact(make_float2(x.x, x.y), tn0);
                 const float2 b = cmul_exact(make_float2(x.z, x.w), tn1);
                 const int blk = r / D, m = r % D;
-                float2 *dst = &s_t[blk & 1][(blk >> 1) * BP + m];
-                dst[0] = a;
-                dst[1] = b;
+                v4f ab; ab.x = a.x; ab.y = a.y; ab.z = b.x; ab.w = b.y;          // m is even: one aligned 16-byte store
+                *reinterpret_cast<v4f *>(&s_t[blk & 1][(blk >> 1) * BP + m]) = ab;
             }
         }
     }
@@ -1022,42 +1023,53 @@ __global__ __launch_bounds__(NT, 2) void demod_exact2_kernel(const ChanWork *__r
     const int o0 = 2 * tid;
     if (o0 < T && o0 < cur.n_out) {
         const int first_blk = cur.first_valid / D;           // tile blocks before this precede the demodulator's origin
-        float wr0 = 0.0f, wi0 = 0.0f, wr1 = 0.0f, wi1 = 0.0f; // the two workspace slots, zero after their last read-out (:178)
         // Software pipeline, unrolled by six (two sample buffers x three tap buffers rotate by renaming): while step n is computed,
         // the LDS reads of block n + 1 and the tap loads of block n + 1 are in flight.  (Occupancy is LDS-bound -- three tiles, six
         // waves per CU -- so registers are plentiful and latency has to be hidden inside the wave.)
-        auto load_block = [&](int n, float2 (&t)[D], float2 &ph) {
-            const float2 *tp = &s_t[n & 1][(tid + (n >> 1)) * BP];
+        // Everything per block is written on <2 x float> values (re, im): the products (re*h, im*h) are ONE v_pk_mul_f32, the running
+        // sums ONE v_pk_add_f32 -- the same IEEE operations on the same operands, half the instructions.  Packed f32 has no higher
+        // FLOP rate than scalar f32, but with two waves per SIMD (LDS-bound occupancy) the kernel is ISSUE-bound, and a packed
+        // instruction keeps the pipe busy for two issue slots.
+        auto load_block = [&](int n, v2f (&t)[D], v2f &ph) {
+            const v4f *tp = reinterpret_cast<const v4f *>(&s_t[n & 1][(tid + (n >> 1)) * BP]);
 #pragma unroll
-            for (int m = 0; m < D; ++m) t[m] = tp[m];
-            ph = s_phase[o0 + n];
+            for (int m = 0; m < D; m += 2) {
+                const v4f q = tp[m >> 1];
+                t[m] = v2f{q.x, q.y};
+                t[m + 1] = v2f{q.z, q.w};
+            }
+            ph = *reinterpret_cast<const v2f *>(&s_phase[o0 + n]);
         };
         auto load_taps = [&](int n, v4f (&h)[D / 4]) {
 #pragma unroll
             for (int q = 0; q < D / 4; ++q) h[q] = tapv[(D / 4) * (n < 32 ? n : 31) + q];
         };
-        auto accumulate = [&](const float2 (&t)[D], const v4f (&h)[D / 4], float2 ph, float &wr, float &wi) {
-            float sr = 0.0f, si = 0.0f;
+        auto accumulate = [&](const v2f (&t)[D], const v4f (&h)[D / 4], v2f ph, v2f &w) {
+            v2f sum = {0.0f, 0.0f};
 #pragma unroll
             for (int m = 0; m < D; ++m) {
                 const float hm = h[m >> 2][m & 3];
-                sr = sr + t[m].x * hm;
-                si = si + t[m].y * hm;
+                const v2f hh = {hm, hm};
+                sum = sum + t[m] * hh;                       // sr += t.x*h ; si += t.y*h   (:167-168)
             }
-            const float2 pr = cmul_exact(make_float2(sr, si), ph);   // sum * phase (:170)
-            wr = wr + pr.x;
-            wi = wi + pr.y;
+            // sum * phase (:170), std::complex's (ac - bd, ad + bc): ac, ad from sum.x, bd, bc from sum.y
+            const v2f sxx = {sum.x, sum.x}, syy = {sum.y, sum.y}, phs = {ph.y, ph.x};
+            const v2f p1 = sxx * ph;                         // (ac, ad)
+            const v2f p2 = syy * phs;                        // (bd, bc)
+            const v2f pr = {p1.x - p2.x, p1.y + p2.y};
+            w = w + pr;
         };
         // step n: block o0 + n feeds output o0 with tap block n (n <= 31) and output o0 + 1 with tap block n - 1 (n >= 1)
-        auto step = [&](int n, const float2 (&t)[D], float2 ph, const v4f (&hn)[D / 4], const v4f (&hnm1)[D / 4]) {
+        v2f w0 = {0.0f, 0.0f}, w1 = {0.0f, 0.0f};           // the two workspace slots, zero after their last read-out (:178)
+        auto step = [&](int n, const v2f (&t)[D], v2f ph, const v4f (&hn)[D / 4], const v4f (&hnm1)[D / 4]) {
             if (o0 + n >= first_blk) {
-                if (n <= 31) accumulate(t, hn, ph, wr0, wi0);
-                if (n >= 1) accumulate(t, hnm1, ph, wr1, wi1);
+                if (n <= 31) accumulate(t, hn, ph, w0);
+                if (n >= 1) accumulate(t, hnm1, ph, w1);
             }
         };
         // taps[n] lives in buffer n mod 3: at step n the current block is buffer n mod 3, the previous one (n - 1) mod 3, and the
         // third is free for the prefetch of taps[n + 1]; the mixed samples ping-pong between tA and tB.
-        float2 tA[D], tB[D], phA, phB;
+        v2f tA[D], tB[D], phA, phB;
         v4f h0[D / 4], h1[D / 4], h2[D / 4];
 #pragma unroll
         for (int q = 0; q < D / 4; ++q) { h0[q] = hnext[q]; h2[q] = hnext[q]; }   // tap block 0 (fetched at the top); h2 is a placeholder for "block -1"
@@ -1072,6 +1084,7 @@ __global__ __launch_bounds__(NT, 2) void demod_exact2_kernel(const ChanWork *__r
             load_taps(n + 5, h2); load_block(n + 5, tB, phB); step(n + 4, tA, phA, h1, h0);
             load_taps(n + 6, h0); load_block(n + 6, tA, phA); step(n + 5, tB, phB, h2, h1);
         }
+        const float wr0 = w0.x, wi1 = w1.y;
         // Iterate(): out[k] for block index mod 4 (qs and T are multiples of 4; o0 is even)
         const float v0 = (o0 & 2) ? -wr0 : wr0;
         const float v1 = (o0 & 2) ? wi1 * cur.sign : -wi1 * cur.sign;
