@@ -38,7 +38,7 @@ namespace cwslg {
 
 // ---------------------------------------------------------------------------------------------
 constexpr int kTile = 256;             // outputs per demod workgroup
-constexpr int kTileExact = 232;        // ... of demod_exact2_kernel (four tiles of 39.5 KB per CU)
+constexpr int kTileExact = 248;        // ... of demod_exact2_kernel (124 of 128 lanes busy; four tiles of 39.7 KB per CU)
 constexpr int kDemodThreads = 256;
 constexpr int kFinThreads = 256;
 constexpr int kCkptStride = cwslg::kCk;   // blocks between phasor checkpoints

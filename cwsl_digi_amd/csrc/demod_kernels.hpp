@@ -48,6 +48,14 @@ __device__ __forceinline__ const CWSLG_GLOBAL T *as_global(const T *p)
 {
     return (const CWSLG_GLOBAL T *)(uintptr_t)p;
 }
+// Constant address space: a uniform load through it is always a scalar load (s_load), whatever stores the kernel makes elsewhere.
+// Only for memory no kernel writes (the tap tables).
+#define CWSLG_CONST __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const CWSLG_CONST T *as_const(const T *p)
+{
+    return (const CWSLG_CONST T *)(uintptr_t)p;
+}
 template <typename T>
 __device__ __forceinline__ CWSLG_GLOBAL T *as_global_rw(T *p)
 {
@@ -208,7 +216,10 @@ __device__ __forceinline__ int reduce_lanes(float (&acc)[16], int k)
 // when it cannot raise the maximum -- costs more than it saves, 2.85 ms: the load's round trip lands on the workgroup's tail.)
 __device__ __forceinline__ void publish_peak(unsigned *peak, float mx)
 {
-    if (mx > 0.0f) atomicMax(peak, __float_as_uint(mx));
+    // through the GLOBAL address space: a generic-pointer atomic is a FLAT instruction, which is counted in lgkmcnt as well as vmcnt
+    // and so stalls the next LDS wait for an HBM round trip
+    if (mx > 0.0f)
+        __hip_atomic_fetch_max((CWSLG_GLOBAL unsigned *)(uintptr_t)peak, __float_as_uint(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -963,8 +974,11 @@ __global__ __launch_bounds__(NT, 2) void demod_exact2_kernel(const ChanWork *__r
                                                           // stride 2 (D + 2) dwords = 36 (mod 64) for D = 16: the 16 lanes of a b128 group hit 16
                                                           // distinct 16-byte slots
     static_assert(2 * NT >= T && T % 4 == 0 && D % 4 == 0, "two outputs per thread");
+    // row b >> 1 of array b & 1 = block b: its D mixed samples, then (slot D) the mixer phase of the block -- the pad that makes the
+    // pitch even carries the one other per-block value the FIR step reads, so there is no separate phase array and a 248-output
+    // tile fits four to a CU
     __shared__ __attribute__((aligned(16))) float2 s_t[2][NBH * BP];
-    __shared__ float2 s_phase[Geo::NBLK + 4];             // the pipeline reads (never uses) two blocks past the tile
+    static_assert(sizeof(float2) * 2 * NBH * BP <= 40960, "four tiles per CU");
 
     const int total = (tiles_x < 0 ? -tiles_x : tiles_x) * n_ch;
     const int per_xcd = (total + 7) >> 3;
@@ -997,7 +1011,7 @@ __global__ __launch_bounds__(NT, 2) void demod_exact2_kernel(const ChanWork *__r
 #pragma unroll
                 for (int s = 0; s < kCk; ++s) {
                     const int pb = pbase + s;
-                    if (pb >= 0 && pb < Geo::NBLK) s_phase[pb] = p;
+                    if (pb >= 0 && pb < Geo::NBLK) s_t[pb & 1][(pb >> 1) * BP + D] = p;
                     p = cmul_exact(p, cur.inc);
                 }
             }
@@ -1038,7 +1052,7 @@ __global__ __launch_bounds__(NT, 2) void demod_exact2_kernel(const ChanWork *__r
                 t[m] = v2f{q.x, q.y};
                 t[m + 1] = v2f{q.z, q.w};
             }
-            ph = *reinterpret_cast<const v2f *>(&s_phase[o0 + n]);
+            ph = *reinterpret_cast<const v2f *>(&s_t[n & 1][(tid + (n >> 1)) * BP + D]);
         };
         auto load_taps = [&](int n, v4f (&h)[D / 4]) {
 #pragma unroll
