@@ -654,6 +654,10 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s,
         fin.push_back(f);
         max_len = std::max(max_len, ch.frame_len);
     }
+    if (c->cand_pending && (c->sync_variant & 32)) {     // the previous boundary's sync chain (side stream) reads the int16 frames
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->cand_done, 0));
+        c->cand_pending = false;
+    }
     WorkBuf *w = acquire_workbuf(c, fin.size() * sizeof(FinWork));
     if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
     std::memcpy(w->h, fin.data(), fin.size() * sizeof(FinWork));

@@ -951,14 +951,15 @@ __global__ __launch_bounds__(NT) void demod_exact_kernel(const ChanWork *__restr
 // its counters (LDS array 86 % busy, 16 waves per CU, 7.7 ms per 512 slots = 19.7 % of HBM peak):
 //   * one thread computes TWO adjacent outputs o, o + 1.  Their 32-block windows share 31 blocks, so each block's 16 mixed
 //     samples are read from LDS once and used twice (tap block n for o, n - 1 for o + 1): half the LDS reads per output;
-//   * even and odd blocks live in separate LDS arrays of pitch D + 1: lane l reads block 2 l + n, i.e. entry l + n/2 of the
-//     array of parity n & 1 -- lane stride D + 1 complex (odd): conflict-free ds_read_b64;
+//   * even and odd blocks live in separate LDS arrays of pitch D + 2 (a row = the block's D mixed samples, then its mixer phase in
+//     the pad slot): lane l reads block 2 l + n, i.e. row l + n/2 of the array of parity n & 1, as ds_read_b128 whose 16-lane groups hit
+//     16 distinct 16-byte slots;
 //   * the 16 taps of a block are fetched by VECTOR loads from a lane-invariant address (L1 broadcast) one step ahead: they are
 //     counted in vmcnt, so waiting for them does not drain the LDS reads in flight the way scalar loads (lgkmcnt) did in the
 //     round-1 attempt at this layout.
-// Tile = 232 outputs on 128 threads (116 active): 39.5 KB of LDS, so FOUR tiles = 8 waves fit a CU -- two waves per SIMD, which the VALU needs
-// to issue every 2 cycles (a lone wave issues every 4); with 256-output tiles (41.7 KB, 3 per CU) this kernel ran no faster than
-// the one-output form.
+// Tile = 248 outputs on 128 threads (124 active): 39.7 KB of LDS, so FOUR tiles = 8 waves fit a CU -- two waves per SIMD; with
+// 256-output tiles (41.7 KB, 3 per CU) this kernel ran no faster than the one-output form.  A persistent form with register prefetch
+// of the next tile was measured no faster.
 // The un-fused order needs 150 VALU lane-operations per input sample against demod_kernel's 44, so its ceiling is ~40 % of the
 // HBM roofline at full VALU rate; this is the mode whose int16 frames -- and therefore candidate lists -- equal the reference
 // chain's bit for bit (tests/test_gpu_exact.py, tests/test_gpu_e2e_candidates.py).
