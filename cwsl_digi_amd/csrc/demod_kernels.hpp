@@ -35,6 +35,7 @@
 // This translation unit is compiled with -ffp-contract=off; every fused multiply-add below is an
 // explicit __builtin_fmaf, every bit-exact sequence is plain * and +/-.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -347,13 +348,24 @@ __device__ __forceinline__ void issue_tile_loads(const TileCtx<D, T> &c, int tid
     using Geo = DemodGeom<D, T>;
     constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
     const CWSLG_GLOBAL v4f *ring4 = as_global(reinterpret_cast<const v4f *>(c.ring));
+    if (c.base + (unsigned)Geo::NSAMP <= c.cap) {
+        // the tile does not cross the end of the ring (all but one tile per ring revolution): one uniform base, lane offset
+        // tid, no per-load wrap arithmetic (it was 6 VALU instructions per load)
+        const CWSLG_GLOBAL v4f *p = ring4 + (c.base >> 1);
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        int r = 2 * tid + it * 2 * NT;
+        for (int it = 0; it < NIT - 1; ++it) xs[it] = p[tid + it * NT];
+        int r = 2 * tid + (NIT - 1) * 2 * NT;
         if (r > Geo::NSAMP - 2) r = Geo::NSAMP - 2;            // clamp: the load is unconditional
-        unsigned idx = c.base + (unsigned)r;
-        if (idx >= c.cap) idx -= c.cap;
-        xs[it] = ring4[idx >> 1];
+        xs[NIT - 1] = p[r >> 1];
+    } else {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int r = 2 * tid + it * 2 * NT;
+            if (r > Geo::NSAMP - 2) r = Geo::NSAMP - 2;
+            unsigned idx = c.base + (unsigned)r;
+            if (idx >= c.cap) idx -= c.cap;
+            xs[it] = ring4[idx >> 1];
+        }
     }
     // unconditional (clamped) checkpoint load: a predicated load would be merged with a default right away,
     // and that copy makes hipcc wait for every load issued so far
@@ -498,32 +510,39 @@ __global__ __launch_bounds__(NT, 4) void demod_kernel(const ChanWork *__restrict
             const float2 tn0 = make_float2(tn.x, tn.y), tn1 = make_float2(tn.z, tn.w);
             if (has_next) tn = as_global(reinterpret_cast<const v4f *>(nxt.tone))[((2 * tid) % D) >> 1];
             const int fv = cur.first_valid;
+            // two copies of the loop behind ONE scalar branch: with the origin test inside a single loop hipcc if-converts it, and
+            // its four moves and the compare are then issued (under an empty exec mask) for every load of every tile
+            auto mix = [&](auto slow_tag) {
+                constexpr bool SLOW = decltype(slow_tag)::value;
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int r = 2 * tid + it * 2 * NT;
-                const v4f x = xs[it];
-                if (has_next) {                                  // in-place prefetch: xs[it] is free from here on
-                    int rn = (r > Geo::NSAMP - 2) ? Geo::NSAMP - 2 : r;
-                    unsigned idx = nxt.base + (unsigned)rn;
-                    if (idx >= nxt.cap) idx -= nxt.cap;
-                    xs[it] = nring4[idx >> 1];
+                for (int it = 0; it < NIT; ++it) {
+                    const int r = 2 * tid + it * 2 * NT;
+                    const v4f x = xs[it];
+                    if (has_next) {                                  // in-place prefetch: xs[it] is free from here on
+                        int rn = (r > Geo::NSAMP - 2) ? Geo::NSAMP - 2 : r;
+                        unsigned idx = nxt.base + (unsigned)rn;
+                        if (idx >= nxt.cap) idx -= nxt.cap;
+                        xs[it] = nring4[idx >> 1];
+                    }
+                    float ar = __builtin_fmaf(x.x, tn0.x, -(x.y * tn0.y));
+                    float ai = __builtin_fmaf(x.x, tn0.y, x.y * tn0.x);
+                    float y0r = __builtin_fmaf(ar, ph[it].x, -(ai * ph[it].y));
+                    float y0i = __builtin_fmaf(ar, ph[it].y, ai * ph[it].x);
+                    ar = __builtin_fmaf(x.z, tn1.x, -(x.w * tn1.y));
+                    ai = __builtin_fmaf(x.z, tn1.y, x.w * tn1.x);
+                    float y1r = __builtin_fmaf(ar, ph[it].x, -(ai * ph[it].y));
+                    float y1i = __builtin_fmaf(ar, ph[it].y, ai * ph[it].x);
+                    if (SLOW) {                                      // only the first tiles of a slot
+                        if (r < fv) { y0r = 0.f; y0i = 0.f; y1r = 0.f; y1i = 0.f; }
+                    }
+                    const bool in0 = (it < NIT - 1) || (r < G * (T / 2 + 15));          // plane 0 drops the last D samples
+                    const bool in1 = (it > 0) ? ((it < NIT - 1) || (r < Geo::NSAMP)) : (r >= D);   // plane 1 drops the first D
+                    if (in0) *reinterpret_cast<float2 *>(p0 + 2 * it * WSTEP) = make_float2(y0r, y1r);
+                    if (in1) *reinterpret_cast<float2 *>(p1 + 2 * it * WSTEP) = make_float2(y0i, y1i);
                 }
-                float ar = __builtin_fmaf(x.x, tn0.x, -(x.y * tn0.y));
-                float ai = __builtin_fmaf(x.x, tn0.y, x.y * tn0.x);
-                float y0r = __builtin_fmaf(ar, ph[it].x, -(ai * ph[it].y));
-                float y0i = __builtin_fmaf(ar, ph[it].y, ai * ph[it].x);
-                ar = __builtin_fmaf(x.z, tn1.x, -(x.w * tn1.y));
-                ai = __builtin_fmaf(x.z, tn1.y, x.w * tn1.x);
-                float y1r = __builtin_fmaf(ar, ph[it].x, -(ai * ph[it].y));
-                float y1i = __builtin_fmaf(ar, ph[it].y, ai * ph[it].x);
-                if (fv != 0) {                                   // wave-uniform: only the first tiles of a slot
-                    if (r < fv) { y0r = 0.f; y0i = 0.f; y1r = 0.f; y1i = 0.f; }
-                }
-                const bool in0 = (it < NIT - 1) || (r < G * (T / 2 + 15));          // plane 0 drops the last D samples
-                const bool in1 = (it > 0) ? ((it < NIT - 1) || (r < Geo::NSAMP)) : (r >= D);   // plane 1 drops the first D
-                if (in0) *reinterpret_cast<float2 *>(p0 + 2 * it * WSTEP) = make_float2(y0r, y1r);
-                if (in1) *reinterpret_cast<float2 *>(p1 + 2 * it * WSTEP) = make_float2(y0i, y1i);
-            }
+            };
+            if (fv != 0) mix(std::true_type{});
+            else mix(std::false_type{});
         }
         lds_barrier();
         STAMP(4);
