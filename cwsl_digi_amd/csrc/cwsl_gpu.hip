@@ -166,7 +166,8 @@ struct cwslg_ctx {
     int demod_variant = 0;             // CWSLG_DEMOD_VARIANT: 0 = one workgroup per tile (default); measured alternatives: 1 persistent +
                                        // prefetch, 2 persistent loop, 4..7 FIR on the matrix cores (192 kHz); 9..11 memory-traffic probe
     hipStream_t stream = nullptr;
-    std::string last_error;
+    std::string last_error;            // guarded by err_mu: fail() is also reached from code that does not hold `mu` (the staging copy of a push)
+    std::mutex err_mu;
     float scale_ft = 0.90f, scale_wspr = 0.20f;    // CWSL_DIGI.cpp:100-101
     std::vector<Receiver> rxs;
     std::vector<Channel> chans;
@@ -219,7 +220,10 @@ int fail(cwslg_ctx *c, int code, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (c) c->last_error = buf;
+    if (c) {
+        std::lock_guard<std::mutex> g(c->err_mu);
+        c->last_error = buf;
+    }
     return code;
 }
 
@@ -718,7 +722,15 @@ const char *cwslg_strerror(int s)
     }
 }
 
-const char *cwslg_last_error(cwslg_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+const char *cwslg_last_error(cwslg_ctx *ctx)
+{
+    if (!ctx) return "";
+    // a per-thread copy: the returned pointer stays valid until this thread asks again, whatever other threads report meanwhile
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> g(ctx->err_mu);
+    copy = ctx->last_error;
+    return copy.c_str();
+}
 
 int cwslg_create(cwslg_ctx **out, int device_ordinal)
 {

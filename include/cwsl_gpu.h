@@ -71,7 +71,8 @@ int  cwslg_abi_version(void);
 int  cwslg_create(cwslg_ctx **out, int device_ordinal);
 void cwslg_destroy(cwslg_ctx *ctx);
 const char *cwslg_strerror(int status);
-/* Text of the last failure on this context (HIP error string included). */
+/* Text of the last failure on this context (HIP error string included).  Safe from any thread; the pointer is to a per-thread copy,
+ * valid until the same thread calls this function again. */
 const char *cwslg_last_error(cwslg_ctx *ctx);
 /* wsjtx.ftaudioscalefactor / wsjtx.wspraudioscalefactor (CWSL_DIGI.cpp:100-101; defaults 0.90 / 0.20) */
 int  cwslg_set_scale_factors(cwslg_ctx *ctx, float scale_ft, float scale_wspr);
