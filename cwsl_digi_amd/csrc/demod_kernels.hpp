@@ -43,6 +43,10 @@ namespace cwslg {
 
 // Pointers fetched from a descriptor in memory are generic to the compiler (flat_load); these are
 // known to be HBM addresses, so say so and get global_load / global_store.
+// -DCWSLG_FIR_PK=1: the FIR of demod_kernel on v_pk_fma_f32 (half the issue slots, same FLOPs; measured alternative, see phase 2)
+#ifndef CWSLG_FIR_PK
+#define CWSLG_FIR_PK 0
+#endif
 #define CWSLG_GLOBAL __attribute__((address_space(1)))
 template <typename T>
 __device__ __forceinline__ const CWSLG_GLOBAL T *as_global(const T *p)
@@ -557,6 +561,34 @@ __global__ __launch_bounds__(NT, 4) void demod_kernel(const ChanWork *__restrict
                 const float4 *src = reinterpret_cast<const float4 *>(
                     s_plane + pl * Geo::PLANE_FLOATS + k * PR + 2 * 16 * chunk);
                 float acc[16];
+#if CWSLG_FIR_PK
+                // The lane's two branches accumulate side by side in ONE register pair per output: (x_even, x_odd) is an aligned
+                // pair of the float4 read from LDS, (h_even, h_odd) an aligned pair of tap registers, so the two FMAs are one
+                // v_pk_fma_f32: 256 instead of 512 FMA instructions per wave and tile, same VGPR count.  Measured (same box, 512 / 4096
+                // slots): 2.558-2.565 against 2.563-2.573 ms, 20.51-20.63 against 20.64-20.68 ms per launch -- within noise.  Neither
+                // the issue slots nor (section 10 of DESIGN.md) the instruction count bound this kernel; the FLOPs and bytes, which
+                // set its power, do.  Off by default because it changes the summation order (evens + odds) for no gain.
+                v2f acc2[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[r] = v2f{0.0f, 0.0f};
+                const v4f *src4 = reinterpret_cast<const v4f *>(src);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const v4f c4 = src4[q];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int j = 2 * q + h;
+                        const v2f x2 = h ? v2f{c4.z, c4.w} : v2f{c4.x, c4.y};
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) {
+                            const int r = j - v;
+                            if (r >= 0 && r < 16) acc2[r] = __builtin_elementwise_fma(x2, v2f{tap[v].x, tap[v].y}, acc2[r]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = acc2[r].x + acc2[r].y;
+#else
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
                 // column j = w - 16*chunk (0..30) feeds acc[j - v], v = 0..15; one float4 = columns 2q, 2q+1 x both branches
@@ -577,6 +609,7 @@ __global__ __launch_bounds__(NT, 4) void demod_kernel(const ChanWork *__restrict
                         }
                     }
                 }
+#endif
                 const int rbase = reduce_lanes<GL>(acc, k);
                 constexpr int NV = 16 / GL;
 #pragma unroll
