@@ -112,7 +112,7 @@ _lib = None
 ABI_SYMBOLS = [
     "cwslg_abi_version", "cwslg_create", "cwslg_destroy", "cwslg_strerror", "cwslg_last_error",
     "cwslg_set_scale_factors", "cwslg_set_exact", "cwslg_receiver_open", "cwslg_receiver_close", "cwslg_push_iq",
-    "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_parse_decoder_line", "cwslg_channel_open_line", "cwslg_channel_open", "cwslg_channel_close", "cwslg_channel_tune",
+    "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_parse_decoder_line", "cwslg_channel_open_line", "cwslg_channel_open", "cwslg_channel_close", "cwslg_channel_tune", "cwslg_channel_tune_ex",
     "cwslg_channel_info", "cwslg_process", "cwslg_slot_boundary", "cwslg_slot_boundary_channel",
     "cwslg_set_boundary_rendezvous", "cwslg_rccl_unique_id", "cwslg_rccl_init",
     "cwslg_enable_long_sync", "cwslg_fetch_wspr_candidates", "cwslg_fetch_fst4w_candidates", "cwslg_long_sync_debug_fetch",
@@ -178,6 +178,7 @@ def load_library(build_if_missing=True):
     L.cwslg_channel_open.argtypes = [vp, i32, C.c_int32, i32, C.c_char_p, C.POINTER(i32)]
     L.cwslg_channel_close.argtypes = [vp, i32]
     L.cwslg_channel_tune.argtypes = [vp, i32, C.c_int32, i32]
+    L.cwslg_channel_tune_ex.argtypes = [vp, i32, C.c_int32, i32, i32]
     L.cwslg_channel_info.argtypes = [vp, i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_size_t)]
     L.cwslg_process.argtypes = [vp]
     L.cwslg_slot_boundary.argtypes = [vp, i32, u64]
@@ -369,9 +370,10 @@ class Context:
         self._chk(self.L.cwslg_channel_close(self.h, ch))
         self._modes.pop(ch, None)
 
-    def channel_tune(self, ch, demod_hz, usb=True):
-        """SSBD::Tune(F, isUSB): retune in place, history and phasor restart (SSBD.hpp:96-123)."""
-        self._chk(self.L.cwslg_channel_tune(self.h, ch, int(demod_hz), 1 if usb else 0))
+    def channel_tune(self, ch, demod_hz, usb=True, reset=True):
+        """SSBD::Tune(F, isUSB, reset): retune in place; reset=True restarts history and phasor, reset=False keeps them
+        (SSBD.hpp:96-123)."""
+        self._chk(self.L.cwslg_channel_tune_ex(self.h, ch, int(demod_hz), 1 if usb else 0, 1 if reset else 0))
 
     def channel_info(self, ch):
         a, b, c_, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()

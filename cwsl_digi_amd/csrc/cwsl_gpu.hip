@@ -78,6 +78,7 @@ struct PhasorTable {
     int refs = 0;
     bool built = false;
     float2 inc{};
+    float2 start = make_float2(1.0f, 0.0f);     // checkpoint 0 (SSBD.hpp:121); the live phase for a table made by Tune(reset = false)
 };
 
 struct LongConfig {
@@ -120,12 +121,24 @@ struct Channel {
     float2 *d_tone = nullptr;
     // constants
     DemodConstants k;
+    // The tuning the channel was opened with.  Instance re-creates its SSBD from its OWN demodFreq / USB after every emitted frame
+    // (Instance.cpp:251), so a Tune() on the live object lasts until then.
+    DemodConstants k_open;
+    int32_t open_demod_hz = 0;
+    bool open_usb = true;
     std::tuple<uint32_t, int32_t, int, size_t> phasor_key;
     // Instance state (Instance.cpp:203-276)
     uint64_t fill[2] = {0, 0};
     uint64_t t0[2] = {0, 0};
     int wr = 0, rd = 0;
     int64_t origin_abs = 0;            // receiver sample index at which the demodulator was created
+    // SSBD::Tune(F, isUSB, reset = false): the phasor continues from its live value, so the channel walks a PRIVATE checkpoint
+    // table (start = that value) until its demodulator is next re-created; and the 32 outputs after the retune point are made by
+    // demod_transition_kernel from history mixed with the old tuning (parameters kept by value in `trans`).
+    bool use_priv = false;
+    PhasorTable priv;
+    bool trans_active = false;
+    std::shared_ptr<TransWork> trans;  // template of the transition work (tones, phases, sign); positions are filled per launch
     int64_t pend_lo = 0;               // first not-yet-demodulated sample
     uint32_t pend_n = 0;               // samples accepted but not yet demodulated
     uint64_t pend_fill0 = 0;           // frame fill at pend_lo
@@ -325,21 +338,8 @@ int ensure_taps(cwslg_ctx *c, uint32_t fs)
     return CWSLG_OK;
 }
 
-int build_pending_phasors(cwslg_ctx *c)
+int launch_phasor_jobs(cwslg_ctx *c, const std::vector<PhasorJob> &jobs)
 {
-    if (c->phasor_todo.empty()) return CWSLG_OK;
-    std::vector<PhasorJob> jobs;
-    for (auto &key : c->phasor_todo) {
-        auto it = c->phasors.find(key);
-        if (it == c->phasors.end() || it->second.built) continue;
-        PhasorJob j{};
-        j.ckpt = it->second.d_ckpt;
-        j.inc = it->second.inc;
-        j.n_ckpt = (unsigned)it->second.n_ckpt;
-        jobs.push_back(j);
-        it->second.built = true;
-    }
-    c->phasor_todo.clear();
     if (jobs.empty()) return CWSLG_OK;
     WorkBuf *w = acquire_workbuf(c, jobs.size() * sizeof(PhasorJob));
     if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
@@ -354,6 +354,70 @@ int build_pending_phasors(cwslg_ctx *c)
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(w->done, c->stream));
     w->in_flight = true;
+    return CWSLG_OK;
+}
+
+int build_pending_phasors(cwslg_ctx *c)
+{
+    if (c->phasor_todo.empty()) return CWSLG_OK;
+    std::vector<PhasorJob> jobs;
+    for (auto &key : c->phasor_todo) {
+        auto it = c->phasors.find(key);
+        if (it == c->phasors.end() || it->second.built) continue;
+        PhasorJob j{};
+        j.ckpt = it->second.d_ckpt;
+        j.inc = it->second.inc;
+        j.start = it->second.start;
+        j.n_ckpt = (unsigned)it->second.n_ckpt;
+        jobs.push_back(j);
+        it->second.built = true;
+    }
+    c->phasor_todo.clear();
+    return launch_phasor_jobs(c, jobs);
+}
+
+// The channel's private checkpoint table (Tune with reset = false): n_ckpt entries from `start` with step `inc`, (re)built on the
+// context stream.  Caller holds the mutex; a table that may be in use by a queued launch is only replaced after a stream wait.
+int build_private_phasor(cwslg_ctx *c, Channel &ch, size_t n_ckpt, float2 start, float2 inc)
+{
+    PhasorTable &pt = ch.priv;
+    if (pt.d_ckpt && pt.n_ckpt != n_ckpt) {
+        HIPCHK(c, sync_streams(c));
+        (void)hipFree(pt.d_ckpt);
+        pt.d_ckpt = nullptr;
+    }
+    if (!pt.d_ckpt && hipMalloc(&pt.d_ckpt, n_ckpt * sizeof(float2)) != hipSuccess) {
+        pt.d_ckpt = nullptr;
+        return fail(c, CWSLG_ERR_NOMEM, "phasor table allocation failed");
+    }
+    pt.n_ckpt = n_ckpt; pt.start = start; pt.inc = inc; pt.built = true; pt.refs = 1;
+    PhasorJob j{};
+    j.ckpt = pt.d_ckpt; j.inc = inc; j.start = start; j.n_ckpt = (unsigned)n_ckpt;
+    return launch_phasor_jobs(c, std::vector<PhasorJob>{j});
+}
+
+void drop_private_phasor(Channel &ch)       // the demodulator is re-created: back to the shared table of its tuning
+{
+    ch.use_priv = false;
+    ch.trans_active = false;
+}
+
+int retarget_phasor(cwslg_ctx *c, Channel &ch, const std::tuple<uint32_t, int32_t, int, size_t> &new_key, float2 inc);
+
+// Instance.cpp:251: the new SSBD is constructed from the Instance's own demodFreq and USB, so a channel retuned by Tune() goes
+// back to the tuning it was opened with.  Only a retuned channel pays the stream wait (its retuned table may be in use).
+int restore_open_tuning(cwslg_ctx *c, Channel &ch, const Receiver &rx)
+{
+    if (ch.demod_hz == ch.open_demod_hz && ch.usb == ch.open_usb) return CWSLG_OK;
+    HIPCHK(c, sync_streams(c));
+    const auto key = std::make_tuple(rx.fs, ch.open_demod_hz, ch.open_usb ? 1 : 0, std::get<3>(ch.phasor_key));
+    int rc = retarget_phasor(c, ch, key, make_float2(ch.k_open.inc.real(), ch.k_open.inc.imag()));
+    if (rc) return rc;
+    ch.k = ch.k_open;
+    ch.demod_hz = ch.open_demod_hz;
+    ch.usb = ch.open_usb;
+    HIPCHK(c, hipMemcpyAsync(ch.d_tone, ch.k.tone.data(), ch.k.block * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, sync_streams(c));             // (the source is this channel's own storage; keep it simple on this rare path)
     return CWSLG_OK;
 }
 
@@ -481,6 +545,14 @@ int process_locked(cwslg_ctx *c)
             Channel &ch = c->chans[id];
             if (!ch.open || ch.pend_n == 0) continue;
             const size_t need = ckpt_need((ch.pend_lo - ch.origin_abs) / (int64_t)rx.D, ch.pend_n / rx.D);
+            if (ch.use_priv) {
+                if (need > ch.priv.n_ckpt) {
+                    rc = build_private_phasor(c, ch, std::max(need, 2 * ch.priv.n_ckpt), ch.priv.start, ch.priv.inc);
+                    if (rc) return rc;
+                    c->stats.phasor_regrows++;
+                }
+                continue;
+            }
             const size_t have = std::get<3>(ch.phasor_key);
             if (need <= have) continue;
             HIPCHK(c, sync_streams(c));             // the old table may be in use by a queued launch
@@ -501,6 +573,7 @@ int process_locked(cwslg_ctx *c)
         }
     // one launch per distinct sample rate; channels grouped by receiver so that a receiver's channels are neighbours
     std::map<uint32_t, std::vector<ChanWork>> by_fs;
+    std::map<uint32_t, std::vector<TransWork>> trans_by_fs;
     std::map<uint32_t, unsigned> max_blocks;
     std::map<uint32_t, unsigned> max_share;            // most channels with pending work on one receiver
     for (size_t r = 0; r < c->rxs.size(); ++r) {
@@ -510,12 +583,36 @@ int process_locked(cwslg_ctx *c)
         for (int id : rx.channels) {
             Channel &ch = c->chans[id];
             if (!ch.open || ch.pend_n == 0) continue;
+            if (ch.trans_active) {
+                // the 32 outputs after a Tune(reset = false): history mixed with the old tuning (origin_abs is the retune point)
+                const int64_t rel = (ch.pend_lo - ch.origin_abs) / (int64_t)rx.D;
+                if (rel < 32) {
+                    const uint32_t t_n = (uint32_t)std::min<int64_t>(ch.pend_n / rx.D, 32 - rel);
+                    TransWork t = *ch.trans;
+                    t.ring = rx.d_ring;
+                    t.ring_cap = rx.cap;
+                    t.pos_b0 = (unsigned)((uint64_t)ch.origin_abs % rx.cap);
+                    t.out = ch.d_frame[ch.wr] + ch.pend_fill0;
+                    t.peak = ch.d_peak + ch.wr;
+                    t.o_first = (int)rel;
+                    t.n_out = (int)t_n;
+                    trans_by_fs[rx.fs].push_back(t);
+                    c->stats.demod_samples += (uint64_t)t_n * rx.D;
+                    ch.pend_lo += (int64_t)t_n * rx.D;
+                    ch.pend_fill0 += t_n;
+                    ch.pend_n -= t_n * rx.D;
+                    if (rel + t_n >= 32) { ch.trans_active = false; ch.trans.reset(); }
+                } else {
+                    ch.trans_active = false; ch.trans.reset();
+                }
+                if (ch.pend_n == 0) continue;
+            }
             ++share;
             ChanWork w{};
             w.ring = rx.d_ring;
             w.out = ch.d_frame[ch.wr] + ch.pend_fill0;
             w.peak = ch.d_peak + ch.wr;
-            w.ckpt = c->phasors[ch.phasor_key].d_ckpt;
+            w.ckpt = ch.use_priv ? ch.priv.d_ckpt : c->phasors[ch.phasor_key].d_ckpt;
             w.tone = ch.d_tone;
             w.ring_cap = rx.cap;
             w.n_blocks = ch.pend_n / rx.D;
@@ -543,7 +640,24 @@ int process_locked(cwslg_ctx *c)
         else rc = fail(c, CWSLG_ERR_UNSUPPORTED, "sample rate %u unsupported", fs);
         if (rc) return rc;
     }
-    if (!by_fs.empty()) HIPCHK(c, hipEventRecord(c->demod_done, c->stream));
+    for (auto &kv : trans_by_fs) {
+        const uint32_t fs = kv.first;
+        const uint32_t D = fs / kWaveSR;
+        WorkBuf *w = acquire_workbuf(c, kv.second.size() * sizeof(TransWork));
+        if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
+        std::memcpy(w->h, kv.second.data(), kv.second.size() * sizeof(TransWork));
+        HIPCHK(c, hipMemcpyAsync(w->d, w->h, kv.second.size() * sizeof(TransWork), hipMemcpyHostToDevice, c->stream));
+        const dim3 grid((unsigned)kv.second.size());
+        const float *taps = (const float *)c->d_taps[fs];
+        if (D == 16) hipLaunchKernelGGL(demod_transition_kernel<16>, grid, dim3(64), 0, c->stream, (const TransWork *)w->d, taps);
+        else if (D == 8) hipLaunchKernelGGL(demod_transition_kernel<8>, grid, dim3(64), 0, c->stream, (const TransWork *)w->d, taps);
+        else if (D == 4) hipLaunchKernelGGL(demod_transition_kernel<4>, grid, dim3(64), 0, c->stream, (const TransWork *)w->d, taps);
+        else return fail(c, CWSLG_ERR_UNSUPPORTED, "sample rate %u unsupported", fs);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(w->done, c->stream));
+        w->in_flight = true;
+    }
+    if (!by_fs.empty() || !trans_by_fs.empty()) HIPCHK(c, hipEventRecord(c->demod_done, c->stream));
     return CWSLG_OK;
 }
 
@@ -648,7 +762,9 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s,
             ch.frame_idx = cur;
             ch.frame_t0 = ch.t0[cur];
             ch.frame_valid = ch.fill[cur];
-            ch.origin_abs = (int64_t)rx.total;          // :251 new SSBD: history and phasor restart
+            ch.origin_abs = (int64_t)rx.total;          // :251 new SSBD: history and phasor restart, the Instance's own tuning
+            drop_private_phasor(ch);
+            if ((rc = restore_open_tuning(c, ch, rx)) != CWSLG_OK) return rc;
             c->stats.frames_emitted++;
             emitted.push_back(id);
         } else {
@@ -882,6 +998,7 @@ int cwslg_receiver_close(cwslg_ctx *c, int rx_id)
         if (ch.longbuf.d_block) { (void)hipFree(ch.longbuf.d_block); ch.longbuf = LongChannelBuffers(); }
         auto it = c->phasors.find(ch.phasor_key);
         if (it != c->phasors.end() && --it->second.refs == 0) { hipFree(it->second.d_ckpt); c->phasors.erase(it); }
+        if (ch.priv.d_ckpt) (void)hipFree(ch.priv.d_ckpt);
         ch = Channel();
     }
     hipFree(rx.d_ring);
@@ -1115,6 +1232,7 @@ int cwslg_channel_open(cwslg_ctx *c, int rx_id, int32_t demod_hz, int usb, const
     ch.sync_fst4w = (ch.mode == "FST4W-120");
     ch.frame_len = frame_length(*mi);
     ch.k = make_constants(rx.fs, kSsbBw, f_hz, usb != 0);
+    ch.k_open = ch.k; ch.open_demod_hz = demod_hz; ch.open_usb = usb != 0;
     // one device allocation: 2 float frames | int16 frame | peaks | factor | tone
     const size_t fbytes = (ch.frame_len * sizeof(float) + 255) & ~size_t(255);
     const size_t ibytes = (ch.frame_len * sizeof(int16_t) + 255) & ~size_t(255);
@@ -1269,6 +1387,7 @@ int cwslg_channel_close(cwslg_ctx *c, int ch_id)
         if (ch.longbuf.d_block) { (void)hipFree(ch.longbuf.d_block); ch.longbuf = LongChannelBuffers(); }
     auto it = c->phasors.find(ch.phasor_key);
     if (it != c->phasors.end() && --it->second.refs == 0) { hipFree(it->second.d_ckpt); c->phasors.erase(it); }
+    if (ch.priv.d_ckpt) (void)hipFree(ch.priv.d_ckpt);
     ch = Channel();
     return CWSLG_OK;
 }
@@ -1298,6 +1417,85 @@ int cwslg_channel_tune(cwslg_ctx *c, int ch_id, int32_t demod_hz, int usb)
     HIPCHK(c, sync_streams(c));
     ch.origin_abs = (int64_t)rx.total;                                          // workspace zeroed, phase (1,0): history restarts here
     ch.pend_lo = ch.origin_abs;
+    drop_private_phasor(ch);
+    return CWSLG_OK;
+}
+
+// SSBD::Tune(F, isUSB, reset) (SSBD.hpp:97-123).  reset = 0 skips :116-121: workspace, index and phase survive, i.e. the FIR
+// history stays as it was mixed (old tone, old phasor sequence) and the phasor continues from its live value with the new step.
+// Here: everything pushed so far is demodulated with the old tuning; the live phase is read back from the channel's checkpoint
+// table (the retune point is a multiple of 4 blocks from the origin, hence a checkpoint); the channel gets a private table that
+// starts at that value and a new origin at the retune point; and the next 32 outputs -- the only ones whose windows straddle the
+// two tunings -- are made by demod_transition_kernel.
+int cwslg_channel_tune_ex(cwslg_ctx *c, int ch_id, int32_t demod_hz, int usb, int reset)
+{
+    if (reset) return cwslg_channel_tune(c, ch_id, demod_hz, usb);
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
+    hipSetDevice(c->device);
+    Channel &ch = c->chans[ch_id];
+    Receiver &rx = c->rxs[ch.rx];
+    const double f_hz = (double)(float)demod_hz;
+    int rc = check_tuning(rx.fs, kSsbBw, f_hz, usb != 0);
+    if (rc) return fail(c, rc, "%s", cwslg_strerror(rc));
+    if ((rc = process_locked(c)) != CWSLG_OK) return rc;                        // everything already pushed: old tuning
+    if (ch.trans_active)
+        return fail(c, CWSLG_ERR_UNSUPPORTED, "a second Tune(reset = false) within 32 blocks of the previous one is not supported");
+    const int64_t b0_abs = (int64_t)rx.total;
+    const int64_t q0 = (b0_abs - ch.origin_abs) / (int64_t)rx.D;               // blocks since the origin: a multiple of 4
+    if (q0 % kCkptStride != 0) return fail(c, CWSLG_ERR_BLOCK, "retune point is not a multiple of %d blocks from the origin", kCkptStride);
+    // the live phase and the phases of the last 32 blocks, from the checkpoints q0/4 - 8 .. q0/4 of the table in use
+    if ((rc = build_pending_phasors(c)) != CWSLG_OK) return rc;
+    const PhasorTable &cur = ch.use_priv ? ch.priv : c->phasors[ch.phasor_key];
+    const int64_t c_hi = q0 / kCkptStride, c_lo = std::max<int64_t>(0, c_hi - 8);
+    if ((size_t)c_hi >= cur.n_ckpt) return fail(c, CWSLG_ERR_ARG, "checkpoint table shorter than the stream");
+    float2 ck[9];
+    HIPCHK(c, hipMemcpyAsync(ck, cur.d_ckpt + c_lo, (size_t)(c_hi - c_lo + 1) * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, sync_streams(c));
+    auto cmul = [](float2 a, float2 b) {                                        // cmul_exact on the host (this TU is built -ffp-contract=off)
+        const float ac = a.x * b.x, bd = a.y * b.y, ad = a.x * b.y, bc = a.y * b.x;
+        return make_float2(ac - bd, ad + bc);
+    };
+    const DemodConstants k_old = ch.k;
+    const float2 inc_old = make_float2(k_old.inc.real(), k_old.inc.imag());
+    auto t = std::make_shared<TransWork>();
+    std::memset(t.get(), 0, sizeof(TransWork));
+    t->blocks_before = (int)std::min<int64_t>(32, q0);
+    for (int j = 1; j <= t->blocks_before; ++j) {                               // block q0 - j: from its checkpoint, like the kernels do
+        const int64_t q = q0 - j, cq = q / kCkptStride;
+        float2 p = ck[cq - c_lo];
+        for (int64_t sft = cq * kCkptStride; sft < q; ++sft) p = cmul(p, inc_old);
+        t->phase_old[32 - j] = p;
+    }
+    const float2 p0 = ck[c_hi - c_lo];                                          // the live phase (phase after q0 blocks)
+    DemodConstants k = make_constants(rx.fs, kSsbBw, f_hz, usb != 0);
+    const float2 inc_new = make_float2(k.inc.real(), k.inc.imag());
+    {
+        float2 p = p0;
+        for (int j = 0; j < 32; ++j) { t->phase_new[j] = p; p = cmul(p, inc_new); }
+    }
+    for (uint32_t m = 0; m < k.block; ++m) {
+        t->tone_old[m] = make_float2(k_old.tone[m].real(), k_old.tone[m].imag());
+        t->tone_new[m] = make_float2(k.tone[m].real(), k.tone[m].imag());
+    }
+    t->sign = k.sign;
+    // private table from the live phase; the shared table of the new tuning is what the channel returns to when its
+    // demodulator is next re-created (slot boundary)
+    const size_t n_ckpt = std::get<3>(ch.phasor_key);
+    if ((rc = build_private_phasor(c, ch, n_ckpt, p0, inc_new)) != CWSLG_OK) return rc;
+    const auto new_key = std::make_tuple(rx.fs, demod_hz, usb ? 1 : 0, n_ckpt);
+    if ((rc = retarget_phasor(c, ch, new_key, inc_new)) != CWSLG_OK) return rc;
+    ch.k = k;
+    ch.demod_hz = demod_hz;
+    ch.usb = usb != 0;
+    HIPCHK(c, hipMemcpyAsync(ch.d_tone, ch.k.tone.data(), ch.k.block * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, sync_streams(c));
+    ch.origin_abs = b0_abs;                                                      // block indices count from the retune point now
+    ch.pend_lo = b0_abs;
+    ch.use_priv = true;
+    ch.trans = t;
+    ch.trans_active = true;
     return CWSLG_OK;
 }
 

@@ -106,8 +106,28 @@ struct alignas(16) FinWork {
 struct alignas(16) PhasorJob {
     float2  *ckpt;
     float2   inc;
+    float2   start;       // checkpoint 0: (1, 0) for a fresh demodulator (SSBD.hpp:121), the live phase after Tune(reset = false)
     unsigned n_ckpt;
     unsigned pad_;
+};
+
+// One channel's outputs right after SSBD::Tune(F, isUSB, reset = false) (SSBD.hpp:97-123 with :116-121 skipped): the workspace
+// keeps the partial sums of the last 31 blocks, which were mixed with the OLD tone and multiplied by the OLD phasor sequence, so
+// output b0 + o (b0 = the block at which the retune took effect) sums tap block n over block b0 + o - 31 + n with the old
+// parameters where that block precedes b0 and the new ones from b0 on.  Everything is passed by value: the old tuning's tables
+// may be gone by the time the samples arrive.
+struct alignas(16) TransWork {
+    const float2 *ring;
+    float        *out;           // output b0 + o_first goes to out[0]
+    unsigned     *peak;
+    float2        tone_old[16], tone_new[16];
+    float2        phase_old[32];  // blocks b0 - 32 .. b0 - 1
+    float2        phase_new[32];  // blocks b0 .. b0 + 31
+    float         sign;           // the NEW sideband sign: Iterate reads it when the output leaves (SSBD.hpp:131-134)
+    unsigned      ring_cap;
+    unsigned      pos_b0;         // ring index of the first sample of block b0
+    int           o_first, n_out; // outputs b0 + o_first .. b0 + o_first + n_out - 1, all below b0 + 32
+    int           blocks_before;  // blocks that exist before b0 since the demodulator's origin (older ones are x = 0), at most 32
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -133,7 +153,7 @@ __global__ void phasor_coarse_kernel(const PhasorJob *__restrict__ jobs, int n_j
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_jobs) return;
     const PhasorJob job = jobs[j];
-    float2 p = make_float2(1.0f, 0.0f);                 // SSBD.hpp:121
+    float2 p = job.start;                               // (1, 0): SSBD.hpp:121
     for (unsigned c = 0; c < job.n_ckpt; c += kCoarse) {
         job.ckpt[c] = p;
         for (int s = 0; s < kCoarse * kCk; ++s) p = cmul_exact(p, job.inc);
@@ -1163,6 +1183,53 @@ __global__ __launch_bounds__(NT, 2) void demod_exact2_kernel(const ChanWork *__r
         for (int msk = 32; msk >= 1; msk >>= 1) mx = fmaxf(mx, __shfl_xor(mx, msk, 64));
         if ((tid & 63) == 0) publish_peak(cur.peak, mx);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// demod_transition_kernel: the (at most 32) outputs after a phase-continuous retune, in ProcessBlock's own order (SSBD.hpp:160-183)
+// whatever the context's mode -- they are a handful per retune.  grid = works, 64 threads: thread = output.
+template <int D>
+__global__ __launch_bounds__(64) void demod_transition_kernel(const TransWork *__restrict__ works, const float *__restrict__ taps)
+{
+    const TransWork *w = works + blockIdx.x;
+    const int o = threadIdx.x;
+    if (o >= w->n_out) return;
+    const int b = w->o_first + o;                              // output block, relative to b0
+    const CWSLG_GLOBAL float2 *ring = as_global(w->ring);
+    float wr = 0.0f, wi = 0.0f;                                // the workspace slot, zero after its last read-out (:178)
+    for (int n = 0; n < 32; ++n) {                             // oldest block first, as the blocks arrived
+        const int beta = b - 31 + n;                           // block, relative to b0
+        if (beta < -w->blocks_before) continue;                // before the demodulator existed: nothing was ever added
+        const bool old = beta < 0;
+        const float2 *tone = old ? w->tone_old : w->tone_new;
+        const float2 ph = old ? w->phase_old[beta + 32] : w->phase_new[beta];
+        long long pos = (long long)w->pos_b0 + (long long)beta * D;
+        if (pos < 0) pos += w->ring_cap;
+        if (pos >= (long long)w->ring_cap) pos -= w->ring_cap;
+        float sr = 0.0f, si = 0.0f;
+        for (int m = 0; m < D; ++m) {                          // :166-169, un-fused
+            unsigned idx = (unsigned)pos + (unsigned)m;
+            if (idx >= w->ring_cap) idx -= w->ring_cap;
+            const float2 x = make_float2(ring[idx].x, ring[idx].y);
+            const float2 t = cmul_exact(x, tone[m]);
+            const float h = taps[m + D * n];
+            sr = sr + t.x * h;
+            si = si + t.y * h;
+        }
+        const float2 pr = cmul_exact(make_float2(sr, si), ph);  // sum * phase (:170)
+        wr = wr + pr.x;
+        wi = wi + pr.y;
+    }
+    // Iterate (:131-134): block position mod 4 (b0 is a multiple of 4 blocks from the origin)
+    float v;
+    switch (b & 3) {
+    case 0: v = wr; break;
+    case 1: v = -wi * w->sign; break;
+    case 2: v = -wr; break;
+    default: v = wi * w->sign; break;
+    }
+    as_global_rw(w->out)[o] = v;
+    publish_peak(w->peak, fabsf(v));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -118,8 +118,18 @@ int cwslg_channel_close(cwslg_ctx *ctx, int ch_id);
 /* SSBD::Tune(F, isUSB) with its default reset = true (SSBD.hpp:96-123): the channel gets a new tone and phasor step, its
  * filter history is forgotten and its phasor restarts at (1, 0); samples pushed before the call keep the old tuning and
  * the frame keeps filling where it was.  The band checks fail with the same two statuses / messages as at open, and then
- * leave the old tuning in place.  (Tune's reset = false -- a phase-continuous retune over a live workspace -- is not offered.) */
+ * leave the old tuning in place.  Like a Tune() on Instance's live SSBD object, the retune lasts until the demodulator is next
+ * re-created: after every emitted frame Instance constructs a new SSBD from its OWN demodFreq / USB (Instance.cpp:251), and so
+ * does cwslg_slot_boundary -- the channel is back on the tuning it was opened with.  (A lasting change of frequency is a new
+ * channel, as band rotation is a new Instance in the reference, CWSL_DIGI.cpp:1217-1226.) */
 int cwslg_channel_tune(cwslg_ctx *ctx, int ch_id, int32_t demod_hz, int usb);
+/* SSBD::Tune(F, isUSB, reset) with its third argument (SSBD.hpp:97, :116-121).  reset != 0 is cwslg_channel_tune.  reset == 0 is the
+ * phase-continuous retune: the filter history stays as it was mixed with the old tuning, the phasor continues from its live value
+ * with the new step, the block count (Iterate's position) goes on -- so the 31 outputs after the retune point blend the two
+ * tunings exactly as the reference's workspace does (bit-identical in exact mode; in the default mode those outputs are computed
+ * in the reference's order and the rest within the usual 1e-5).  The reference never passes reset = false itself.
+ * A second reset == 0 retune before 32 more blocks have been pushed returns CWSLG_ERR_UNSUPPORTED. */
+int cwslg_channel_tune_ex(cwslg_ctx *ctx, int ch_id, int32_t demod_hz, int usb, int reset);
 /* SSBD getters (SSBD.hpp:140-154) for the shim */
 int cwslg_channel_info(cwslg_ctx *ctx, int ch_id, uint32_t *in_size, uint32_t *out_size,
                        uint32_t *out_rate, uint32_t *delay, size_t *frame_len);

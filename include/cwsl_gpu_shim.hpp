@@ -87,10 +87,11 @@ public:
     std::size_t GetOutSize() const { return out_; }     // :146
     std::size_t GetOutRate() const { return rate_; }    // :142
     std::size_t GetDelay() const { return delay_; }     // :154
-    // SSBD::Tune(F, isUSB): throws the same std::invalid_argument texts; the old tuning stays in force after a throw
-    void Tune(double F, bool isUSB)
+    // SSBD::Tune(F, isUSB, reset = true) (SSBD.hpp:97): throws the same std::invalid_argument texts; the old tuning stays in force
+    // after a throw.  reset = false keeps filter history, block position and phase, as :116-121 does when skipped.
+    void Tune(double F, bool isUSB, bool reset = true)
     {
-        const int rc = cwslg_channel_tune(ctx_.raw(), id_, static_cast<std::int32_t>(F), isUSB ? 1 : 0);
+        const int rc = cwslg_channel_tune_ex(ctx_.raw(), id_, static_cast<std::int32_t>(F), isUSB ? 1 : 0, reset ? 1 : 0);
         if (rc == CWSLG_ERR_BAND_LOW || rc == CWSLG_ERR_BAND_HIGH || rc == CWSLG_ERR_RATIO) throw std::invalid_argument(cwslg_strerror(rc));
         check(ctx_.raw(), rc);
     }

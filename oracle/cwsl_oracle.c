@@ -84,7 +84,12 @@ int orc_demod_open(orc_demod_t *d, uint64_t fs, uint64_t bw, double f_hz, int us
 
 /* SSBD::Tune(F, isUSB, reset = true), SSBD.hpp:96-123.  On a range error the object is left untouched (the throw
  * happens before anything is stored). */
-int orc_demod_tune(orc_demod_t *d, double f_hz, int usb)
+int orc_demod_tune(orc_demod_t *d, double f_hz, int usb) { return orc_demod_tune_ex(d, f_hz, usb, 1); }
+
+/* The same with Tune's third argument: reset = 0 keeps workspace, index and phase (:116-121 skipped), so the partial sums of the
+ * last 31 blocks -- mixed with the OLD tone and phase -- stay in the workspace and the phasor continues from its current value
+ * with the new step. */
+int orc_demod_tune_ex(orc_demod_t *d, double f_hz, int usb, int reset)
 {
     const uint64_t fs = d->fs, bw = d->bw;
     /* range checks use integer Fs/2 promoted to double (:100-103) */
@@ -108,9 +113,11 @@ int orc_demod_tune(orc_demod_t *d, double f_hz, int usb)
         d->inc_re = crealf(e);
         d->inc_im = cimagf(e);
     }
-    for (int k = 0; k < ORC_NUM_WS; ++k) { d->ws_re[k] = 0.0f; d->ws_im[k] = 0.0f; }     /* :117-121 */
-    d->head = 0;
-    d->ph_re = 1.0f; d->ph_im = 0.0f;
+    if (reset) {                                                /* :116-121 */
+        for (int k = 0; k < ORC_NUM_WS; ++k) { d->ws_re[k] = 0.0f; d->ws_im[k] = 0.0f; }
+        d->head = 0;
+        d->ph_re = 1.0f; d->ph_im = 0.0f;
+    }
     return ORC_OK;
 }
 

@@ -68,6 +68,8 @@ int  orc_demod_open(orc_demod_t *d, uint64_t fs, uint64_t bw, double f_hz, int u
 void orc_demod_close(orc_demod_t *d);
 /* SSBD::Tune(F, isUSB, reset = true) on an open demodulator (SSBD.hpp:96-123) */
 int  orc_demod_tune(orc_demod_t *d, double f_hz, int usb);
+/* SSBD::Tune(F, isUSB, reset): reset = 0 keeps workspace, index and phase (SSBD.hpp:116-121 skipped) */
+int  orc_demod_tune_ex(orc_demod_t *d, double f_hz, int usb, int reset);
 /* one Iterate(): consumes 4*block complex samples, emits 4 floats (SSBD.hpp:127-137,160-183) */
 void orc_demod_iterate(orc_demod_t *d, const float *iq_ri, float *out4);
 /* n_complex must be a multiple of 4*block; phase_trace (optional) gets the phasor before every block */

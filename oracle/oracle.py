@@ -61,6 +61,7 @@ def lib():
         L.orc_demod_open.argtypes = [C.POINTER(_Demod), C.c_uint64, C.c_uint64, C.c_double, C.c_int]
         L.orc_demod_close.argtypes = [C.POINTER(_Demod)]
         L.orc_demod_tune.argtypes = [C.POINTER(_Demod), C.c_double, C.c_int]
+        L.orc_demod_tune_ex.argtypes = [C.POINTER(_Demod), C.c_double, C.c_int, C.c_int]
         L.orc_demod_run.argtypes = [C.POINTER(_Demod), _f32p, C.c_uint64, _f32p, C.c_void_p]
         L.orc_rx_period.argtypes = [C.c_char_p]; L.orc_rx_period.restype = C.c_double
         L.orc_frame_len.argtypes = [C.c_char_p]; L.orc_frame_len.restype = C.c_size_t
@@ -131,6 +132,7 @@ def ref():
         R.ref_ssbd_run.restype = C.c_int
         R.ref_build_lowpass.argtypes = [C.c_uint64, C.c_double, _f32p]
         R.ref_ssbd_tune.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_char_p, C.c_int]
+        R.ref_ssbd_tune_ex.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_char_p, C.c_int]
         R.ref_bench_cpu.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint64]
         R.ref_bench_cpu.restype = C.c_double
         R.ref_inst_new.argtypes = [C.c_uint64, C.c_uint32, C.c_double, C.c_uint64]; R.ref_inst_new.restype = C.c_void_p
@@ -188,9 +190,9 @@ class Demod:
     def phase_delta(self):
         return np.float32(self.s.phase_delta)
 
-    def tune(self, f_hz, usb=True):
-        """SSBD::Tune(F, isUSB) on the live object; raises ValueError with the reference's text, state untouched."""
-        rc = lib().orc_demod_tune(C.byref(self.s), float(f_hz), 1 if usb else 0)
+    def tune(self, f_hz, usb=True, reset=True):
+        """SSBD::Tune(F, isUSB, reset) on the live object; raises ValueError with the reference's text, state untouched."""
+        rc = lib().orc_demod_tune_ex(C.byref(self.s), float(f_hz), 1 if usb else 0, 1 if reset else 0)
         if rc != 0:
             raise ValueError({-2: "Signal outside of band (low)", -3: "Signal outside of band (high)"}.get(rc, str(rc)))
 
@@ -265,9 +267,9 @@ class RefDemod:
 
     __del__ = close
 
-    def tune(self, f_hz, usb=True):
+    def tune(self, f_hz, usb=True, reset=True):
         err = C.create_string_buffer(256)
-        if ref().ref_ssbd_tune(self.h, float(f_hz), 1 if usb else 0, err, 256) != 0:
+        if ref().ref_ssbd_tune_ex(self.h, float(f_hz), 1 if usb else 0, 1 if reset else 0, err, 256) != 0:
             raise ValueError(err.value.decode())
 
     @property
@@ -315,9 +317,9 @@ class Channel:
 
     __del__ = close
 
-    def tune(self, demod_hz, usb=True):
+    def tune(self, demod_hz, usb=True, reset=True):
         """Instance's SSBD retuned in place (SSBD::Tune): float(demod_hz) as at construction (Instance.cpp:187)."""
-        rc = lib().orc_demod_tune(C.byref(self.c.demod), float(np.float32(demod_hz)), 1 if usb else 0)
+        rc = lib().orc_demod_tune_ex(C.byref(self.c.demod), float(np.float32(demod_hz)), 1 if usb else 0, 1 if reset else 0)
         if rc != 0:
             raise ValueError({-2: "Signal outside of band (low)", -3: "Signal outside of band (high)"}.get(rc, str(rc)))
 

@@ -123,6 +123,15 @@ int ref_ssbd_tune(void* h, double F, int usb, char* err, int errlen)
         return -1;
     }
 }
+// the same with Tune's third argument (reset = false keeps workspace, index and phase)
+int ref_ssbd_tune_ex(void* h, double F, int usb, int reset, char* err, int errlen)
+{
+    try { static_cast<SSBD<float>*>(h)->Tune(F, usb != 0, reset != 0); return 0; }
+    catch (const std::exception& e) {
+        if (err && errlen > 0) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+        return -1;
+    }
+}
 
 // BuildLowPass<float> alone (LowPass.hpp:16-35), un-normalised.
 void ref_build_lowpass(uint64_t order, double bandwidth, float* taps)

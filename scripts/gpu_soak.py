@@ -65,8 +65,19 @@ def main():
                 m = min(n - pos, blk * int(rng.integers(1, 60)))
                 if 0 <= retune_at - pos < m and retune_at > pos:
                     m = retune_at - pos
-                if pos == retune_at:
-                    ctx.channel_tune(ch, f2); oc.tune(f2); st["retunes"] += 1
+                if pos == retune_at:                # SSBD::Tune with reset = true or false (SSBD.hpp:97), sometimes flipping the sideband
+                    keep, usb2 = bool(rng.random() < 0.5), bool(rng.random() < 0.8)
+                    try:
+                        oc.tune(f2, usb2, reset=not keep)
+                    except ValueError:              # out of band for this sideband: both sides refuse and keep the old tuning
+                        try:
+                            ctx.channel_tune(ch, f2, usb2, reset=not keep)
+                            st["failures"].append(dict(tag, what="retune accepted that the reference refuses"))
+                        except P.CwslGpuError:
+                            pass
+                    else:
+                        ctx.channel_tune(ch, f2, usb2, reset=not keep)
+                    st["retunes"] += 1; st["retunes_keep"] = st.get("retunes_keep", 0) + int(keep)
                 ctx.push_iq(rx, iq[pos:pos + m]); oc.push_many(iq[pos:pos + m]); pos += m
             ctx.slot_boundary(mode, 25)
             ref = oc.boundary(25, want_f32=True)

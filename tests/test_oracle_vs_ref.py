@@ -132,3 +132,25 @@ def test_tune_on_a_live_demodulator_matches_reference(ref):
     # a retuned object equals a freshly constructed one from that point on (workspace, index and phase are reset)
     c = ref.Demod(fs, 31000)
     assert np.array_equal(c.run(iq[n1:]).view(np.uint32), ya.view(np.uint32))
+
+
+def test_tune_without_reset_matches_reference(ref):
+    """SSBD::Tune(F, isUSB, reset = false) (SSBD.hpp:97,116-121): workspace, index and phase survive the retune.  The oracle's
+    orc_demod_tune_ex against the compiled header, bit for bit, through two retunes (one of them flipping the sideband)."""
+    fs = 192000
+    iq = ref.synth_iq(5, 64 * 40 * 9, fs, tones_hz=[-26000 + 900.0, 60000 + 1500.0, 1234 + 700.0], amp=9000.0)
+    a, b = ref.Demod(fs, -26000), ref.RefDemod(fs, -26000)
+    cuts = [0, 64 * 40 * 3, 64 * 40 * 6, 64 * 40 * 9]
+    plan = [None, (60000, True), (1234, False)]
+    outs = []
+    for k in range(3):
+        if plan[k] is not None:
+            a.tune(plan[k][0], plan[k][1], reset=False); b.tune(plan[k][0], plan[k][1], reset=False)
+        ya, yb = a.run(iq[cuts[k]:cuts[k + 1]]), b.run(iq[cuts[k]:cuts[k + 1]])
+        assert np.array_equal(ya.view(np.uint32), yb.view(np.uint32)), k
+        outs.append(ya)
+    # and it is NOT the reset form: the 31 outputs after the retune still carry the old tuning's partial sums
+    c = ref.Demod(fs, -26000)
+    c.run(iq[:cuts[1]]); c.tune(60000, True, reset=True)
+    yc = c.run(iq[cuts[1]:cuts[2]])
+    assert not np.array_equal(yc[:31].view(np.uint32), outs[1][:31].view(np.uint32))
