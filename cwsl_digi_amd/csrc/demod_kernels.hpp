@@ -565,7 +565,8 @@ __global__ __launch_bounds__(NT, 4) void demod_kernel(const ChanWork *__restrict
                     if (in1) *reinterpret_cast<float2 *>(p1 + 2 * it * WSTEP) = make_float2(y0i, y1i);
                 }
             };
-            if (fv != 0) mix(std::true_type{});
+            if (PERSIST) mix(std::true_type{});          // (one copy only: with two, the in-place prefetch spills at 128 VGPRs)
+            else if (fv != 0) mix(std::true_type{});
             else mix(std::false_type{});
         }
         lds_barrier();
