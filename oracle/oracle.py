@@ -53,7 +53,9 @@ _ref = None
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(_HERE, "liboracle.so")
+        # CWSL_ORACLE_LIB: another build of the same sources, e.g. `make -C oracle liboracle_asan.so` run with
+        # LD_PRELOAD=$(gcc -print-file-name=libasan.so) -- the sanitizer pass over the checker itself
+        path = os.environ.get("CWSL_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
         if not os.path.isfile(path):
             build(ref=False)
         L = C.CDLL(path)
