@@ -906,6 +906,7 @@ void cwslg_destroy(cwslg_ctx *c)
         if (ch.d_block) hipFree(ch.d_block);
         sync_free_channel(ch.syncbuf);
         if (ch.longbuf.d_block) { (void)hipFree(ch.longbuf.d_block); ch.longbuf = LongChannelBuffers(); }
+        if (ch.priv.d_ckpt) { (void)hipFree(ch.priv.d_ckpt); ch.priv.d_ckpt = nullptr; }
     }
     for (Receiver &rx : c->rxs) if (rx.d_ring) hipFree(rx.d_ring);
     for (auto &kv : c->d_taps) hipFree(kv.second);
