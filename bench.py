@@ -260,7 +260,7 @@ def main():
                        "slots_per_gpu": S, "channels_per_receiver": C, "fs_hz": FS, "iq_block": IQ_LEN, "stages": "nco-mix+polyphase-decimate, peak-normalise+int16" + (", ft8 symbol-spectra+costas-sync+candidates" if args.sync else ""),
                        "sharding": f"slots x{world}, one 8-byte RCCL all-reduce per slot boundary inside cwslg_slot_boundary" if world > 1 else "single GPU"},
             "realtime_ft8_slots": msps / 0.192,
-            "roofline": {"bound": "hbm", "kernel": "demod_exact_kernel<16,256,256>" if args.exact else "demod_kernel<16,256,256,0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "demod_exact2_kernel<16,248,128>" if args.exact else "demod_kernel<16,256,256,0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "bytes_per_sample": bps, "samples_per_launch": samples_per_launch,
                          "valu_tflops": 80.0 * samples_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
