@@ -430,7 +430,8 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     std::memcpy(w->h, works.data(), works.size() * sizeof(ChanWork));
     HIPCHK(c, hipMemcpyAsync(w->d, w->h, works.size() * sizeof(ChanWork), hipMemcpyHostToDevice, c->stream));
     const bool exact2 = c->exact && c->demod_variant != 20;
-    const int tile = exact2 ? kTileExact : kTile;
+    const bool small_tile = !c->exact && c->demod_variant == 15 && D == 16;     // 192-output tiles: 31 KB of LDS, five workgroups per CU
+    const int tile = exact2 ? kTileExact : (small_tile ? 192 : kTile);
     const int tiles_n = (int)((max_blocks + tile - 1) / tile);
     const int tiles_x = tile_major ? -tiles_n : tiles_n;        // sign selects the work-item order (demod_kernels.hpp)
     const long long total = (long long)tiles_n * (long long)works.size();
@@ -469,6 +470,14 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
         else if (c->demod_variant == 5) go(demod_mfma1p_kernel<kTile, kDemodThreads, 5>);
         else if (c->demod_variant == 6) go(demod_mfma1p_kernel<kTile, kDemodThreads, 6>);
         else go(demod_mfma1p_kernel<kTile, kDemodThreads, 7>);
+    } else if (small_tile) {
+        if constexpr (D == 16)
+            hipLaunchKernelGGL((demod_kernel<16, 192, kDemodThreads, 0>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
+                               c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
+    } else if (c->demod_variant == 8 && D == 16) {
+        // the dense product on the bf16 matrix cores at fp32 accuracy (three-way split operands)
+        hipLaunchKernelGGL((demod_mfma_bf16_kernel<kTile, kDemodThreads, 4>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0, c->stream,
+                           (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
     } else if (c->demod_variant >= 9 && c->demod_variant <= 14) {
         auto go = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0, c->stream, (const ChanWork *)w->d,

@@ -43,6 +43,9 @@ namespace cwslg {
 
 // Pointers fetched from a descriptor in memory are generic to the compiler (flat_load); these are
 // known to be HBM addresses, so say so and get global_load / global_store.
+#ifndef CWSLG_BF16_DIAG
+#define CWSLG_BF16_DIAG 0
+#endif
 // -DCWSLG_FIR_PK=1: the FIR of demod_kernel on v_pk_fma_f32 (half the issue slots, same FLOPs; measured alternative, see phase 2)
 #ifndef CWSLG_FIR_PK
 #define CWSLG_FIR_PK 0
@@ -401,7 +404,7 @@ __device__ __forceinline__ void issue_tile_loads(const TileCtx<D, T> &c, int tid
 }
 
 template <int D, int T, int NT, int MODE>
-__global__ __launch_bounds__(NT, 4) void demod_kernel(const ChanWork *__restrict__ works,
+__global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const ChanWork *__restrict__ works,
                                                                      const float *__restrict__ taps,
                                                                      int tiles_x, int n_ch)
 {
@@ -854,6 +857,252 @@ __global__ __launch_bounds__(NT, WGS) void demod_mfma1p_kernel(const ChanWork *_
     {
         const int pl = tid >> 7, p = tid & 127;
         const float *src = s_plane + pl * 16 * PW + p;
+        float sum = 0.0f;
+#pragma unroll
+        for (int wq = 0; wq < 16; ++wq) sum = sum + src[wq * (PW + 1)];
+        const float sgn_plane = pl ? -cur.sign : 1.0f;
+        const float sg = (p & 1) ? -sgn_plane : sgn_plane;
+        s_aux[2 * p + pl] = sg * sum;
+    }
+    lds_barrier();
+    {
+        CWSLG_GLOBAL float *out = as_global_rw(cur.out) + (size_t)cur.tile * T;
+        float mx = 0.0f;
+        for (int o = tid; o < cur.n_out; o += NT) {
+            const float v = s_aux[o];
+            out[o] = v;
+            mx = fmaxf(mx, fabsf(v));
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        if (lane == 0) publish_peak(cur.peak, mx);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// demod_mfma_bf16_kernel (D = 16; CWSLG_DEMOD_VARIANT=8): demod_mfma1p_kernel's structure with the dense product on the BF16 matrix
+// cores at fp32 accuracy.  demod_kernel holds the package at its 1400 W limit (profiles/r2_power.txt): what separates it from the
+// floor of its access pattern is the ENERGY of the fp32 FMAs, and a bf16 MFMA costs a small fraction of an fp32 FMA per product.
+// Every mixed sample y and every tap h is split into three bf16 terms,  y = a + b + c,  h = d + e + f  (a = bf16(y), b = bf16(y - a),
+// c = bf16(y - a - b): the residuals are exact in fp32, so the three terms carry all 24 bits), and
+//     y h  =  a d + a e + b d + a f + b e + c d   (+ b f + c e + c f, below 2^-24 of the product: dropped)
+// Each bf16 x bf16 product is exact in fp32 and the MFMA accumulates in fp32, so the result has fp32-class rounding (measured
+// against the reference-order arithmetic by the same tests as demod_kernel).  Per 16-column row block and plane: six
+// v_mfma_f32_16x16x32_bf16 (K = 32 = the branches, one instruction each) instead of eight v_mfma_f32_16x16x4_f32 at 16 instead of
+// 32 cycles: 0.375 of the matrix-pipe time.  LDS image per plane: [split][column q][branch u] bf16, 80-byte column pitch (the 16
+// lanes of a ds_read_b128 group start 20 banks apart: conflict-free), 34.5 KB, one plane resident at a time: 4 workgroups per CU.
+// Result (same box, 512 slots, demod only): numerics as hoped -- 4.6e-7 of frame peak, every parity test of the default mode green --
+// and 2.67 ms at 1400 W / 1.97 GHz against demod_kernel's 2.58 ms at 1400 W / 1.90 GHz and the f32 matrix-core form's 2.59 ms at
+// 1400 W / 1.99 GHz.  Three different ways of doing the FIR, one launch time and one power reading: the FIR's arithmetic is NOT what
+// holds the package at its limit.  Kept as a measured alternative.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// (y0, y1) -> three packed bf16 pairs (round to nearest even); the residuals y - a and y - a - b are exact
+__device__ __forceinline__ void split3_bf16(float y0, float y1, unsigned &a, unsigned &b, unsigned &c)
+{
+    auto pk = [](float u0, float u1) {
+        const bf16x2 t = __builtin_convertvector(v2f{u0, u1}, bf16x2);
+        return __builtin_bit_cast(unsigned, t);
+    };
+    a = pk(y0, y1);
+    const float f0 = y0 - __uint_as_float(a << 16), f1 = y1 - __uint_as_float(a & 0xFFFF0000u);
+    b = pk(f0, f1);
+    const float g0 = f0 - __uint_as_float(b << 16), g1 = f1 - __uint_as_float(b & 0xFFFF0000u);
+    c = pk(g0, g1);
+}
+
+template <int T, int NT, int WGS>
+__global__ __launch_bounds__(NT, WGS) void demod_mfma_bf16_kernel(const ChanWork *__restrict__ works,
+                                                                  const float *__restrict__ taps,
+                                                                  int tiles_x, int n_ch)
+{
+    constexpr int D = 16;
+    using Geo = DemodGeom<D, T>;
+    constexpr int G = Geo::G;
+    constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
+    constexpr int NRB = (T / 2 + 15 + 15) / 16;          // 9 row blocks of 16 columns per plane
+    constexpr int PPW = (NRB + NT / 64 - 1) / (NT / 64);     // row blocks per wave and plane: 3 (wave 0) / 2
+    constexpr int PW = T / 2 + 17;                       // pitch of the product image [w][q]
+    constexpr int NQ = 16 * NRB;                         // 144 columns
+    constexpr int QP = 80;                               // bytes per column of one split image
+    constexpr int SPLIT_BYTES = NQ * QP;                 // 11 520
+    static_assert(T == 256 && NT == 256 && G == 32 && 2 * 16 * PW * 4 <= 3 * SPLIT_BYTES, "geometry");
+
+    __shared__ __attribute__((aligned(16))) unsigned char s_img[3 * SPLIT_BYTES];
+    __shared__ __attribute__((aligned(16))) float s_aux[Geo::AUX_FLOATS];
+    float2 *s_phase = reinterpret_cast<float2 *>(s_aux);
+    float *s_prod = reinterpret_cast<float *>(s_img);
+
+    const int total = (tiles_x < 0 ? -tiles_x : tiles_x) * n_ch;
+    const int per_xcd = (total + 7) >> 3;
+    const int item = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (item >= min(((int)(blockIdx.x & 7) + 1) * per_xcd, total)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    TileCtx<D, T> cur;
+    int ich, itile;
+    item_to_ch_tile(item, tiles_x, n_ch, ich, itile);
+    decode_item<D, T>(works + ich, itile, cur);
+    v4f xs[NIT];
+    float2 ck;
+    v4f tn;
+    issue_tile_loads<D, T, NT>(cur, tid, xs, ck, tn);
+    // B operand: H[u = 8 (lane >> 4) + j][w = lane & 15], j = 0..7, as three bf16 fragments
+    bf16x8 hd, he, hf;
+    {
+        const float *hp = taps + G * (lane & 15) + 8 * (lane >> 4);
+        unsigned d[4], e[4], f[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split3_bf16(hp[2 * j], hp[2 * j + 1], d[j], e[j], f[j]);
+        struct U4 { unsigned v[4]; };
+        hd = __builtin_bit_cast(bf16x8, U4{{d[0], d[1], d[2], d[3]}});
+        he = __builtin_bit_cast(bf16x8, U4{{e[0], e[1], e[2], e[3]}});
+        hf = __builtin_bit_cast(bf16x8, U4{{f[0], f[1], f[2], f[3]}});
+    }
+
+    // image addresses of this thread's sample pairs: sample r = 2 tid + 512 it -> column r / 32, branches (r % 32, r % 32 + 1)
+    unsigned char *w0 = s_img + (tid >> 4) * QP + (tid & 15) * 4;                    // plane 0: rel = r
+    const int rel1 = 2 * tid - D + 2 * NT;                                           // plane 1: rel = r - D, taken at it = 1
+    unsigned char *w1 = s_img + ((rel1 >> 5) - (2 * NT) / G) * QP + (rel1 & 31) * 2;
+    constexpr int WSTEP_B = ((2 * NT) / G) * QP;                                     // bytes per iteration: 16 columns
+
+    {   // ---- phase 0: bit-exact phasor for the tile's T+31 blocks
+        const int cidx = cur.ck_first + tid;
+        if (tid < Geo::NCK && cidx >= 0) {
+            float2 p = ck;
+            const int pbase = cur.pb0 + kCk * tid;
+#pragma unroll
+            for (int s = 0; s < kCk; ++s) {
+                const int pb = pbase + s;
+                if (pb >= 0 && pb < Geo::NBLK) s_phase[pb] = p;
+                p = cmul_exact(p, cur.inc);
+            }
+        }
+    }
+    lds_barrier();
+    if (cur.n_out == 0) return;
+    const int fv = cur.first_valid;
+    // A-fragment / product addresses of this wave's row blocks (the same for both planes)
+    const unsigned char *pa[PPW];
+    float *pd[PPW];
+    bool on[PPW];
+    {
+        const int wvu = __builtin_amdgcn_readfirstlane(wv);
+        const int ld = (lane & 15) * PW + 4 * (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int rb0 = wvu + (NT / 64) * i;
+            on[i] = rb0 < NRB;
+            const int rb = on[i] ? rb0 : 0;                 // a wave without a third block repeats block 0 and drops it
+            pa[i] = s_img + (16 * rb + (lane & 15)) * QP + 16 * (lane >> 4);
+            pd[i] = s_prod + 16 * rb + ld;
+        }
+    }
+    auto products = [&](v4f (&acc)[PPW]) {
+        bf16x8 fa[PPW], fb[PPW], fc[PPW];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            fa[i] = *reinterpret_cast<const bf16x8 *>(pa[i]);
+            fb[i] = *reinterpret_cast<const bf16x8 *>(pa[i] + SPLIT_BYTES);
+            fc[i] = *reinterpret_cast<const bf16x8 *>(pa[i] + 2 * SPLIT_BYTES);
+        }
+#if CWSLG_BF16_DIAG >= 1                                  // diagnostic builds (scripts/gpu_bf16_diag.sh): no matrix instructions
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) acc[i].x += (float)fa[i][0] + (float)fb[i][1] + (float)fc[i][2];
+        return;
+#endif
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {                   // smallest terms first
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc[i], hd, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i], he, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], hf, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i], hd, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], he, acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], hd, acc[i], 0, 0, 0);
+        }
+    };
+    // ---- phase 1a: tone mix (kept in the load registers), Re part -> the split image
+    {
+        const float2 tn0 = make_float2(tn.x, tn.y), tn1 = make_float2(tn.z, tn.w);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = 2 * tid + it * 2 * NT;
+            int blk = (2 * tid) / D + it * (2 * NT / D);
+            if (blk > Geo::NBLK - 1) blk = Geo::NBLK - 1;
+            const float2 ph = s_phase[blk];
+            const v4f x = xs[it];
+            v4f m;
+            m.x = __builtin_fmaf(x.x, tn0.x, -(x.y * tn0.y));
+            m.y = __builtin_fmaf(x.x, tn0.y, x.y * tn0.x);
+            m.z = __builtin_fmaf(x.z, tn1.x, -(x.w * tn1.y));
+            m.w = __builtin_fmaf(x.z, tn1.y, x.w * tn1.x);
+            xs[it] = m;
+            float y0r = __builtin_fmaf(m.x, ph.x, -(m.y * ph.y));
+            float y1r = __builtin_fmaf(m.z, ph.x, -(m.w * ph.y));
+            if (fv != 0) { if (r < fv) { y0r = 0.f; y1r = 0.f; } }
+            const bool in0 = (it < NIT - 1) || (r < G * (T / 2 + 15));
+            if (in0) {
+                unsigned a, b, c;
+#if CWSLG_BF16_DIAG >= 2                                  // ... and no split arithmetic
+                a = __float_as_uint(y0r); b = __float_as_uint(y1r); c = a ^ b;
+#else
+                split3_bf16(y0r, y1r, a, b, c);
+#endif
+                unsigned char *dst = w0 + it * WSTEP_B;
+                *reinterpret_cast<unsigned *>(dst) = a;
+                *reinterpret_cast<unsigned *>(dst + SPLIT_BYTES) = b;
+                *reinterpret_cast<unsigned *>(dst + 2 * SPLIT_BYTES) = c;
+            }
+        }
+    }
+    lds_barrier();
+    v4f acc0[PPW], acc1[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) { acc0[i] = v4f{0.f, 0.f, 0.f, 0.f}; acc1[i] = v4f{0.f, 0.f, 0.f, 0.f}; }
+    products(acc0);
+    lds_barrier();                                        // the Re image has been consumed
+    // ---- phase 1b: Im part -> the same storage (plane-1 alignment: relative sample r - D)
+    {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = 2 * tid + it * 2 * NT;
+            int blk = (2 * tid) / D + it * (2 * NT / D);
+            if (blk > Geo::NBLK - 1) blk = Geo::NBLK - 1;
+            const float2 ph = s_phase[blk];
+            const v4f m = xs[it];
+            float y0i = __builtin_fmaf(m.x, ph.y, m.y * ph.x);
+            float y1i = __builtin_fmaf(m.z, ph.y, m.w * ph.x);
+            if (fv != 0) { if (r < fv) { y0i = 0.f; y1i = 0.f; } }
+            const bool in1 = (it > 0) ? ((it < NIT - 1) || (r < Geo::NSAMP)) : (r >= D);
+            if (in1) {
+                unsigned a, b, c;
+#if CWSLG_BF16_DIAG >= 2
+                a = __float_as_uint(y0i); b = __float_as_uint(y1i); c = a ^ b;
+#else
+                split3_bf16(y0i, y1i, a, b, c);
+#endif
+                unsigned char *dst = w1 + it * WSTEP_B;          // (w1 already carries the one-iteration offset)
+                *reinterpret_cast<unsigned *>(dst) = a;
+                *reinterpret_cast<unsigned *>(dst + SPLIT_BYTES) = b;
+                *reinterpret_cast<unsigned *>(dst + 2 * SPLIT_BYTES) = c;
+            }
+        }
+    }
+    lds_barrier();
+    products(acc1);
+    lds_barrier();                                        // the Im image has been consumed; s_phase is no longer needed either
+    // ---- products -> LDS as [plane][w][q] over the image storage, then the diagonal sums
+#pragma unroll
+    for (int i = 0; i < PPW; ++i)
+        if (on[i]) {
+            pd[i][0] = acc0[i].x; pd[i][1] = acc0[i].y; pd[i][2] = acc0[i].z; pd[i][3] = acc0[i].w;
+            float *d1 = pd[i] + 16 * PW;
+            d1[0] = acc1[i].x; d1[1] = acc1[i].y; d1[2] = acc1[i].z; d1[3] = acc1[i].w;
+        }
+    lds_barrier();
+    {
+        const int pl = tid >> 7, p = tid & 127;
+        const float *src = s_prod + pl * 16 * PW + p;
         float sum = 0.0f;
 #pragma unroll
         for (int wq = 0; wq < 16; ++wq) sum = sum + src[wq * (PW + 1)];

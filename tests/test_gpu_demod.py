@@ -278,3 +278,23 @@ def test_wav_file_is_the_reference_container(ctx, oracle, tmp_path):
     fr = ctx.fetch_frame(ch)["i16"]
     assert raw[:46] == oracle.wav_header(240000) and len(raw) == 46 + 480000
     assert np.array_equal(np.frombuffer(raw[46:], np.int16), fr)
+
+
+@pytest.mark.parametrize("variant", ["7", "8", "2"])
+def test_measured_alternative_kernels_stay_within_tolerance(oracle, monkeypatch, variant):
+    """The measured alternatives of the dominant kernel kept in the tree (CWSLG_DEMOD_VARIANT: 7 = FIR on the f32 matrix cores,
+    8 = on the bf16 matrix cores with three-way split operands, 2 = persistent workgroups) obey the same 1e-5 bound."""
+    import cwsl_digi_amd as P
+    monkeypatch.setenv("CWSLG_DEMOD_VARIANT", variant)
+    with P.Context(0) as ctx:
+        na, nb = 24 * IQ_LEN, 90 * IQ_LEN
+        tones = sum((_tones(f) for f in FREQS[:4]), [])
+        iq = oracle.synth_iq(0xBEEF, na + nb, FS, tones_hz=tones, amp=2.0e4)
+        rx = ctx.receiver_open(FS, IQ_LEN, 0)
+        chans = [ctx.channel_open(rx, f, "FT8") for f in FREQS[:4]]
+        _run_gpu_slot(ctx, rx, chans, iq[:na], iq[na:])
+        for f, ch in zip(FREQS[:4], chans):
+            ref = _run_oracle_slot(oracle, f, iq[:na], iq[na:])
+            f32, nv = ctx.fetch_audio_f32(ch)
+            assert nv == nb // 16
+            assert_frames_match(f32, ref["f32"])
