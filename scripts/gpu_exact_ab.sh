@@ -1,5 +1,5 @@
 #!/bin/bash
-# Exact mode: parity tests, then the 512-slot bench with the persistent kernel (default) and the one-tile-per-workgroup kernel (21)
+# Exact mode: parity tests, then the 512-slot bench in exact mode (VARIANTS: CWSLG_DEMOD_VARIANT values, 20 = round 1's kernel) and the default bench at 512 slots
 O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_exact.py tests/test_gpu_e2e_candidates.py tests/test_gpu_demod.py tests/test_gpu_golden.py tests/test_gpu_configs.py tests/test_gpu_lifecycle.py -x -q -m gpu 2>&1 | tail -5
 for v in ${VARIANTS:-0 0}; do
