@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
     ap.add_argument("--verify", type=int, default=8, help="slots (spread over the whole range) checked against the oracle after the timed region")
+    ap.add_argument("--no-spans", action="store_true", help="diagnostic: no HIP timing events around the kernels (roofline fields are then empty)")
+    ap.add_argument("--host-timing", action="store_true", help="print the host time spent inside each asynchronous call of a step (stderr)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,11 +146,16 @@ def main():
     t_setup = time.time() - t_setup
 
 
+    host_t = []                                        # --host-timing: seconds the host spends inside each (asynchronous) call
     def step(k):
+        a = time.perf_counter()
         ctx.ring_commit_all(SLOT_SAMPLES, IQ_LEN)     # the slot's IQ is already in HBM: bookkeeping only
+        b = time.perf_counter()
         ctx.process()                                  # batched NCO mix + polyphase decimate, all slots
+        c_ = time.perf_counter()
         ctx.slot_boundary("FT8", 15 * (k + 2))         # batched peak-normalise + int16 (+ sync); frames swap; with N > 1 the call
                                                        # waits for this GPU's stream and all-reduces the frame count over RCCL
+        host_t.append((b - a, c_ - b, time.perf_counter() - c_))
     def barrier():
         ctx.synchronize()
         torch.cuda.synchronize()
@@ -160,13 +167,16 @@ def main():
         step(k)
     barrier()
     ctx.reset_stats()
-    ctx.set_timing(True)                  # HIP events on the context stream around every kernel
+    ctx.set_timing(not args.no_spans)     # HIP events on the context stream around every kernel
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
     barrier()
     dt = time.perf_counter() - t0
     ctx.set_timing(False)
+    if args.host_timing and rank == 0:
+        for k, (ta, tb, tc) in enumerate(host_t[args.warmup:]):
+            print("host step %d: ring_commit_all %.3f ms, process %.3f ms, slot_boundary %.3f ms" % (k, ta * 1e3, tb * 1e3, tc * 1e3), file=sys.stderr)
     st = ctx.stats()
     if world > 1:
         assert st["rendezvous_calls"] == args.steps and st["rendezvous_frames"] == S * world, st

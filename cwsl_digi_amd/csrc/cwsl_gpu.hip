@@ -44,6 +44,10 @@ constexpr int kFinThreads = 256;
 constexpr int kCkptStride = cwslg::kCk;   // blocks between phasor checkpoints
 constexpr size_t kStageHalf = 4u << 20;    // pinned staging PER RECEIVER: two halves of 4 MiB, allocated at the receiver's first host push
 constexpr int kWorkBufs = 8;
+// Events that only order device work or tell the host that a descriptor buffer is free again: no system-scope fence (a fenced event
+// behind the last sync kernel of a slot cost a 0.3 ms L2 write-back before the next launch could start).  Host-visible RESULTS are
+// always fetched behind hipStreamSynchronize, which fences.
+constexpr unsigned kOrderEvent = hipEventDisableTiming | hipEventDisableSystemFence;
 constexpr int kCopyStreams = 4;
 
 // Host-push staging of one receiver.  The reference has one thread per Receiver (Receiver.hpp:167); each of them gets its own
@@ -155,6 +159,7 @@ struct Channel {
 
 struct WorkBuf {
     void *h = nullptr;                 // pinned
+    void *h_dev = nullptr;             // the same memory as the device addresses it
     void *d = nullptr;
     size_t bytes = 0;
     hipEvent_t done = nullptr;
@@ -176,6 +181,7 @@ struct cwslg_ctx {
     int cu_count = 256;
     int order_override = 0;            // CWSLG_ITEM_ORDER=1 channel-major, 2 tile-major (A/B); 0 = by topology
     bool exact = false;                // cwslg_set_exact: reference-order arithmetic (bit-exact, slower)
+    bool upload_by_dma = false;        // CWSLG_UPLOAD=dma: descriptors through hipMemcpyAsync as in round 1 (measured alternative)
     int demod_variant = 0;             // CWSLG_DEMOD_VARIANT: 0 = one workgroup per tile (default); measured alternatives: 1 persistent +
                                        // prefetch, 2 persistent loop, 4..7 FIR on the matrix cores (192 kHz); 9..11 memory-traffic probe
     hipStream_t stream = nullptr;
@@ -199,6 +205,7 @@ struct cwslg_ctx {
     // launch descriptors
     WorkBuf wb[kWorkBufs];
     int wb_next = 0;
+    size_t wb_largest = 0;
     // stats / timing
     cwslg_stats stats{};
     bool timing = false;
@@ -260,16 +267,39 @@ WorkBuf *acquire_workbuf(cwslg_ctx *c, size_t bytes)
         w.in_flight = false;
     }
     if (w.bytes < bytes) {
+        // hipFree / hipHostFree wait for the device: a buffer that has to grow costs the host its lead over the GPU (the next launch
+        // then starts only after the queue has drained and the host has prepared it: ~0.3 ms of idle GPU per slot at 4096 slots when
+        // requests of three sizes rotated over the eight buffers).  So every (re)allocation takes the largest size seen so far and the
+        // pool stops growing after its first revolution.
         if (w.h) hipHostFree(w.h);
         if (w.d) hipFree(w.d);
-        size_t nb = std::max<size_t>(bytes, 64 << 10);
+        size_t nb = std::max<size_t>(std::max(bytes, c->wb_largest), 64 << 10);
         nb = (nb + 4095) & ~size_t(4095);
+        c->wb_largest = nb;
         if (hipHostMalloc(&w.h, nb, hipHostMallocDefault) != hipSuccess) return nullptr;
+        if (hipHostGetDevicePointer(&w.h_dev, w.h, 0) != hipSuccess) w.h_dev = nullptr;
         if (hipMalloc(&w.d, nb) != hipSuccess) return nullptr;
         w.bytes = nb;
     }
-    if (!w.done) hipEventCreateWithFlags(&w.done, hipEventDisableTiming);
+    if (!w.done) hipEventCreateWithFlags(&w.done, kOrderEvent);
     return &w;
+}
+
+// Descriptors go host -> device through a COPY KERNEL on the compute queue, not through hipMemcpyAsync: a DMA-engine copy queued
+// behind a kernel makes the runtime resolve the cross-engine dependency on the host, which keeps the host from running ahead of the
+// GPU -- every launch sequence then starts only after the previous kernel has finished and the GPU idles for the host's preparation
+// time (rocprofv3 timeline at 4096 slots: 0.33 ms between the last sync kernel of a slot and the next demod launch).
+__global__ void upload_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, unsigned n16)
+{
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+hipError_t upload_workbuf(cwslg_ctx *c, WorkBuf *w, size_t bytes)
+{
+    if (!w->h_dev || c->upload_by_dma) return hipMemcpyAsync(w->d, w->h, bytes, hipMemcpyHostToDevice, c->stream);
+    const unsigned n16 = (unsigned)((bytes + 15) / 16);                  // buffers are sized in 4 KB steps
+    hipLaunchKernelGGL(upload_kernel, dim3((n16 + 255) / 256), dim3(256), 0, c->stream, (uint4 *)w->d, (const uint4 *)w->h_dev, n16);
+    return hipGetLastError();
 }
 
 void span_begin(cwslg_ctx *c, int kind, hipEvent_t *a, hipEvent_t *b)
@@ -344,7 +374,7 @@ int launch_phasor_jobs(cwslg_ctx *c, const std::vector<PhasorJob> &jobs)
     WorkBuf *w = acquire_workbuf(c, jobs.size() * sizeof(PhasorJob));
     if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
     std::memcpy(w->h, jobs.data(), jobs.size() * sizeof(PhasorJob));
-    HIPCHK(c, hipMemcpyAsync(w->d, w->h, jobs.size() * sizeof(PhasorJob), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, upload_workbuf(c, w, jobs.size() * sizeof(PhasorJob)));
     const int n = (int)jobs.size();
     unsigned max_ckpt = 0;
     for (const PhasorJob &j : jobs) max_ckpt = std::max(max_ckpt, j.n_ckpt);
@@ -428,7 +458,7 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     WorkBuf *w = acquire_workbuf(c, works.size() * sizeof(ChanWork));
     if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
     std::memcpy(w->h, works.data(), works.size() * sizeof(ChanWork));
-    HIPCHK(c, hipMemcpyAsync(w->d, w->h, works.size() * sizeof(ChanWork), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, upload_workbuf(c, w, works.size() * sizeof(ChanWork)));
     const bool exact2 = c->exact && c->demod_variant != 20;
     const bool small_tile = !c->exact && c->demod_variant == 15 && D == 16;     // 192-output tiles: 31 KB of LDS, five workgroups per CU
     const int tile = exact2 ? kTileExact : (small_tile ? 192 : kTile);
@@ -655,7 +685,7 @@ int process_locked(cwslg_ctx *c)
         WorkBuf *w = acquire_workbuf(c, kv.second.size() * sizeof(TransWork));
         if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
         std::memcpy(w->h, kv.second.data(), kv.second.size() * sizeof(TransWork));
-        HIPCHK(c, hipMemcpyAsync(w->d, w->h, kv.second.size() * sizeof(TransWork), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, upload_workbuf(c, w, kv.second.size() * sizeof(TransWork)));
         const dim3 grid((unsigned)kv.second.size());
         const float *taps = (const float *)c->d_taps[fs];
         if (D == 16) hipLaunchKernelGGL(demod_transition_kernel<16>, grid, dim3(64), 0, c->stream, (const TransWork *)w->d, taps);
@@ -790,7 +820,7 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s,
     WorkBuf *w = acquire_workbuf(c, fin.size() * sizeof(FinWork));
     if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
     std::memcpy(w->h, fin.data(), fin.size() * sizeof(FinWork));
-    HIPCHK(c, hipMemcpyAsync(w->d, w->h, fin.size() * sizeof(FinWork), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, upload_workbuf(c, w, fin.size() * sizeof(FinWork)));
     const unsigned gx = (unsigned)((max_len + kFinThreads * 8 - 1) / (kFinThreads * 8));
     hipEvent_t ea, eb;
     span_begin(c, 1, &ea, &eb);
@@ -876,6 +906,7 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
     c->device = device_ordinal;
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *v = std::getenv("CWSLG_DEMOD_VARIANT")) c->demod_variant = std::atoi(v);
+    if (const char *v = std::getenv("CWSLG_UPLOAD")) c->upload_by_dma = std::strcmp(v, "dma") == 0;
     if (const char *v = std::getenv("CWSLG_FT4_DFT")) c->ft4_dft_valu = std::strcmp(v, "valu") == 0;
     if (const char *v = std::getenv("CWSLG_ITEM_ORDER")) c->order_override = std::atoi(v);
     if (const char *v = std::getenv("CWSLG_SYNC_VARIANT")) c->sync_variant = std::atoi(v);
@@ -886,7 +917,7 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
         if (hipStreamCreateWithFlags(&c->copy_stream[k], hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
         hipEventCreateWithFlags(&c->copy_done[k], hipEventDisableTiming);
     }
-    hipEventCreateWithFlags(&c->demod_done, hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->demod_done, kOrderEvent);
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
     hipEventCreateWithFlags(&c->sync2d_done, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->cand_done, hipEventDisableTiming);
