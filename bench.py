@@ -153,10 +153,16 @@ def main():
         b = time.perf_counter()
         ctx.process()                                  # batched NCO mix + polyphase decimate, all slots
         c_ = time.perf_counter()
-        ctx.slot_boundary("FT8", 15 * (k + 2))         # batched peak-normalise + int16 (+ sync); frames swap; with N > 1 the call
-                                                       # waits for this GPU's stream and all-reduces the frame count over RCCL
+        if world > 1:
+            # the rendezvous of the PREVIOUS boundary runs now, while this slot's demod launch (queued just above) keeps the GPU
+            # busy: wait for that boundary's kernels, all-reduce the frame count over RCCL; then queue this boundary's work
+            ctx.slot_boundary_end()
+            ctx.slot_boundary_begin("FT8", 15 * (k + 2))
+        else:
+            ctx.slot_boundary("FT8", 15 * (k + 2))     # batched peak-normalise + int16 (+ sync); frames swap
         host_t.append((b - a, c_ - b, time.perf_counter() - c_))
     def barrier():
+        ctx.slot_boundary_end()                        # (N > 1) the last boundary's rendezvous
         ctx.synchronize()
         torch.cuda.synchronize()
         if world > 1:

@@ -113,7 +113,7 @@ ABI_SYMBOLS = [
     "cwslg_abi_version", "cwslg_create", "cwslg_destroy", "cwslg_strerror", "cwslg_last_error",
     "cwslg_set_scale_factors", "cwslg_set_exact", "cwslg_receiver_open", "cwslg_receiver_close", "cwslg_push_iq",
     "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_parse_decoder_line", "cwslg_channel_open_line", "cwslg_channel_open", "cwslg_channel_close", "cwslg_channel_tune", "cwslg_channel_tune_ex",
-    "cwslg_channel_info", "cwslg_process", "cwslg_slot_boundary", "cwslg_slot_boundary_channel",
+    "cwslg_channel_info", "cwslg_process", "cwslg_slot_boundary", "cwslg_slot_boundary_begin", "cwslg_slot_boundary_end", "cwslg_slot_boundary_channel",
     "cwslg_set_boundary_rendezvous", "cwslg_rccl_unique_id", "cwslg_rccl_init",
     "cwslg_enable_long_sync", "cwslg_fetch_wspr_candidates", "cwslg_fetch_fst4w_candidates", "cwslg_long_sync_debug_fetch",
     "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_write_wav", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
@@ -182,6 +182,8 @@ def load_library(build_if_missing=True):
     L.cwslg_channel_info.argtypes = [vp, i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_size_t)]
     L.cwslg_process.argtypes = [vp]
     L.cwslg_slot_boundary.argtypes = [vp, i32, u64]
+    L.cwslg_slot_boundary_begin.argtypes = [vp, i32, u64]
+    L.cwslg_slot_boundary_end.argtypes = [vp]
     L.cwslg_slot_boundary_channel.argtypes = [vp, i32, u64]
     L.cwslg_synchronize.argtypes = [vp]
     L.cwslg_fetch_frame.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(u64), C.POINTER(C.c_size_t), C.POINTER(f32)]
@@ -390,6 +392,15 @@ class Context:
         else:
             g = int(group)
         self._chk(self.L.cwslg_slot_boundary(self.h, g, int(epoch_s)))
+
+    def slot_boundary_begin(self, group, epoch_s):
+        """First half of slot_boundary: queue the boundary's device work, return at once (see cwslg_slot_boundary_begin)."""
+        g = (GROUPS[group] if group in GROUPS else _MODE_GROUP[group]) if isinstance(group, str) else int(group)
+        self._chk(self.L.cwslg_slot_boundary_begin(self.h, g, int(epoch_s)))
+
+    def slot_boundary_end(self):
+        """Second half: wait for that boundary's kernels and run the rendezvous."""
+        self._chk(self.L.cwslg_slot_boundary_end(self.h))
 
     def set_boundary_rendezvous(self, fn):
         """Install the multi-GPU slot-boundary rendezvous: fn(group, epoch_s, frames_local) -> frames over all

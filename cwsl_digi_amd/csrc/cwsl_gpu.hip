@@ -229,6 +229,11 @@ struct cwslg_ctx {
     void *rdv_user = nullptr;
     ncclComm_t rccl_comm = nullptr;
     uint64_t *d_rdv = nullptr, *h_rdv = nullptr;   // [2]: local count, sum over ranks
+    // cwslg_slot_boundary_begin / _end: the rendezvous of a boundary whose device work is queued but not yet waited for
+    bool rdv_pending = false;
+    int rdv_group = 0;
+    uint64_t rdv_epoch = 0, rdv_mine = 0;
+    hipEvent_t rdv_ready = nullptr;                // behind the boundary's finalise (+ sync) kernels on the context stream
 };
 
 namespace {
@@ -967,6 +972,7 @@ void cwslg_destroy(cwslg_ctx *c)
         if (c->copy_done[k]) hipEventDestroy(c->copy_done[k]);
     }
     if (c->demod_done) hipEventDestroy(c->demod_done);
+    if (c->rdv_ready) hipEventDestroy(c->rdv_ready);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     for (hipEvent_t e : {c->sync2d_done, c->cand_done, c->sync_tail}) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -1585,6 +1591,57 @@ int cwslg_slot_boundary(cwslg_ctx *c, int group, uint64_t epoch_s)
     }
     uint64_t total = mine;                                  // ... and after the rendezvous so are every other GPU's
     const int rc = fn(user, group, epoch_s, mine, &total);
+    std::lock_guard<std::mutex> g(c->mu);
+    if (rc < 0) return fail(c, rc, "slot-boundary rendezvous failed (%d)", rc);
+    c->stats.rendezvous_calls++;
+    c->stats.rendezvous_frames = total;
+    return CWSLG_OK;
+}
+
+// The same boundary in two halves, for a host that keeps the GPU busy across boundaries (bench.py with N > 1; a real-time host has
+// 15 s between boundaries and uses cwslg_slot_boundary).  _begin queues the boundary's device work and returns; the host pushes and
+// queues the NEXT slot's demodulation; _end then waits for the boundary's own kernels only (an event behind them, not the stream) and
+// runs the rendezvous -- so the all-reduce and the host's preparation overlap the next slot's demod launch instead of idling the GPU.
+// Frames and candidates of the epoch must not be fetched before _end has returned.
+int cwslg_slot_boundary_begin(cwslg_ctx *c, int group, uint64_t epoch_s)
+{
+    if (!c || group < 0 || group >= CWSLG_NUM_GROUPS) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (c->rdv_pending) return fail(c, CWSLG_ERR_ARG, "cwslg_slot_boundary_begin: the previous boundary has not been ended");
+    hipSetDevice(c->device);
+    std::vector<int> ids;
+    for (size_t k = 0; k < c->chans.size(); ++k)
+        if (c->chans[k].open && c->chans[k].group == group) ids.push_back((int)k);
+    uint64_t mine = 0;
+    int rc = boundary_locked(c, ids, epoch_s, &mine);
+    if (rc) return rc;
+    if (!c->rdv_fn) return CWSLG_OK;
+    if (!c->rdv_ready) HIPCHK(c, hipEventCreateWithFlags(&c->rdv_ready, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->rdv_ready, c->stream));
+    c->rdv_pending = true;
+    c->rdv_group = group; c->rdv_epoch = epoch_s; c->rdv_mine = mine;
+    return CWSLG_OK;
+}
+
+int cwslg_slot_boundary_end(cwslg_ctx *c)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    cwslg_rendezvous_fn fn = nullptr;
+    void *user = nullptr;
+    int group = 0;
+    uint64_t epoch = 0, mine = 0;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        if (!c->rdv_pending) return CWSLG_OK;
+        hipSetDevice(c->device);
+        HIPCHK(c, hipEventSynchronize(c->rdv_ready));          // this GPU's frames of the epoch are final ...
+        fn = c->rdv_fn; user = c->rdv_user;
+        group = c->rdv_group; epoch = c->rdv_epoch; mine = c->rdv_mine;
+        c->rdv_pending = false;
+        if (!fn) return CWSLG_OK;
+    }
+    uint64_t total = mine;                                      // ... and after the rendezvous so are every other GPU's
+    const int rc = fn(user, group, epoch, mine, &total);
     std::lock_guard<std::mutex> g(c->mu);
     if (rc < 0) return fail(c, rc, "slot-boundary rendezvous failed (%d)", rc);
     c->stats.rendezvous_calls++;

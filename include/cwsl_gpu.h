@@ -161,6 +161,12 @@ int cwslg_process(cwslg_ctx *ctx);
  * per-Instance reaction to it (Instance.cpp:203-253): swap frames, stamp the new frame with epoch_s,
  * finalise (peak-normalise + int16) the finished one unless its start time is 0, restart the demodulator. */
 int cwslg_slot_boundary(cwslg_ctx *ctx, int group, uint64_t epoch_s);
+/* The same boundary in two halves, for a throughput host that keeps the GPU busy across boundaries (bench.py with N > 1): _begin queues
+ * the boundary's device work and returns; the host queues the next slot's demodulation; _end waits for the boundary's own kernels
+ * (not for the stream) and runs the rendezvous, which thereby overlaps the next demod launch.  Without a rendezvous installed _end
+ * does nothing.  Do not fetch the epoch's frames or candidates before _end has returned; one boundary may be open at a time. */
+int cwslg_slot_boundary_begin(cwslg_ctx *ctx, int group, uint64_t epoch_s);
+int cwslg_slot_boundary_end(cwslg_ctx *ctx);
 /* Same for a single channel (one SyncPredicate). */
 int cwslg_slot_boundary_channel(cwslg_ctx *ctx, int ch_id, uint64_t epoch_s);
 int cwslg_synchronize(cwslg_ctx *ctx);

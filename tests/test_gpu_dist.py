@@ -28,7 +28,7 @@ def _slot_freq(gs):
     return -90000 + (gs * 4373) % 176000
 
 
-def _run_slots(ctx, slot_ids):
+def _run_slots(ctx, slot_ids, split=False):
     chans = []
     for gs in slot_ids:
         f = _slot_freq(gs)
@@ -40,12 +40,22 @@ def _run_slots(ctx, slot_ids):
     for gs, rx, ch in chans:
         f = _slot_freq(gs)
         ctx.push_synth(rx, 0xC0FFEE ^ gs, N, BLK, tones_hz=[f + 650.0, f + 1490.0], amp=2e4)
-    ctx.slot_boundary("FT8", 16)
+    if split:                                         # the boundary in two halves: the next slot's work is queued in between
+        ctx.slot_boundary_begin("FT8", 16)
+        with pytest.raises(Exception):
+            ctx.slot_boundary_begin("FT8", 17)        # one open boundary at a time
+        for gs, rx, ch in chans:
+            ctx.push_synth(rx, 0xBEEF ^ gs, 4 * BLK, BLK, tones_hz=[_slot_freq(gs) + 900.0], amp=1e4)
+        ctx.process()
+        ctx.slot_boundary_end()
+        ctx.slot_boundary_end()                       # nothing pending: no-op
+    else:
+        ctx.slot_boundary("FT8", 16)
     crcs = {gs: zlib.crc32(ctx.fetch_frame(ch)["i16"].tobytes()) for gs, rx, ch in chans}
     return first, ctx.stats(), crcs
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, split=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -55,19 +65,22 @@ def _worker(rank, world, port, q):
     with P.Context(0) as ctx:                         # both ranks on GPU 0: the test box has one
         shard.install_rendezvous(ctx)
         mine = list(shard.slots_of_rank(TOTAL, rank, world))
-        first, st, crcs = _run_slots(ctx, mine)
+        first, st, crcs = _run_slots(ctx, mine, split)
     gathered = [None] * world
     dist.all_gather_object(gathered, crcs)
     q.put((rank, first, st["rendezvous_calls"], st["rendezvous_frames"], st["frames_emitted"], gathered))
     dist.destroy_process_group()
 
 
-def test_two_ranks_rendezvous_through_the_c_abi():
+@pytest.mark.parametrize("split", [False, True])
+def test_two_ranks_rendezvous_through_the_c_abi(split):
+    """split: cwslg_slot_boundary_begin / _end with the next slot's demodulation queued between the halves (what bench.py does
+    for N > 1) -- same frames, same counts."""
     world = 2
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()
-    ps = [mpc.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    ps = [mpc.Process(target=_worker, args=(r, world, port, q, split)) for r in range(world)]
     for p in ps:
         p.start()
     res = [q.get(timeout=300) for _ in ps]
@@ -95,3 +108,7 @@ def test_builtin_rccl_rendezvous_world_1():
         ctx.rccl_init(uid, 0, 1)
         first, st, crcs = _run_slots(ctx, range(3))
         assert first == 0 and st["rendezvous_calls"] == 2 and st["rendezvous_frames"] == 3 == st["frames_emitted"]
+    with P.Context(0) as ctx:                          # the two-halves form: the all-reduce runs beside the next slot's demod launch
+        ctx.rccl_init(P.rccl_unique_id(), 0, 1)
+        first2, st2, crcs2 = _run_slots(ctx, range(3), split=True)
+        assert first2 == 0 and st2["rendezvous_calls"] == 2 and st2["rendezvous_frames"] == 3 and crcs2 == crcs
