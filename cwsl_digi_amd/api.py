@@ -13,7 +13,11 @@ import numpy as np
 from . import build as _build
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.environ.get("CWSLG_LIB") or os.path.join(_HERE, "lib", "libcwslgpu.so")   # CWSLG_LIB: A/B of kernel builds
+# CWSLG_LIB: another build of the library -- a path, or "lab" for lib/libcwslgpu_lab.so (the measured alternative kernels and the
+# environment switches that select them; the product library has neither)
+_LIB_PATH = os.environ.get("CWSLG_LIB") or os.path.join(_HERE, "lib", "libcwslgpu.so")
+if _LIB_PATH == "lab":
+    _LIB_PATH = os.path.join(_HERE, "lib", "libcwslgpu_lab.so")
 
 STATUS_NAMES = {
     0: "OK", -1: "ERR_RATIO", -2: "ERR_BAND_LOW", -3: "ERR_BAND_HIGH", -4: "ERR_NOMEM", -5: "ERR_MODE",
@@ -118,7 +122,7 @@ ABI_SYMBOLS = [
     "cwslg_enable_long_sync", "cwslg_fetch_wspr_candidates", "cwslg_fetch_fst4w_candidates", "cwslg_long_sync_debug_fetch",
     "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_write_wav", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
     "cwslg_enable_sync", "cwslg_fetch_candidates", "cwslg_set_ft4_syncmin", "cwslg_enable_ft4_coherent", "cwslg_fetch_ft4_sync", "cwslg_sync_debug_fetch", "cwslg_get_stats", "cwslg_reset_stats",
-    "cwslg_set_timing", "cwslg_stream", "cwslg_channel_constants", "cwslg_phasor_checkpoint_stride", "cwslg_channel_phasor_checkpoints",
+    "cwslg_set_timing", "cwslg_demod_kernel_name", "cwslg_stream", "cwslg_channel_constants", "cwslg_phasor_checkpoint_stride", "cwslg_channel_phasor_checkpoints",
     "cwslg_slot_clock_next", "cwslg_pool_sizing", "cwslg_find_band", "cwslg_parse_decode_line",
     "cwslg_decoder_block_bytes", "cwslg_decoder_block_field", "cwslg_fill_decoder_block", "cwslg_decoder_route", "cwslg_decoder_command",
 ]
@@ -141,7 +145,7 @@ def load_library(build_if_missing=True):
         return _lib
     if not build_if_missing and not os.path.isfile(_LIB_PATH):
         raise CwslGpuError(-7, f"{_LIB_PATH} not built")
-    if build_if_missing and not os.environ.get("CWSLG_LIB"):
+    if build_if_missing and os.environ.get("CWSLG_LIB", "lab") == "lab":
         _build.build()          # returns at once when the library is newer than every source; serialised by a file lock
     try:
         # If torch is (or will be) in the process, let it load ITS libamdhip64 first: both copies carry
@@ -158,6 +162,7 @@ def load_library(build_if_missing=True):
     L.cwslg_last_error.argtypes = [vp]; L.cwslg_last_error.restype = C.c_char_p
     L.cwslg_set_scale_factors.argtypes = [vp, f32, f32]
     L.cwslg_set_exact.argtypes = [vp, i32]
+    L.cwslg_demod_kernel_name.argtypes = [vp]; L.cwslg_demod_kernel_name.restype = C.c_char_p
     L.cwslg_set_boundary_rendezvous.argtypes = [vp, RENDEZVOUS_FN, vp]
     L.cwslg_rccl_unique_id.argtypes = [vp]
     L.cwslg_rccl_init.argtypes = [vp, vp, i32, i32]
@@ -573,6 +578,10 @@ class Context:
     def set_exact(self, on=True):
         """Reference-order arithmetic: float and int16 frames bit-identical to the compiled reference."""
         self._chk(self.L.cwslg_set_exact(self.h, 1 if on else 0))
+
+    def demod_kernel_name(self):
+        """Name of the kernel the most recent demod launch ran (bench.py's roofline.kernel)."""
+        return (self.L.cwslg_demod_kernel_name(self.h) or b"").decode()
 
     def stream(self):
         return self.L.cwslg_stream(self.h)

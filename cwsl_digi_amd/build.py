@@ -11,6 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcwslgpu.so")
+# -DCWSLG_LAB=1: the measured alternatives of every kernel and the environment switches that select them (scripts/, A/B tests).
+# The product library above carries one kernel per job and reads no such switch.
+LAB_LIB = os.path.join(LIBDIR, "libcwslgpu_lab.so")
 BINDIR = os.path.join(HERE, "bin")
 SKIMMER = os.path.join(BINDIR, "cwsl_gpu_skimmer")
 
@@ -45,7 +48,7 @@ def _source_hash():
 
 
 def _stale():
-    if not os.path.isfile(LIB) or not os.path.isfile(SKIMMER) or not os.path.isfile(HASHFILE):
+    if not os.path.isfile(LIB) or not os.path.isfile(LAB_LIB) or not os.path.isfile(SKIMMER) or not os.path.isfile(HASHFILE):
         return True
     return open(HASHFILE).read().strip() != _source_hash()
 
@@ -56,6 +59,8 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
+        if os.path.isfile(LIB) and not force:      # a deployed tree without the toolchain: the library it came with is the product
+            return LIB
         raise RuntimeError("hipcc not found: libcwslgpu.so cannot be built (and there is no CPU fallback)")
     os.makedirs(LIBDIR, exist_ok=True)
     # one builder at a time (N ranks may import together); the library appears atomically
@@ -64,18 +69,27 @@ def build(force=False, verbose=False):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and not _stale():          # another process built it while this one waited
             return LIB
-        tmp = LIB + ".tmp.%d" % os.getpid()
-        cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp] + sources() + ["-ldl"]
-        if verbose:
-            print(" ".join(cmd))
+        procs = []
+        for lib, extra in ((LIB, []), (LAB_LIB, ["-DCWSLG_LAB=1"])):
+            tmp = lib + ".tmp.%d" % os.getpid()
+            cmd = [hipcc] + HIPCC_FLAGS + extra + ["-o", tmp] + sources() + ["-ldl"]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((subprocess.Popen(cmd), tmp, lib, cmd))
         try:
-            subprocess.check_call(cmd)
-            os.replace(tmp, LIB)
+            for pr, tmp, lib, cmd in procs:
+                if pr.wait() != 0:
+                    raise subprocess.CalledProcessError(pr.returncode, cmd)
+            for pr, tmp, lib, cmd in procs:
+                os.replace(tmp, lib)
             with open(HASHFILE, "w") as fh:
                 fh.write(_source_hash() + "\n")
         finally:
-            if os.path.exists(tmp):
-                os.remove(tmp)
+            for pr, tmp, lib, cmd in procs:
+                if pr.poll() is None:
+                    pr.kill()
+                if os.path.exists(tmp):
+                    os.remove(tmp)
         build_skimmer(force=True, verbose=verbose)
     return LIB
 

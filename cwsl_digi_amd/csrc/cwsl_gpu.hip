@@ -23,6 +23,13 @@
 #include <tuple>
 #include <vector>
 
+// -DCWSLG_LAB=1 builds libcwslgpu_lab.so: the measured alternatives of every kernel (round-1/-2 forms, matrix-core and persistent
+// variants, memory-traffic probes) and the environment switches that select them.  The product library has ONE kernel per job and
+// no environment-dependent arithmetic.
+#ifndef CWSLG_LAB
+#define CWSLG_LAB 0
+#endif
+
 #include "../../include/cwsl_gpu.h"
 #include "demod_kernels.hpp"
 #include "host_dsp.hpp"
@@ -38,7 +45,8 @@ namespace cwslg {
 
 // ---------------------------------------------------------------------------------------------
 constexpr int kTile = 256;             // outputs per demod workgroup
-constexpr int kTileExact = 248;        // ... of demod_exact2_kernel (124 of 128 lanes busy; four tiles of 39.7 KB per CU)
+constexpr int kTileExact = 256;        // ... of demod_exact3_kernel (two outputs per thread, 128 threads; four tiles of 38.5 KB per CU)
+constexpr int kTileExact2 = 248;       // ... of demod_exact2_kernel, lab build (124 of 128 lanes busy; four tiles of 39.7 KB per CU)
 constexpr int kDemodThreads = 256;
 constexpr int kFinThreads = 256;
 constexpr int kCkptStride = cwslg::kCk;   // blocks between phasor checkpoints
@@ -191,6 +199,8 @@ struct cwslg_ctx {
     std::vector<Receiver> rxs;
     std::vector<Channel> chans;
     std::map<uint32_t, float *> d_taps;            // per sample rate
+    std::map<uint32_t, float *> d_taps2;           // the same taps interleaved for demod_exact3_kernel: [33][D][2] = (h[m + D n], h[m + D (n-1)])
+    const char *demod_kernel_name = "";           // the demod kernel the last launch used (cwslg_demod_kernel_name)
     std::map<uint32_t, std::vector<float>> h_taps;
     std::map<std::tuple<uint32_t, int32_t, int, size_t>, PhasorTable> phasors;
     std::vector<decltype(phasors)::key_type> phasor_todo;
@@ -369,6 +379,19 @@ int ensure_taps(cwslg_ctx *c, uint32_t fs)
     HIPCHK(c, hipMalloc(&d, h.size() * sizeof(float)));
     HIPCHK(c, hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     c->d_taps[fs] = d;
+    // demod_exact3_kernel reads the taps as wave-uniform PAIRS: step n of a thread's two adjacent outputs uses tap block n for the
+    // even one and n - 1 for the odd one; blocks -1 and 32 do not exist (their addends are masked in the kernel): zeros
+    const size_t D = h.size() / 32;
+    std::vector<float> h2(33 * D * 2, 0.0f);
+    for (size_t n = 0; n < 33; ++n)
+        for (size_t m = 0; m < D; ++m) {
+            if (n <= 31) h2[(n * D + m) * 2] = h[m + D * n];
+            if (n >= 1) h2[(n * D + m) * 2 + 1] = h[m + D * (n - 1)];
+        }
+    float *d2 = nullptr;
+    HIPCHK(c, hipMalloc(&d2, h2.size() * sizeof(float)));
+    HIPCHK(c, hipMemcpy(d2, h2.data(), h2.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->d_taps2[fs] = d2;
     c->h_taps[fs] = std::move(h);
     return CWSLG_OK;
 }
@@ -464,21 +487,34 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
     std::memcpy(w->h, works.data(), works.size() * sizeof(ChanWork));
     HIPCHK(c, upload_workbuf(c, w, works.size() * sizeof(ChanWork)));
-    const bool exact2 = c->exact && c->demod_variant != 20;
+    // product build: ONE kernel per job -- demod_exact3_kernel in exact mode (the default), demod_kernel in fast mode.  The measured
+    // alternatives (CWSLG_DEMOD_VARIANT) exist in the lab build only (-DCWSLG_LAB=1 -> libcwslgpu_lab.so).
+    int tile = c->exact ? kTileExact : kTile;
+#if CWSLG_LAB
     const bool small_tile = !c->exact && c->demod_variant == 15 && D == 16;     // 192-output tiles: 31 KB of LDS, five workgroups per CU
-    const int tile = exact2 ? kTileExact : (small_tile ? 192 : kTile);
+    if (c->exact && c->demod_variant == 20) tile = kTile;                       // round 1's exact kernel: one output per thread
+    if (c->exact && c->demod_variant == 21) tile = kTileExact2;
+    if (small_tile) tile = 192;
+#endif
     const int tiles_n = (int)((max_blocks + tile - 1) / tile);
     const int tiles_x = tile_major ? -tiles_n : tiles_n;        // sign selects the work-item order (demod_kernels.hpp)
     const long long total = (long long)tiles_n * (long long)works.size();
     const long long per_xcd = (total + 7) / 8;
     hipEvent_t ea, eb;
     span_begin(c, 0, &ea, &eb);
+    bool launched = false;
+#if CWSLG_LAB
+    launched = true;
     if (c->exact && c->demod_variant == 20) {      // CWSLG_DEMOD_VARIANT=20: the round-1 exact kernel, one output per thread (same bits)
+        c->demod_kernel_name = "demod_exact_kernel";
         hipLaunchKernelGGL((demod_exact_kernel<D, kTile, kDemodThreads>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
                            c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
-    } else if (c->exact) {
-        hipLaunchKernelGGL((demod_exact2_kernel<D, kTileExact, 128>), dim3((unsigned)(per_xcd * 8)), dim3(128), 0,
+    } else if (c->exact && c->demod_variant == 21) {   // round 2's exact kernel (taps through broadcast vector loads)
+        c->demod_kernel_name = "demod_exact2_kernel";
+        hipLaunchKernelGGL((demod_exact2_kernel<D, kTileExact2, 128>), dim3((unsigned)(per_xcd * 8)), dim3(128), 0,
                            c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
+    } else if (c->exact) {
+        launched = false;
     } else if (c->demod_variant == 1 || c->demod_variant == 2) {
         // persistent variants (measured alternatives): as many workgroups as are resident at once
         int occ = 0;
@@ -489,6 +525,7 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
         if (const char *v = std::getenv("CWSLG_PERSIST_WGS_PER_CU")) occ = std::max(1, std::atoi(v));
         long long wgs = std::min<long long>((long long)c->cu_count * occ, per_xcd * 8);
         wgs = (wgs + 7) / 8 * 8;
+        c->demod_kernel_name = loop ? "demod_kernel<persistent loop>" : "demod_kernel<persistent prefetch>";
         if (loop)
             hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, 2>), dim3((unsigned)wgs), dim3(kDemodThreads), 0,
                                c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
@@ -501,16 +538,19 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
             hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0, c->stream, (const ChanWork *)w->d,
                                (const float *)c->d_taps[fs], tiles_x, (int)works.size());
         };
+        c->demod_kernel_name = "demod_mfma1p_kernel";
         if (c->demod_variant == 4) go(demod_mfma1p_kernel<kTile, kDemodThreads, 4>);
         else if (c->demod_variant == 5) go(demod_mfma1p_kernel<kTile, kDemodThreads, 5>);
         else if (c->demod_variant == 6) go(demod_mfma1p_kernel<kTile, kDemodThreads, 6>);
         else go(demod_mfma1p_kernel<kTile, kDemodThreads, 7>);
     } else if (small_tile) {
+        c->demod_kernel_name = "demod_kernel<16,192,256,0>";
         if constexpr (D == 16)
             hipLaunchKernelGGL((demod_kernel<16, 192, kDemodThreads, 0>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
                                c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
     } else if (c->demod_variant == 8 && D == 16) {
         // the dense product on the bf16 matrix cores at fp32 accuracy (three-way split operands)
+        c->demod_kernel_name = "demod_mfma_bf16_kernel";
         hipLaunchKernelGGL((demod_mfma_bf16_kernel<kTile, kDemodThreads, 4>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0, c->stream,
                            (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
     } else if (c->demod_variant >= 9 && c->demod_variant <= 14) {
@@ -518,6 +558,7 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
             hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0, c->stream, (const ChanWork *)w->d,
                                (const float *)c->d_taps[fs], tiles_x, (int)works.size());
         };
+        c->demod_kernel_name = "ring_probe_kernel";
         if (c->demod_variant == 9) go(ring_probe_kernel<D, kTile, kDemodThreads, 0>);
         else if (c->demod_variant == 10) go(ring_probe_kernel<D, kTile, kDemodThreads, 1>);
         else if (c->demod_variant == 11) go(ring_probe_kernel<D, kTile, kDemodThreads, 2>);
@@ -525,6 +566,15 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
         else if (c->demod_variant == 13) go(ring_probe_kernel<D, kTile, kDemodThreads, 4>);
         else go(ring_probe_kernel<D, kTile, kDemodThreads, 5>);
     } else {
+        launched = false;
+    }
+#endif
+    if (!launched && c->exact) {
+        c->demod_kernel_name = D == 16 ? "demod_exact3_kernel<16,256,128>" : D == 8 ? "demod_exact3_kernel<8,256,128>" : "demod_exact3_kernel<4,256,128>";
+        hipLaunchKernelGGL((demod_exact3_kernel<D, kTileExact, 128>), dim3((unsigned)(per_xcd * 8)), dim3(128), 0,
+                           c->stream, (const ChanWork *)w->d, (const float *)c->d_taps2[fs], tiles_x, (int)works.size());
+    } else if (!launched) {
+        c->demod_kernel_name = D == 16 ? "demod_kernel<16,256,256,0>" : D == 8 ? "demod_kernel<8,256,256,0>" : "demod_kernel<4,256,256,0>";
         hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, 0>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
                            c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
     }
@@ -565,12 +615,13 @@ int retarget_phasor(cwslg_ctx *c, Channel &ch, const std::tuple<uint32_t, int32_
     return CWSLG_OK;
 }
 
-// Checkpoints a launch may touch for blocks [q_first, q_first + n_blocks): the last tile is walked whole (kTile + 31
-// blocks from its first input block) and every lane of phase 0 reads one checkpoint whether it is used or not.
+// Checkpoints a launch may touch for blocks [q_first, q_first + n_blocks), whatever tile size T <= 256 the kernel walks them with: the
+// last tile starts at or before block q_first + n_blocks - 1, is walked whole (T + 31 blocks from its first input block), and every
+// lane of the phasor rebuild reads one checkpoint whether it is used or not (NCK = (T + 31 + 3)/4 + 1 of them from the tile's
+// first): the highest index is below (q_first + n_blocks + 2 T + 2)/4 + 1.
 inline size_t ckpt_need(long long q_first, unsigned n_blocks)
 {
-    const long long tiles = ((long long)n_blocks + kTile - 1) / kTile;
-    const long long last = std::max<long long>(0, q_first + tiles * kTile + 31);
+    const long long last = std::max<long long>(0, q_first + (long long)n_blocks + 2 * kTile + 2);
     return (size_t)(last / kCkptStride) + 4;
 }
 
@@ -910,6 +961,9 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
     std::unique_ptr<cwslg_ctx, void (*)(cwslg_ctx *)> c(new cwslg_ctx, cwslg_destroy);   // a failed create releases what it made
     c->device = device_ordinal;
     c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+#if CWSLG_LAB
+    // lab build only: the switches that select a measured alternative.  The product library reads no environment variable that
+    // changes a kernel or the order of its arithmetic.
     if (const char *v = std::getenv("CWSLG_DEMOD_VARIANT")) c->demod_variant = std::atoi(v);
     if (const char *v = std::getenv("CWSLG_UPLOAD")) c->upload_by_dma = std::strcmp(v, "dma") == 0;
     if (const char *v = std::getenv("CWSLG_FT4_DFT")) c->ft4_dft_valu = std::strcmp(v, "valu") == 0;
@@ -917,6 +971,7 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
     if (const char *v = std::getenv("CWSLG_SYNC_VARIANT")) c->sync_variant = std::atoi(v);
     if (const char *v = std::getenv("CWSLG_LONG_VARIANT")) c->long_variant = std::atoi(v);
     if (const char *v = std::getenv("CWSLG_COPY_ON_MAIN")) c->copy_on_main = std::atoi(v) != 0;
+#endif
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
     for (int k = 0; k < kCopyStreams; ++k) {
         if (hipStreamCreateWithFlags(&c->copy_stream[k], hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
@@ -955,6 +1010,7 @@ void cwslg_destroy(cwslg_ctx *c)
     }
     for (Receiver &rx : c->rxs) if (rx.d_ring) hipFree(rx.d_ring);
     for (auto &kv : c->d_taps) hipFree(kv.second);
+    for (auto &kv : c->d_taps2) hipFree(kv.second);
     for (auto &kv : c->phasors) if (kv.second.d_ckpt) hipFree(kv.second.d_ckpt);
     for (WorkBuf &w : c->wb) {
         if (w.h) hipHostFree(w.h);
@@ -1853,6 +1909,13 @@ int cwslg_reset_stats(cwslg_ctx *c)
     std::lock_guard<std::mutex> g(c->mu);
     c->stats = cwslg_stats{};
     return CWSLG_OK;
+}
+
+const char *cwslg_demod_kernel_name(cwslg_ctx *c)
+{
+    if (!c) return "";
+    std::lock_guard<std::mutex> g(c->mu);
+    return c->demod_kernel_name;
 }
 
 int cwslg_set_timing(cwslg_ctx *c, int enable)

@@ -1436,6 +1436,256 @@ __global__ __launch_bounds__(NT, 2) void demod_exact2_kernel(const ChanWork *__r
 }
 
 // ---------------------------------------------------------------------------------------------
+// Registers of demod_exact3_kernel's software pipeline, filled by hand-issued loads (see the kernel).
+typedef float v8f __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+template <int D>
+struct ExactBlock {                 // one block's D mixed samples and its mixer phase
+    // one 64-bit register pair per complex sample (ds_read_b64: the same LDS cycles per byte as ds_read_b128): hipcc reaches either
+    // word of a 64-bit operand through op_sel, but copies the fourth word of a 128-bit value into a fresh register first
+    v2f q[D];
+    v2f php;                        // the block's mixer phase: the row's pad slot
+    __device__ __forceinline__ v2f t(int m) const { return q[m]; }
+    __device__ __forceinline__ v2f ph() const { return php; }
+    __device__ __forceinline__ v2f phn() const { return v2f{-php.y, php.x}; }
+    __device__ __forceinline__ void issue(unsigned row_addr)
+    {
+#pragma unroll
+        for (int i = 0; i <= D; ++i)
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(i < D ? q[i] : php) : "v"(row_addr), "n"(8 * i) : "memory");
+    }
+};
+
+template <int D> struct ExactTaps;   // one tap row = D wave-uniform pairs (h[m + D n], h[m + D (n-1)]) in SGPRs
+template <>
+struct ExactTaps<16> {
+    v16f lo, hi;
+    __device__ __forceinline__ v2f pair(int m) const { return m < 8 ? v2f{lo[2 * m], lo[2 * m + 1]} : v2f{hi[2 * m - 16], hi[2 * m - 15]}; }
+    __device__ __forceinline__ void issue(const CWSLG_CONST float *row)
+    {
+        asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(lo) : "s"(row) : "memory");
+        asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(hi) : "s"(row) : "memory");
+    }
+};
+template <>
+struct ExactTaps<8> {
+    v16f lo;
+    __device__ __forceinline__ v2f pair(int m) const { return v2f{lo[2 * m], lo[2 * m + 1]}; }
+    __device__ __forceinline__ void issue(const CWSLG_CONST float *row)
+    {
+        asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(lo) : "s"(row) : "memory");
+    }
+};
+template <>
+struct ExactTaps<4> {
+    v8f lo;
+    __device__ __forceinline__ v2f pair(int m) const { return v2f{lo[2 * m], lo[2 * m + 1]}; }
+    __device__ __forceinline__ void issue(const CWSLG_CONST float *row)
+    {
+        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(lo) : "s"(row) : "memory");
+    }
+};
+// Wait for everything the wave has in flight on the LDS / scalar-memory counter; the tied operands make every later use of the
+// registers the hand-issued loads fill depend on this statement.
+__device__ __forceinline__ void exact_wait(ExactBlock<16> &b, ExactTaps<16> &h)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(b.q[0]), "+v"(b.q[1]), "+v"(b.q[2]), "+v"(b.q[3]), "+v"(b.q[4]), "+v"(b.q[5]), "+v"(b.q[6]), "+v"(b.q[7]),
+                   "+v"(b.q[8]), "+v"(b.q[9]), "+v"(b.q[10]), "+v"(b.q[11]), "+v"(b.q[12]), "+v"(b.q[13]), "+v"(b.q[14]), "+v"(b.q[15]),
+                   "+v"(b.php), "+s"(h.lo), "+s"(h.hi) :: "memory");
+}
+__device__ __forceinline__ void exact_wait(ExactBlock<8> &b, ExactTaps<8> &h)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(b.q[0]), "+v"(b.q[1]), "+v"(b.q[2]), "+v"(b.q[3]), "+v"(b.q[4]), "+v"(b.q[5]), "+v"(b.q[6]), "+v"(b.q[7]),
+                   "+v"(b.php), "+s"(h.lo) :: "memory");
+}
+__device__ __forceinline__ void exact_wait(ExactBlock<4> &b, ExactTaps<4> &h)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b.q[0]), "+v"(b.q[1]), "+v"(b.q[2]), "+v"(b.q[3]), "+v"(b.php), "+s"(h.lo) :: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------
+// demod_exact3_kernel: ProcessBlock's arithmetic, operation for operation (bit-identical frames), with the two outputs of a
+// thread computed side by side in the two halves of packed registers.
+//
+//   A thread owns outputs o (even) and o + 1.  Iterate() reads only Re of the even output's workspace slot and only Im of the odd
+//   one's (SSBD.hpp:131-134), and at step n block o + n feeds BOTH of them -- with tap block n for o, n - 1 for o + 1 -- through the
+//   SAME mixed samples t[m] and the same block phase.  So the running sums live transposed:
+//       sX = (Re sum_o, Re sum_{o+1}),  sY = (Im sum_o, Im sum_{o+1})
+//       sX += (t.x, t.x) * (h[m + D n], h[m + D (n-1)])        one v_pk_mul_f32 + one v_pk_add_f32, un-fused (:167-168)
+//       sY += (t.y, t.y) * (same tap pair)
+//   and the tap PAIR is wave-uniform: it comes from a host-interleaved table taps2[33][D][2] through the SCALAR cache into an SGPR
+//   pair that the packed multiply reads directly -- no vector-memory tap loads (exact2's four broadcast global_load_dwordx4 per step
+//   and wave kept the CU's texture-address path about as busy as its VALU), no tap VGPRs, no register shuffles for odd taps.
+//   sum * phase (:170) is needed in one component per output only:
+//       (Re_o, Im_{o+1}) = sX * (ph.x, ph.y) + sY * (-ph.y, ph.x)        two v_pk_mul_f32 + one v_pk_add_f32, then W += ...
+//   (ac - bd is computed as ac + (-(bd)): negation commutes with rounding; the first product of a block starts the sum instead of
+//   being added to 0, which can only change the sign of a zero SUM -- and a workspace slot that starts at +0 and is only ever added
+//   to cannot see the sign of a zero addend.)  66 packed instructions per step and thread against 72 + 8 moves in exact2.
+//   Samples before the demodulator's origin are stored as exact zeros by the mix (wave-uniform slow path, first tiles of a slot
+//   only), so the FIR loop carries no per-lane origin test: their blocks contribute +-0 to a slot that is still +0.
+//   Steps 0 and 32 touch one output only (tap blocks -1 and 32 do not exist): the other half's addend is replaced by +0 there.
+// LDS image, tiles, phasor rebuild and occupancy are exact2's (248 outputs on 128 threads, four tiles = eight waves per CU).
+template <int D, int T, int NT>
+__global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__restrict__ works,
+                                                              const float *__restrict__ taps2,
+                                                              int tiles_x, int n_ch)
+{
+    using Geo = DemodGeom<D, T>;
+    constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
+    constexpr int NBH = (Geo::NBLK + 1) / 2 + 1;          // blocks per parity array (+1 slack)
+    // Row = the block's D mixed samples + its mixer phase; pitch D + 1 complex = 2 (D + 1) dwords, which is 2 (mod 4): the 32 lanes of
+    // a ds_read_b64 group (lane l reads row l + n/2) start on the 32 distinct even banks -- conflict-free.  (ds_read_b128 wants a
+    // pitch of 4 (mod 8) dwords instead -- exact2's D + 2 -- but its 128-bit results cost hipcc a v_mov per second sample, see ExactBlock.)
+    constexpr int BP = D + 1;
+    static_assert(2 * NT >= T && T % 4 == 0 && D % 4 == 0, "two outputs per thread");
+    __shared__ __attribute__((aligned(16))) float2 s_t[2][NBH * BP];
+    static_assert(sizeof(float2) * 2 * NBH * BP <= 40960, "four tiles per CU");
+#ifdef CWSLG_STAMP
+    const bool stamp_on = true;
+#endif
+    STAMP(0);
+
+    const int total = (tiles_x < 0 ? -tiles_x : tiles_x) * n_ch;
+    const int per_xcd = (total + 7) >> 3;
+    const int wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (wid >= min(((int)(blockIdx.x & 7) + 1) * per_xcd, total)) return;
+    const int tid = threadIdx.x;
+    TileCtx<D, T> cur;
+    int ich, itile;
+    item_to_ch_tile(wid, tiles_x, n_ch, ich, itile);
+    decode_item<D, T>(works + ich, itile, cur);
+    if (cur.n_out == 0) return;
+    v4f xs[NIT];
+    float2 ck;
+    v4f tn;
+    issue_tile_loads<D, T, NT>(cur, tid, xs, ck, tn);
+    STAMP(1);
+    {
+        for (int lt = tid; lt < Geo::NCK; lt += NT) {
+            const int cidx = cur.ck_first + lt;
+            if (cidx >= 0) {
+                const v2f t = as_global(reinterpret_cast<const v2f *>(cur.ckpt))[cidx];
+                float2 p = make_float2(t.x, t.y);
+                const int pbase = cur.pb0 + kCk * lt;
+#pragma unroll
+                for (int s = 0; s < kCk; ++s) {
+                    const int pb = pbase + s;
+                    if (pb >= 0 && pb < Geo::NBLK) s_t[pb & 1][(pb >> 1) * BP + D] = p;
+                    p = cmul_exact(p, cur.inc);
+                }
+            }
+        }
+    }
+    STAMP(2);
+    // t = in[m] * tone[m]  (SSBD.hpp:167), un-fused, into the parity arrays; x[i < 0] = 0 on the (wave-uniform) slow path
+    {
+        const float2 tn0 = make_float2(tn.x, tn.y), tn1 = make_float2(tn.z, tn.w);
+        const int fv = cur.first_valid;
+        auto mix = [&](auto slow_tag) {
+            constexpr bool SLOW = decltype(slow_tag)::value;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int r = 2 * tid + it * 2 * NT;
+                if (r < Geo::NSAMP) {
+                    v4f x = xs[it];
+                    if (SLOW) {
+                        if (r < fv) x = v4f{0.0f, 0.0f, 0.0f, 0.0f};       // fv is a multiple of D: both samples of the pair
+                    }
+                    const float2 a = cmul_exact(make_float2(x.x, x.y), tn0);
+                    const float2 b = cmul_exact(make_float2(x.z, x.w), tn1);
+                    const int blk = r / D, m = r % D;
+                    float2 *row = &s_t[blk & 1][(blk >> 1) * BP + m];               // rows are 8-byte aligned only: two ds_write_b64
+                    row[0] = a;
+                    row[1] = b;
+                }
+            }
+        };
+        if (fv != 0) mix(std::true_type{});
+        else mix(std::false_type{});
+    }
+    __syncthreads();
+    STAMP(3);
+    const int o0 = 2 * tid;
+    if (o0 < T && o0 < cur.n_out) {
+        // The FIR loop's memory operations are issued by hand (inline assembly) so that their ORDER is what is written here: at the
+        // top of step n one `s_waitcnt lgkmcnt(0)` covers the LDS reads and the scalar tap loads of step n, which were issued a whole
+        // step earlier; then the reads and loads of step n + 1 are issued; then step n is computed.  (Left to hipcc, the loads of every
+        // other step sank to their first use -- loop form -- or, fully unrolled, every ds_read was followed by its own wait.)
+        // hipcc does not track these operations; the wait statement also "rewrites" every register they fill (tied operands), so no
+        // use of a loaded value can be scheduled above it.
+        ExactBlock<D> bA, bB;
+        ExactTaps<D> hA, hB;
+        const unsigned lds0 = (unsigned)(uintptr_t)&s_t[0][tid * BP];          // block 2 l of this lane's window
+        const unsigned lds1 = (unsigned)(uintptr_t)&s_t[1][tid * BP];          // block 2 l + 1
+        const CWSLG_CONST float *h2 = as_const(taps2);
+        v2f W = {0.0f, 0.0f};                                // (Re of o0's workspace slot, Im of o0 + 1's): zero after their last read-out (:178)
+        auto step = [&](const ExactBlock<D> &b, const ExactTaps<D> &h, bool first, bool last) {
+            v2f t0 = b.t(0);
+            v2f sX = v2f{t0.x, t0.x} * h.pair(0);
+            v2f sY = v2f{t0.y, t0.y} * h.pair(0);
+#pragma unroll
+            for (int m = 1; m < D; ++m) {
+                const v2f t = b.t(m);
+                sX = sX + v2f{t.x, t.x} * h.pair(m);         // sr += t.x*h   (:167-168), both outputs
+                sY = sY + v2f{t.y, t.y} * h.pair(m);         // si += t.y*h
+            }
+            const v2f A = sX * b.ph();                       // (ac of o0, ad of o0 + 1)
+            const v2f B = sY * b.phn();                      // (-(bd) of o0, bc of o0 + 1): the row holds (-ph.y, ph.x) next to ph
+            v2f R = A + B;                                   // (ac - bd, ad + bc)   (:170)
+            if (first) R.y = 0.0f;                           // tap block -1 does not exist
+            if (last) R.x = 0.0f;                            // tap block 32 does not exist
+            W = W + R;
+        };
+        // step n reads block o0 + n = row (n >> 1) of the parity-(n & 1) array relative to this lane's row, and tap row n
+        constexpr unsigned ROW = BP * sizeof(float2);        // bytes per LDS row
+        constexpr unsigned TROW = 2 * D * sizeof(float);     // bytes per tap row
+        hA.issue(h2);
+        bA.issue(lds0);
+        // step 0
+        exact_wait(bA, hA);
+        hB.issue(h2 + 2 * D); bB.issue(lds1);
+        step(bA, hA, true, false);
+        // steps 1 .. 30 in pairs (odd, even)
+        unsigned a0 = lds0 + ROW, a1 = lds1;                 // even / odd array rows of the NEXT even / CURRENT odd step
+        const CWSLG_CONST float *hp = h2 + 4 * D;           // tap row of the next even step
+#pragma unroll 1
+        for (int it = 0; it < 15; ++it) {
+            exact_wait(bB, hB);                              // step 2 it + 1
+            hA.issue(hp); bA.issue(a0);
+            step(bB, hB, false, false);
+            exact_wait(bA, hA);                              // step 2 it + 2
+            a1 += ROW;
+            hB.issue(hp + 2 * D); bB.issue(a1);
+            step(bA, hA, false, false);
+            a0 += ROW; hp += 4 * D;
+        }
+        (void)TROW;
+        // steps 31, 32
+        exact_wait(bB, hB);
+        hA.issue(hp); bA.issue(a0);
+        step(bB, hB, false, false);
+        exact_wait(bA, hA);
+        step(bA, hA, false, true);
+        STAMP(4);
+        const float wr0 = W.x, wi1 = W.y;
+        // Iterate(): out[k] for block index mod 4 (qs and T are multiples of 4; o0 is even)
+        const float v0 = (o0 & 2) ? -wr0 : wr0;
+        const float v1 = (o0 & 2) ? wi1 * cur.sign : -wi1 * cur.sign;
+        CWSLG_GLOBAL v2f *out2 = reinterpret_cast<CWSLG_GLOBAL v2f *>(as_global_rw(cur.out) + (size_t)cur.tile * T + o0);
+        v2f ov; ov.x = v0; ov.y = v1;
+        *out2 = ov;
+        float mx = fmaxf(fabsf(v0), fabsf(v1));
+#pragma unroll
+        for (int msk = 32; msk >= 1; msk >>= 1) mx = fmaxf(mx, __shfl_xor(mx, msk, 64));
+        if ((tid & 63) == 0) publish_peak(cur.peak, mx);
+    }
+    STAMP(5);
+}
+
+// ---------------------------------------------------------------------------------------------
 // demod_transition_kernel: the (at most 32) outputs after a phase-continuous retune, in ProcessBlock's own order (SSBD.hpp:160-183)
 // whatever the context's mode -- they are a handful per retune.  grid = works, 64 threads: thread = output.
 template <int D>

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CWSLG_ABI_VERSION 2
+#define CWSLG_ABI_VERSION 3
 
 /* ---- status codes ---- */
 #define CWSLG_OK                  0
@@ -347,6 +347,9 @@ int cwslg_get_stats(cwslg_ctx *ctx, cwslg_stats *out);
 int cwslg_reset_stats(cwslg_ctx *ctx);
 /* Enable HIP-event timing of every kernel launch (bench.py's roofline leg).  Off by default. */
 int cwslg_set_timing(cwslg_ctx *ctx, int enable);
+/* Name (with template arguments) of the kernel the context's most recent demod launch ran -- what bench.py reports as
+ * roofline.kernel; "" before the first launch.  The pointer is to a string literal. */
+const char *cwslg_demod_kernel_name(cwslg_ctx *ctx);
 /* Raw stream handle (hipStream_t) so callers can order their own work (torch, RCCL) against it. */
 void *cwslg_stream(cwslg_ctx *ctx);
 /* Host-side DSP constants exactly as uploaded (tests pin them against the oracle):
