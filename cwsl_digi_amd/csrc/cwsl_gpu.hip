@@ -45,7 +45,9 @@ namespace cwslg {
 
 // ---------------------------------------------------------------------------------------------
 constexpr int kTile = 256;             // outputs per demod workgroup
-constexpr int kTileExact = 256;        // ... of demod_exact3_kernel (two outputs per thread, 128 threads; four tiles of 38.5 KB per CU)
+constexpr int kTileExact = 512;        // ... of demod_exact3_kernel (two outputs per thread, 256 threads; two tiles of 72.5 KB per CU)
+constexpr int kExactThreads = kTileExact / 2;
+constexpr int kTileMax = 512;          // the largest tile any demod kernel walks a channel with (sizes the phasor checkpoint tables)
 constexpr int kTileExact2 = 248;       // ... of demod_exact2_kernel, lab build (124 of 128 lanes busy; four tiles of 39.7 KB per CU)
 constexpr int kDemodThreads = 256;
 constexpr int kFinThreads = 256;
@@ -188,7 +190,8 @@ struct cwslg_ctx {
     int device = 0;
     int cu_count = 256;
     int order_override = 0;            // CWSLG_ITEM_ORDER=1 channel-major, 2 tile-major (A/B); 0 = by topology
-    bool exact = false;                // cwslg_set_exact: reference-order arithmetic (bit-exact, slower)
+    bool exact = true;                 // the default: reference-order arithmetic, frames and candidate lists bit-identical to the reference
+                                       // chain's; cwslg_set_exact(ctx, 0) selects the fused polyphase form (faster, within 1e-5 of frame peak)
     bool upload_by_dma = false;        // CWSLG_UPLOAD=dma: descriptors through hipMemcpyAsync as in round 1 (measured alternative)
     int demod_variant = 0;             // CWSLG_DEMOD_VARIANT: 0 = one workgroup per tile (default); measured alternatives: 1 persistent +
                                        // prefetch, 2 persistent loop, 4..7 FIR on the matrix cores (192 kHz); 9..11 memory-traffic probe
@@ -483,10 +486,13 @@ template <int D>
 int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_blocks, uint32_t fs, bool tile_major)
 {
     if (works.empty()) return CWSLG_OK;
-    WorkBuf *w = acquire_workbuf(c, works.size() * sizeof(ChanWork));
+    // the descriptors, then (64-byte aligned) the eight per-XCD work counters of demod_exact3_kernel, zero at launch
+    const size_t ctr_off = (works.size() * sizeof(ChanWork) + 63) & ~size_t(63);
+    WorkBuf *w = acquire_workbuf(c, ctr_off + 64);
     if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
     std::memcpy(w->h, works.data(), works.size() * sizeof(ChanWork));
-    HIPCHK(c, upload_workbuf(c, w, works.size() * sizeof(ChanWork)));
+    std::memset((char *)w->h + works.size() * sizeof(ChanWork), 0, ctr_off + 64 - works.size() * sizeof(ChanWork));
+    HIPCHK(c, upload_workbuf(c, w, ctr_off + 64));
     // product build: ONE kernel per job -- demod_exact3_kernel in exact mode (the default), demod_kernel in fast mode.  The measured
     // alternatives (CWSLG_DEMOD_VARIANT) exist in the lab build only (-DCWSLG_LAB=1 -> libcwslgpu_lab.so).
     int tile = c->exact ? kTileExact : kTile;
@@ -494,6 +500,8 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     const bool small_tile = !c->exact && c->demod_variant == 15 && D == 16;     // 192-output tiles: 31 KB of LDS, five workgroups per CU
     if (c->exact && c->demod_variant == 20) tile = kTile;                       // round 1's exact kernel: one output per thread
     if (c->exact && c->demod_variant == 21) tile = kTileExact2;
+    if (c->exact && c->demod_variant == 23) tile = 256;                         // exact3 with two-wave workgroups (four per CU)
+    if (c->exact && c->demod_variant == 24) tile = 128;                         // exact3 with one-wave workgroups (seven per CU)
     if (small_tile) tile = 192;
 #endif
     const int tiles_n = (int)((max_blocks + tile - 1) / tile);
@@ -570,9 +578,26 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     }
 #endif
     if (!launched && c->exact) {
-        c->demod_kernel_name = D == 16 ? "demod_exact3_kernel<16,256,128>" : D == 8 ? "demod_exact3_kernel<8,256,128>" : "demod_exact3_kernel<4,256,128>";
-        hipLaunchKernelGGL((demod_exact3_kernel<D, kTileExact, 128>), dim3((unsigned)(per_xcd * 8)), dim3(128), 0,
-                           c->stream, (const ChanWork *)w->d, (const float *)c->d_taps2[fs], tiles_x, (int)works.size());
+        c->demod_kernel_name = D == 16 ? "demod_exact3_kernel<16,512,256>" : D == 8 ? "demod_exact3_kernel<8,512,256>" : "demod_exact3_kernel<4,512,256>";
+        // Large launches: as many workgroups as are resident at once (two per CU, LDS-bound: one wave of each on every SIMD), each
+        // drawing runs of tiles with the next tile's loads in flight under its FIR; small launches (real-time pushes): one
+        // workgroup per run of tiles.
+        auto go = [&](auto kern, int nt, int &occ) {
+            if (occ == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, nt, 0) != hipSuccess || occ < 1)) occ = 1;
+            const long long slots = std::max<long long>(1, (long long)c->cu_count * occ / 8);     // resident workgroups per XCD
+            const int run_len = (int)std::min<long long>(8, std::max<long long>(1, per_xcd / slots));  // items per draw
+            const long long wgs = 8 * std::min(slots, (per_xcd + run_len - 1) / run_len);
+            hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(nt), 0, c->stream, (const ChanWork *)w->d, (const float *)c->d_taps2[fs],
+                               tiles_x, (int)works.size(), (unsigned *)((char *)w->d + ctr_off), run_len);
+        };
+        static int occ_cache[3][3] = {};                    // resident workgroups per CU, by D and tile form (asked once)
+        const int di = D == 16 ? 0 : D == 8 ? 1 : 2;
+#if CWSLG_LAB
+        if (tile == 256) go(demod_exact3_kernel<D, 256, 128>, 128, occ_cache[di][1]);
+        else if (tile == 128) go(demod_exact3_kernel<D, 128, 64>, 64, occ_cache[di][2]);
+        else
+#endif
+        go(demod_exact3_kernel<D, kTileExact, kExactThreads>, kExactThreads, occ_cache[di][0]);
     } else if (!launched) {
         c->demod_kernel_name = D == 16 ? "demod_kernel<16,256,256,0>" : D == 8 ? "demod_kernel<8,256,256,0>" : "demod_kernel<4,256,256,0>";
         hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, 0>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
@@ -615,13 +640,13 @@ int retarget_phasor(cwslg_ctx *c, Channel &ch, const std::tuple<uint32_t, int32_
     return CWSLG_OK;
 }
 
-// Checkpoints a launch may touch for blocks [q_first, q_first + n_blocks), whatever tile size T <= 256 the kernel walks them with: the
+// Checkpoints a launch may touch for blocks [q_first, q_first + n_blocks), whatever tile size T <= kTileMax the kernel walks them with: the
 // last tile starts at or before block q_first + n_blocks - 1, is walked whole (T + 31 blocks from its first input block), and every
 // lane of the phasor rebuild reads one checkpoint whether it is used or not (NCK = (T + 31 + 3)/4 + 1 of them from the tile's
 // first): the highest index is below (q_first + n_blocks + 2 T + 2)/4 + 1.
 inline size_t ckpt_need(long long q_first, unsigned n_blocks)
 {
-    const long long last = std::max<long long>(0, q_first + (long long)n_blocks + 2 * kTile + 2);
+    const long long last = std::max<long long>(0, q_first + (long long)n_blocks + 2 * kTileMax + 2);
     return (size_t)(last / kCkptStride) + 4;
 }
 

@@ -1442,19 +1442,15 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 template <int D>
 struct ExactBlock {                 // one block's D mixed samples and its mixer phase
-    // one 64-bit register pair per complex sample (ds_read_b64: the same LDS cycles per byte as ds_read_b128): hipcc reaches either
-    // word of a 64-bit operand through op_sel, but copies the fourth word of a 128-bit value into a fresh register first
+    // One 64-bit register pair per complex sample, filled by ds_read_b64.  (hipcc reaches either word of a 64-bit operand through
+    // op_sel but copies the FOURTH word of a 128-bit value into a fresh register before it broadcasts it -- 8 v_mov per step with
+    // ds_read_b128 -- and the form that needs no VGPR broadcast needs the same of SGPR quads, 14 s_mov per step.  Measured on one box,
+    // 512 slots: 8-byte reads 4.92 ms, 16-byte reads with scalar broadcasts 4.95 ms: the LDS is not what bounds this kernel.)
     v2f q[D];
     v2f php;                        // the block's mixer phase: the row's pad slot
     __device__ __forceinline__ v2f t(int m) const { return q[m]; }
     __device__ __forceinline__ v2f ph() const { return php; }
     __device__ __forceinline__ v2f phn() const { return v2f{-php.y, php.x}; }
-    __device__ __forceinline__ void issue(unsigned row_addr)
-    {
-#pragma unroll
-        for (int i = 0; i <= D; ++i)
-            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(i < D ? q[i] : php) : "v"(row_addr), "n"(8 * i) : "memory");
-    }
 };
 
 template <int D> struct ExactTaps;   // one tap row = D wave-uniform pairs (h[m + D n], h[m + D (n-1)]) in SGPRs
@@ -1462,53 +1458,74 @@ template <>
 struct ExactTaps<16> {
     v16f lo, hi;
     __device__ __forceinline__ v2f pair(int m) const { return m < 8 ? v2f{lo[2 * m], lo[2 * m + 1]} : v2f{hi[2 * m - 16], hi[2 * m - 15]}; }
-    __device__ __forceinline__ void issue(const CWSLG_CONST float *row)
-    {
-        asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(lo) : "s"(row) : "memory");
-        asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=s"(hi) : "s"(row) : "memory");
-    }
 };
 template <>
 struct ExactTaps<8> {
     v16f lo;
     __device__ __forceinline__ v2f pair(int m) const { return v2f{lo[2 * m], lo[2 * m + 1]}; }
-    __device__ __forceinline__ void issue(const CWSLG_CONST float *row)
-    {
-        asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(lo) : "s"(row) : "memory");
-    }
 };
 template <>
 struct ExactTaps<4> {
     v8f lo;
     __device__ __forceinline__ v2f pair(int m) const { return v2f{lo[2 * m], lo[2 * m + 1]}; }
-    __device__ __forceinline__ void issue(const CWSLG_CONST float *row)
-    {
-        asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=s"(lo) : "s"(row) : "memory");
-    }
 };
+
+// Issue every load of one FIR step back to back -- ONE assembly statement, so that hipcc cannot spread them over the step that is
+// being computed meanwhile (it did, down to the last third of it: the step's registers die one by one and it reused them in
+// place, which left the LDS a fraction of a step to answer): the tap row through the scalar cache, the block's D + 1 LDS
+// words of 8 bytes.  Early-clobber outputs: the address operands are read by every instruction of the statement.  `pin` is the first
+// sample of the block about to be COMPUTED, passed through untouched: its sums start from it, so the step's arithmetic cannot be
+// scheduled ahead of this statement (hipcc otherwise sinks the statement, whose many results lengthen live ranges, below most of it).
+#define X3_RD(i) "ds_read_b64 %" #i ", %[row] offset:8*" #i "\n\t"
+__device__ __forceinline__ void exact_issue(ExactBlock<16> &b, ExactTaps<16> &h, unsigned row_addr, const CWSLG_CONST float *taps_row, v2f &pin)
+{
+    asm volatile("s_load_dwordx16 %[tl], %[tp], 0x0\n\ts_load_dwordx16 %[th], %[tp], 0x40\n\t"
+                 X3_RD(0) X3_RD(1) X3_RD(2) X3_RD(3) X3_RD(4) X3_RD(5) X3_RD(6) X3_RD(7) X3_RD(8) X3_RD(9) X3_RD(10) X3_RD(11)
+                 X3_RD(12) X3_RD(13) X3_RD(14) X3_RD(15) X3_RD(16)
+                 : "=&v"(b.q[0]), "=&v"(b.q[1]), "=&v"(b.q[2]), "=&v"(b.q[3]), "=&v"(b.q[4]), "=&v"(b.q[5]), "=&v"(b.q[6]), "=&v"(b.q[7]),
+                   "=&v"(b.q[8]), "=&v"(b.q[9]), "=&v"(b.q[10]), "=&v"(b.q[11]), "=&v"(b.q[12]), "=&v"(b.q[13]), "=&v"(b.q[14]),
+                   "=&v"(b.q[15]), "=&v"(b.php), [tl] "=&s"(h.lo), [th] "=&s"(h.hi), "+v"(pin)
+                 : [row] "v"(row_addr), [tp] "s"(taps_row) : "memory");
+}
+__device__ __forceinline__ void exact_issue(ExactBlock<8> &b, ExactTaps<8> &h, unsigned row_addr, const CWSLG_CONST float *taps_row, v2f &pin)
+{
+    asm volatile("s_load_dwordx16 %[tl], %[tp], 0x0\n\t"
+                 X3_RD(0) X3_RD(1) X3_RD(2) X3_RD(3) X3_RD(4) X3_RD(5) X3_RD(6) X3_RD(7) X3_RD(8)
+                 : "=&v"(b.q[0]), "=&v"(b.q[1]), "=&v"(b.q[2]), "=&v"(b.q[3]), "=&v"(b.q[4]), "=&v"(b.q[5]), "=&v"(b.q[6]), "=&v"(b.q[7]),
+                   "=&v"(b.php), [tl] "=&s"(h.lo), "+v"(pin)
+                 : [row] "v"(row_addr), [tp] "s"(taps_row) : "memory");
+}
+__device__ __forceinline__ void exact_issue(ExactBlock<4> &b, ExactTaps<4> &h, unsigned row_addr, const CWSLG_CONST float *taps_row, v2f &pin)
+{
+    asm volatile("s_load_dwordx8 %[tl], %[tp], 0x0\n\t"
+                 X3_RD(0) X3_RD(1) X3_RD(2) X3_RD(3) X3_RD(4)
+                 : "=&v"(b.q[0]), "=&v"(b.q[1]), "=&v"(b.q[2]), "=&v"(b.q[3]), "=&v"(b.php), [tl] "=&s"(h.lo), "+v"(pin)
+                 : [row] "v"(row_addr), [tp] "s"(taps_row) : "memory");
+}
+#undef X3_RD
 // Wait for everything the wave has in flight on the LDS / scalar-memory counter; the tied operands make every later use of the
-// registers the hand-issued loads fill depend on this statement.
-__device__ __forceinline__ void exact_wait(ExactBlock<16> &b, ExactTaps<16> &h)
+// registers the hand-issued loads fill depend on this statement -- and the statement depend on `w`, the running result of the step
+// before: without that hipcc hoists the wait to just behind the loads it covers and sinks the whole step's arithmetic below it.
+__device__ __forceinline__ void exact_wait(ExactBlock<16> &b, ExactTaps<16> &h, v2f &w)
 {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(b.q[0]), "+v"(b.q[1]), "+v"(b.q[2]), "+v"(b.q[3]), "+v"(b.q[4]), "+v"(b.q[5]), "+v"(b.q[6]), "+v"(b.q[7]),
                    "+v"(b.q[8]), "+v"(b.q[9]), "+v"(b.q[10]), "+v"(b.q[11]), "+v"(b.q[12]), "+v"(b.q[13]), "+v"(b.q[14]), "+v"(b.q[15]),
-                   "+v"(b.php), "+s"(h.lo), "+s"(h.hi) :: "memory");
+                   "+v"(b.php), "+s"(h.lo), "+s"(h.hi), "+v"(w) :: "memory");
 }
-__device__ __forceinline__ void exact_wait(ExactBlock<8> &b, ExactTaps<8> &h)
+__device__ __forceinline__ void exact_wait(ExactBlock<8> &b, ExactTaps<8> &h, v2f &w)
 {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(b.q[0]), "+v"(b.q[1]), "+v"(b.q[2]), "+v"(b.q[3]), "+v"(b.q[4]), "+v"(b.q[5]), "+v"(b.q[6]), "+v"(b.q[7]),
-                   "+v"(b.php), "+s"(h.lo) :: "memory");
+                   "+v"(b.php), "+s"(h.lo), "+v"(w) :: "memory");
 }
-__device__ __forceinline__ void exact_wait(ExactBlock<4> &b, ExactTaps<4> &h)
+__device__ __forceinline__ void exact_wait(ExactBlock<4> &b, ExactTaps<4> &h, v2f &w)
 {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b.q[0]), "+v"(b.q[1]), "+v"(b.q[2]), "+v"(b.q[3]), "+v"(b.php), "+s"(h.lo) :: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b.q[0]), "+v"(b.q[1]), "+v"(b.q[2]), "+v"(b.q[3]), "+v"(b.php), "+s"(h.lo), "+v"(w) :: "memory");
 }
 
 // ---------------------------------------------------------------------------------------------
-// demod_exact3_kernel: ProcessBlock's arithmetic, operation for operation (bit-identical frames), with the two outputs of a
-// thread computed side by side in the two halves of packed registers.
+// demod_exact3_kernel: ProcessBlock's arithmetic, operation for operation (bit-identical frames).
 //
 //   A thread owns outputs o (even) and o + 1.  Iterate() reads only Re of the even output's workspace slot and only Im of the odd
 //   one's (SSBD.hpp:131-134), and at step n block o + n feeds BOTH of them -- with tap block n for o, n - 1 for o + 1 -- through the
@@ -1521,54 +1538,84 @@ __device__ __forceinline__ void exact_wait(ExactBlock<4> &b, ExactTaps<4> &h)
 //   and wave kept the CU's texture-address path about as busy as its VALU), no tap VGPRs, no register shuffles for odd taps.
 //   sum * phase (:170) is needed in one component per output only:
 //       (Re_o, Im_{o+1}) = sX * (ph.x, ph.y) + sY * (-ph.y, ph.x)        two v_pk_mul_f32 + one v_pk_add_f32, then W += ...
-//   (ac - bd is computed as ac + (-(bd)): negation commutes with rounding; the first product of a block starts the sum instead of
-//   being added to 0, which can only change the sign of a zero SUM -- and a workspace slot that starts at +0 and is only ever added
-//   to cannot see the sign of a zero addend.)  66 packed instructions per step and thread against 72 + 8 moves in exact2.
+//   (The first product of a block starts the sum instead of being added to 0, which can only change the sign of a zero SUM -- and a
+//   workspace slot that starts at +0 and is only ever added to cannot see the sign of a zero addend.)
 //   Samples before the demodulator's origin are stored as exact zeros by the mix (wave-uniform slow path, first tiles of a slot
 //   only), so the FIR loop carries no per-lane origin test: their blocks contribute +-0 to a slot that is still +0.
-//   Steps 0 and 32 touch one output only (tap blocks -1 and 32 do not exist): the other half's addend is replaced by +0 there.
-// LDS image, tiles, phasor rebuild and occupancy are exact2's (248 outputs on 128 threads, four tiles = eight waves per CU).
+//   Steps 0 and 32 touch one output only (tap blocks -1 and 32 do not exist): the other output's addend is replaced by +0 there.
+//   The loop's LDS reads and scalar loads are issued BY HAND one step ahead (see the loop), and a workgroup walks a run of tiles with
+//   the next tile's HBM loads in flight under its FIR.
 template <int D, int T, int NT>
 __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__restrict__ works,
                                                               const float *__restrict__ taps2,
-                                                              int tiles_x, int n_ch)
+                                                              int tiles_x, int n_ch, unsigned *__restrict__ xcd_next, int run_len)
 {
     using Geo = DemodGeom<D, T>;
     constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
     constexpr int NBH = (Geo::NBLK + 1) / 2 + 1;          // blocks per parity array (+1 slack)
     // Row = the block's D mixed samples + its mixer phase; pitch D + 1 complex = 2 (D + 1) dwords, which is 2 (mod 4): the 32 lanes of
-    // a ds_read_b64 group (lane l reads row l + n/2) start on the 32 distinct even banks -- conflict-free.  (ds_read_b128 wants a
-    // pitch of 4 (mod 8) dwords instead -- exact2's D + 2 -- but its 128-bit results cost hipcc a v_mov per second sample, see ExactBlock.)
+    // a ds_read_b64 group (lane l reads row l + n/2) start on the 32 distinct even banks -- conflict-free.
     constexpr int BP = D + 1;
     static_assert(2 * NT >= T && T % 4 == 0 && D % 4 == 0, "two outputs per thread");
     __shared__ __attribute__((aligned(16))) float2 s_t[2][NBH * BP];
-    static_assert(sizeof(float2) * 2 * NBH * BP <= 40960, "four tiles per CU");
+    static_assert(sizeof(float2) * 2 * NBH * BP <= 81920, "at least two tiles per CU");
 #ifdef CWSLG_STAMP
-    const bool stamp_on = true;
+    bool stamp_on = true;              // a workgroup that walks a run of tiles stamps its 100th only
+    int stamp_iter = 0;
+    if (threadIdx.x == 0 && blockIdx.x < 65536) {          // where and when the workgroup started
+        unsigned hw, xcc;
+        unsigned long long t_;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)\n\ts_memtime %2\n\ts_waitcnt lgkmcnt(0)"
+                     : "=s"(hw), "=s"(xcc), "=s"(t_)::"memory");
+        g_stamps[8 * blockIdx.x + 6] = ((unsigned long long)xcc << 32) | hw;
+        g_stamps[8 * blockIdx.x + 7] = t_;
+    }
 #endif
     STAMP(0);
 
+    // Work items as in demod_kernel: XCD x owns items [x per_xcd, (x + 1) per_xcd), neighbouring items being neighbouring tiles of one
+    // channel.  Its workgroups DRAW them from a per-XCD counter (xcd_next[8], zeroed by the launch), one tile ahead: a workgroup that
+    // walks a run of tiles keeps the NEXT tile's HBM loads in flight, in registers, under its FIR.  (A fixed share per workgroup was
+    // measured 15 % slower than one workgroup per tile: whichever workgroups the dispatcher starts late finish late; a tile here is
+    // ~10 us of work, so the counter sees one atomic per ~100 ns.)
     const int total = (tiles_x < 0 ? -tiles_x : tiles_x) * n_ch;
     const int per_xcd = (total + 7) >> 3;
-    const int wid = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (wid >= min(((int)(blockIdx.x & 7) + 1) * per_xcd, total)) return;
+    const int xcd = blockIdx.x & 7;
+    const int lo_item = xcd * per_xcd, hi_item = min((xcd + 1) * per_xcd, total);
     const int tid = threadIdx.x;
+    // one draw = a run of run_len consecutive items, chosen by the launch (same-address atomics retire at about one per 100 ns: a
+    // draw per tile would bound large launches; small ones use shorter runs so that every CU gets work)
+    const int kRun = run_len;
+    __shared__ int s_draw;
+    CWSLG_GLOBAL unsigned *ctr = as_global_rw(xcd_next) + xcd;
+    if (tid == 0) s_draw = (int)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    int item = lo_item + kRun * (int)uni((unsigned)s_draw);
+    if (item >= hi_item) return;
+    int run_left = kRun - 1;                                 // items of the current run after `item`
     TileCtx<D, T> cur;
     int ich, itile;
-    item_to_ch_tile(wid, tiles_x, n_ch, ich, itile);
+    item_to_ch_tile(item, tiles_x, n_ch, ich, itile);
     decode_item<D, T>(works + ich, itile, cur);
-    if (cur.n_out == 0) return;
     v4f xs[NIT];
     float2 ck;
     v4f tn;
     issue_tile_loads<D, T, NT>(cur, tid, xs, ck, tn);
     STAMP(1);
+    for (;;) {
+    // the run after this one is drawn while its last item is mixed: the atomic's round trip hides under the phasor rebuild and the mix
+    unsigned draw = 0;
+    if (run_left == 0 && tid == 0) draw = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur.n_out > 0) {
     {
-        for (int lt = tid; lt < Geo::NCK; lt += NT) {
+        static_assert(Geo::NCK <= NT, "one checkpoint per lane");
+        {
+            const int lt = tid;
             const int cidx = cur.ck_first + lt;
-            if (cidx >= 0) {
-                const v2f t = as_global(reinterpret_cast<const v2f *>(cur.ckpt))[cidx];
-                float2 p = make_float2(t.x, t.y);
+            if (lt < Geo::NCK) {
+                // blocks before the demodulator's origin (cidx < 0) hold zero samples; their phase slot must still hold a FINITE
+                // number (0 * garbage left in LDS by another kernel could be NaN): zero
+                float2 p = (cidx >= 0) ? ck : make_float2(0.0f, 0.0f);   // ck: fetched by issue_tile_loads (later items: under the previous FIR)
                 const int pbase = cur.pb0 + kCk * lt;
 #pragma unroll
                 for (int s = 0; s < kCk; ++s) {
@@ -1606,8 +1653,20 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
         if (fv != 0) mix(std::true_type{});
         else mix(std::false_type{});
     }
-    __syncthreads();
+    }   // cur.n_out > 0
+    if (run_left == 0 && tid == 0) s_draw = (int)draw;
+    lds_barrier();                                           // the tile's LDS image is complete (every load it came from has been consumed)
     STAMP(3);
+    // the next item of this workgroup: its IQ, checkpoint and tone loads fly while the FIR below runs (xs, ck, tn are free now)
+    const int nitem = run_left ? item + 1 : lo_item + kRun * (int)uni((unsigned)s_draw);
+    run_left = run_left ? run_left - 1 : kRun - 1;
+    const bool has_next = nitem < hi_item;                   // workgroup-uniform
+    TileCtx<D, T> nxt = cur;
+    if (has_next) {
+        item_to_ch_tile(nitem, tiles_x, n_ch, ich, itile);
+        decode_item<D, T>(works + ich, itile, nxt);
+        issue_tile_loads<D, T, NT>(nxt, tid, xs, ck, tn);
+    }
     const int o0 = 2 * tid;
     if (o0 < T && o0 < cur.n_out) {
         // The FIR loop's memory operations are issued by hand (inline assembly) so that their ORDER is what is written here: at the
@@ -1623,7 +1682,9 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
         const CWSLG_CONST float *h2 = as_const(taps2);
         v2f W = {0.0f, 0.0f};                                // (Re of o0's workspace slot, Im of o0 + 1's): zero after their last read-out (:178)
         auto step = [&](const ExactBlock<D> &b, const ExactTaps<D> &h, bool first, bool last) {
-            v2f t0 = b.t(0);
+            // the running sums live TRANSPOSED: sX = (Re sum_o0, Re sum_{o0+1}), sY = (Im sum_o0, Im sum_{o0+1}); the tap pair
+            // (h[m + D n], h[m + D (n-1)]) is an SGPR pair the packed multiply reads as it is, the sample word is broadcast (op_sel)
+            const v2f t0 = b.t(0);
             v2f sX = v2f{t0.x, t0.x} * h.pair(0);
             v2f sY = v2f{t0.y, t0.y} * h.pair(0);
 #pragma unroll
@@ -1633,7 +1694,7 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
                 sY = sY + v2f{t.y, t.y} * h.pair(m);         // si += t.y*h
             }
             const v2f A = sX * b.ph();                       // (ac of o0, ad of o0 + 1)
-            const v2f B = sY * b.phn();                      // (-(bd) of o0, bc of o0 + 1): the row holds (-ph.y, ph.x) next to ph
+            const v2f B = sY * b.phn();                      // (-(bd) of o0, bc of o0 + 1): negation commutes with rounding
             v2f R = A + B;                                   // (ac - bd, ad + bc)   (:170)
             if (first) R.y = 0.0f;                           // tap block -1 does not exist
             if (last) R.x = 0.0f;                            // tap block 32 does not exist
@@ -1641,33 +1702,30 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
         };
         // step n reads block o0 + n = row (n >> 1) of the parity-(n & 1) array relative to this lane's row, and tap row n
         constexpr unsigned ROW = BP * sizeof(float2);        // bytes per LDS row
-        constexpr unsigned TROW = 2 * D * sizeof(float);     // bytes per tap row
-        hA.issue(h2);
-        bA.issue(lds0);
+        { v2f none = {0.0f, 0.0f}; exact_issue(bA, hA, lds0, h2, none); }
         // step 0
-        exact_wait(bA, hA);
-        hB.issue(h2 + 2 * D); bB.issue(lds1);
+        exact_wait(bA, hA, W);
+        exact_issue(bB, hB, lds1, h2 + 2 * D, bA.q[0]);
         step(bA, hA, true, false);
         // steps 1 .. 30 in pairs (odd, even)
         unsigned a0 = lds0 + ROW, a1 = lds1;                 // even / odd array rows of the NEXT even / CURRENT odd step
         const CWSLG_CONST float *hp = h2 + 4 * D;           // tap row of the next even step
 #pragma unroll 1
         for (int it = 0; it < 15; ++it) {
-            exact_wait(bB, hB);                              // step 2 it + 1
-            hA.issue(hp); bA.issue(a0);
+            exact_wait(bB, hB, W);                              // step 2 it + 1
+            exact_issue(bA, hA, a0, hp, bB.q[0]);
             step(bB, hB, false, false);
-            exact_wait(bA, hA);                              // step 2 it + 2
+            exact_wait(bA, hA, W);                              // step 2 it + 2
             a1 += ROW;
-            hB.issue(hp + 2 * D); bB.issue(a1);
+            exact_issue(bB, hB, a1, hp + 2 * D, bA.q[0]);
             step(bA, hA, false, false);
             a0 += ROW; hp += 4 * D;
         }
-        (void)TROW;
         // steps 31, 32
-        exact_wait(bB, hB);
-        hA.issue(hp); bA.issue(a0);
+        exact_wait(bB, hB, W);
+        exact_issue(bA, hA, a0, hp, bB.q[0]);
         step(bB, hB, false, false);
-        exact_wait(bA, hA);
+        exact_wait(bA, hA, W);
         step(bA, hA, false, true);
         STAMP(4);
         const float wr0 = W.x, wi1 = W.y;
@@ -1683,6 +1741,17 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
         if ((tid & 63) == 0) publish_peak(cur.peak, mx);
     }
     STAMP(5);
+    if (!has_next) break;
+    lds_barrier();                                           // every wave has finished reading the image the next mix overwrites
+    cur = nxt;
+    item = nitem;
+#ifdef CWSLG_STAMP
+    if (stamp_iter == 100) break;
+    ++stamp_iter;
+    stamp_on = (stamp_iter == 100);
+    STAMP(0); STAMP(1);
+#endif
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1740,25 +1809,28 @@ __global__ __launch_bounds__(64) void demod_transition_kernel(const TransWork *_
 template <int NT>
 __global__ __launch_bounds__(NT) void finalize_kernel(const FinWork *__restrict__ works)
 {
+    // the descriptor's pointers are HBM addresses: say so (global_load / global_store instead of flat_*, which also count in lgkmcnt)
     const FinWork *fw = works + blockIdx.y;
+    const CWSLG_GLOBAL float *frame = as_global(fw->frame);
+    CWSLG_GLOBAL int16_t *out = as_global_rw(fw->out);
     const unsigned i0 = (blockIdx.x * NT + threadIdx.x) * 8u;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (fw->peak_next) *fw->peak_next = 0u;
+        if (fw->peak_next) *as_global_rw(fw->peak_next) = 0u;
     }
     if (!fw->emit || i0 >= fw->frame_len) return;
-    const float peak = __uint_as_float(*fw->peak);
+    const float peak = __uint_as_float(*as_global(fw->peak));
     float factor = 32767.0f / (peak + 1.0f);
     factor = factor * fw->scale;
-    if (i0 == 0 && fw->factor_out) *fw->factor_out = factor;
+    if (i0 == 0 && fw->factor_out) *as_global_rw(fw->factor_out) = factor;
     const unsigned nv = fw->n_valid;
     float v[8];
     if (i0 + 8 <= nv) {
-        const float4 a = *reinterpret_cast<const float4 *>(fw->frame + i0);
-        const float4 b = *reinterpret_cast<const float4 *>(fw->frame + i0 + 4);
+        const v4f a = *reinterpret_cast<const CWSLG_GLOBAL v4f *>(frame + i0);
+        const v4f b = *reinterpret_cast<const CWSLG_GLOBAL v4f *>(frame + i0 + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     } else {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (i0 + k < nv) ? fw->frame[i0 + k] : 0.0f;
+        for (int k = 0; k < 8; ++k) v[k] = (i0 + k < nv) ? frame[i0 + k] : 0.0f;
     }
     int q[8];
 #pragma unroll
@@ -1767,16 +1839,17 @@ __global__ __launch_bounds__(NT) void finalize_kernel(const FinWork *__restrict_
         const float biased = scaled + 0.5f;                 // + 0.5f
         q[k] = (int)biased;                                 // C truncation toward zero, then narrowed to int16
     }
-    uint4 pk;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    v4u pk;
     pk.x = ((unsigned)q[0] & 0xFFFFu) | ((unsigned)q[1] << 16);
     pk.y = ((unsigned)q[2] & 0xFFFFu) | ((unsigned)q[3] << 16);
     pk.z = ((unsigned)q[4] & 0xFFFFu) | ((unsigned)q[5] << 16);
     pk.w = ((unsigned)q[6] & 0xFFFFu) | ((unsigned)q[7] << 16);
     const unsigned rem = fw->frame_len - i0;
     if (rem >= 8) {
-        *reinterpret_cast<uint4 *>(fw->out + i0) = pk;
+        *reinterpret_cast<CWSLG_GLOBAL v4u *>(out + i0) = pk;
     } else {
-        for (unsigned k = 0; k < rem; ++k) fw->out[i0 + k] = (int16_t)q[k];
+        for (unsigned k = 0; k < rem; ++k) out[i0 + k] = (int16_t)q[k];
     }
 }
 

@@ -75,7 +75,7 @@ int usage()
 {
     std::fprintf(stderr,
         "usage: cwsl_gpu_skimmer --config config.ini --rx file=PATH|-[,header=1][,fs=N,block=N,lo=HZ] [--rx udp=PORT,fs=..]...\n"
-        "         --out DIR [--start-ms UTC_MS] [--pace samples|wall] [--exact] [--sync 0|1] [--wav route|always|never]\n"
+        "         --out DIR [--start-ms UTC_MS] [--pace samples|wall] [--fast] [--sync 0|1] [--wav route|always|never]\n"
         "         [--max-seconds S] [--device N] [--dry-run]\n"
         "         [--world N --rank R --rccl-id FILE]   one process per GPU: decoders shard by receiver (receiver k -> rank k mod N),\n"
         "                                               RCCL rendezvous at every slot boundary; rank 0 writes FILE, the others read it\n");
@@ -96,7 +96,7 @@ int main(int argc, char **argv)
     std::string cfg_path, out_dir = ".", pace = "samples", wav_mode = "route";
     std::vector<std::string> rx_args;
     uint64_t start_ms = 0;
-    bool exact = false, dry = false, have_start = false;
+    bool exact = true, dry = false, have_start = false;     // exact: the library default (bit-identical frames); --fast: the fused form
     int sync = 1, device = -1, world = 1, rank = 0;
     std::string rccl_id_path;
     double max_seconds = 0;
@@ -116,7 +116,8 @@ int main(int argc, char **argv)
         else if (a == "--world" && (v = need("world"))) world = std::atoi(v);
         else if (a == "--rank" && (v = need("rank"))) rank = std::atoi(v);
         else if (a == "--rccl-id" && (v = need("id"))) rccl_id_path = v;
-        else if (a == "--exact") exact = true;
+        else if (a == "--exact") exact = true;              // (the default; accepted for older command lines)
+        else if (a == "--fast") exact = false;
         else if (a == "--dry-run") dry = true;
         else return usage();
     }
@@ -182,7 +183,7 @@ int main(int argc, char **argv)
     if (rc != CWSLG_OK) { std::fprintf(stderr, "cwslg_create: %s\n", cwslg_strerror(rc)); return 3; }
     auto die = [&](const char *what, int code) { std::fprintf(stderr, "%s: %s (%s)\n", what, cwslg_strerror(code), cwslg_last_error(ctx)); cwslg_destroy(ctx); std::exit(4); };
     if ((rc = cwslg_set_scale_factors(ctx, cfg.ft_scale, cfg.wspr_scale)) != CWSLG_OK) die("set_scale_factors", rc);
-    if (exact && (rc = cwslg_set_exact(ctx, 1)) != CWSLG_OK) die("set_exact", rc);
+    if ((rc = cwslg_set_exact(ctx, exact ? 1 : 0)) != CWSLG_OK) die("set_exact", rc);
     if (sync && (rc = cwslg_enable_sync(ctx, 1, 1.5f, 200, 200, cfg.highest_decode_hz)) != CWSLG_OK) {
         // e.g. wsjtx.highestdecodefreq <= 200: no candidate search is possible; frames are still produced
         std::fprintf(stderr, "sync stage disabled: %s (%s)\n", cwslg_strerror(rc), cwslg_last_error(ctx));

@@ -5,10 +5,17 @@
 //   cwslgpu::Context          process-wide handle (one per GPU)
 //   cwslgpu::ReceiverPort     what Receiver::readIQ writes into instead of ring_buffer_spmc_t
 //                             (source/Receiver.hpp:247-249)
-//   cwslgpu::SsbChannel       SSBD<float>-shaped object: same constructor arguments, same getters, same
-//                             std::invalid_argument messages (source/SSBD.hpp:48-59,97-103,140-154)
-//   cwslgpu::FrameSink        what Instance::sampleManager does at a slot boundary, as a callback that
-//                             receives the ItemToDecode ingredients (source/Instance.cpp:238-245)
+//   cwslgpu::SsbChannel       SSBD<float>-shaped object: same constructor arguments, same getters (GetInRate, GetOutRate,
+//                             GetInSize, GetOutSize, GetBandwidth, GetCarrier, IsUSB, GetDelay: source/SSBD.hpp:140-154),
+//                             same Tune, same std::invalid_argument messages (source/SSBD.hpp:48-59,97-103)
+//   cwslgpu::FrameSink        what Instance::sampleManager does after a slot boundary (source/Instance.cpp:221-245) for a
+//                             set of channels: every newly finalised frame goes to a callback as the ingredients of
+//                             ItemToDecode (DecoderPool.hpp:174-210)
+//
+// SSBD::Iterate(in, out) (SSBD.hpp:127-137) is deliberately absent: its contract is a synchronous 64-samples-in / 4-samples-out
+// call, which on a GPU is one kernel launch and one device-to-host wait per 4 output samples; its only caller in the reference
+// is the loop of Instance::sampleManager (Instance.cpp:273) that ReceiverPort::push + Context::slotBoundary + SsbChannel::fetch
+// replace as a whole.
 //
 // Nothing here computes DSP: every call forwards to the C ABI.
 #pragma once
@@ -57,7 +64,7 @@ private:
 class ReceiverPort {
 public:
     ReceiverPort(Context &ctx, std::uint32_t sampleRate, std::uint32_t blockInSamples, std::int32_t lo_hz,
-                 std::uint32_t ringBlocks = 0) : ctx_(ctx)
+                 std::uint32_t ringBlocks = 0) : ctx_(ctx), fs_(sampleRate)
     {
         check(ctx_.raw(), cwslg_receiver_open(ctx_.raw(), sampleRate, blockInSamples, lo_hz, ringBlocks, &id_));
     }
@@ -67,26 +74,37 @@ public:
         check(ctx_.raw(), cwslg_push_iq(ctx_.raw(), id_, reinterpret_cast<const float *>(block), n_complex));
     }
     int id() const { return id_; }
+    std::uint32_t sampleRate() const { return fs_; }     // Receiver::getSampleRate
     Context &context() const { return ctx_; }
 private:
     Context &ctx_;
     int id_ = -1;
+    std::uint32_t fs_ = 0;
 };
 
 // SSBD<float>(Fs, B, F, isUSB) -> SsbChannel(port, F, isUSB, mode).  Fs comes from the port; B is SSB_BW.
+// F is a whole number of Hz: the reference passes static_cast<float>(demodFreq) of an integer FrequencyHz (Instance.cpp:183-187,
+// 251), the C ABI takes it as int32 -- a fractional F given here is truncated toward zero, not rounded.
 class SsbChannel {
 public:
-    SsbChannel(ReceiverPort &port, double F, bool isUSB, const std::string &mode) : ctx_(port.context())
+    SsbChannel(ReceiverPort &port, double F, bool isUSB, const std::string &mode)
+        : ctx_(port.context()), mode_(mode), fs_(port.sampleRate()), carrier_(static_cast<double>(static_cast<std::int32_t>(F))), usb_(isUSB)
     {
         check(ctx_.raw(), cwslg_channel_open(ctx_.raw(), port.id(), static_cast<std::int32_t>(F), isUSB ? 1 : 0,
                                              mode.c_str(), &id_));
         check(ctx_.raw(), cwslg_channel_info(ctx_.raw(), id_, &in_, &out_, &rate_, &delay_, &frame_));
     }
     ~SsbChannel() { cwslg_channel_close(ctx_.raw(), id_); }
-    std::size_t GetInSize() const { return in_; }       // SSBD.hpp:144
-    std::size_t GetOutSize() const { return out_; }     // :146
+    std::size_t GetInRate() const { return fs_; }       // SSBD.hpp:140
     std::size_t GetOutRate() const { return rate_; }    // :142
+    std::size_t GetInSize() const { return in_; }       // :144
+    std::size_t GetOutSize() const { return out_; }     // :146
+    std::size_t GetBandwidth() const { return rate_ / 2; }   // :148  (GetOutRate() is 2*B)
+    double GetCarrier() const { return carrier_; }      // :150  the tuned frequency F as last set (constructor or Tune)
+    bool IsUSB() const { return usb_; }                 // :152
     std::size_t GetDelay() const { return delay_; }     // :154
+    const std::string &mode() const { return mode_; }
+    float trPeriod() const { return static_cast<float>(frame_ / 12000) - 5.0f; }    // frame = 12000 * (period + 5), Instance.cpp:149
     // SSBD::Tune(F, isUSB, reset = true) (SSBD.hpp:97): throws the same std::invalid_argument texts; the old tuning stays in force
     // after a throw.  reset = false keeps filter history, block position and phase, as :116-121 does when skipped.
     void Tune(double F, bool isUSB, bool reset = true)
@@ -94,6 +112,8 @@ public:
         const int rc = cwslg_channel_tune_ex(ctx_.raw(), id_, static_cast<std::int32_t>(F), isUSB ? 1 : 0, reset ? 1 : 0);
         if (rc == CWSLG_ERR_BAND_LOW || rc == CWSLG_ERR_BAND_HIGH || rc == CWSLG_ERR_RATIO) throw std::invalid_argument(cwslg_strerror(rc));
         check(ctx_.raw(), rc);
+        carrier_ = static_cast<double>(static_cast<std::int32_t>(F));
+        usb_ = isUSB;
     }
     std::size_t frameLength() const { return frame_; }  // Instance.cpp:149
     int id() const { return id_; }
@@ -139,8 +159,49 @@ public:
 private:
     Context &ctx_;
     int id_ = -1;
+    std::string mode_;
+    std::uint32_t fs_ = 0;
+    double carrier_ = 0.0;
+    bool usb_ = true;
     std::uint32_t in_ = 0, out_ = 0, rate_ = 0, delay_ = 0;
     std::size_t frame_ = 0;
+};
+
+// What Instance::sampleManager does with a finished frame (Instance.cpp:221-245), for every channel registered here:
+//     ItemToDecode toDecode(audioBuf_i16, digitalMode, startTime, ssbFreq, static_cast<int>(id), cwd, trperiod);
+//     decoderPool->push(toDecode);
+// Call collect() after Context::slotBoundary(): each channel whose last finalised frame is new (its startEpochTime differs from the one
+// delivered before; the first, discarded slot yields none, :224-227) is fetched and handed to the callback with those arguments.
+class FrameSink {
+public:
+    using Callback = std::function<void(std::vector<std::int16_t> &&audio, const std::string &mode, std::uint64_t epochTime,
+                                        std::int64_t baseFreq, int instanceId, const std::string &cwd, float trperiod)>;
+    explicit FrameSink(Callback cb) : cb_(std::move(cb)) {}
+    // ssbFreq, instanceId, cwd: Instance's members of the same names (Instance.cpp:121-176)
+    void add(SsbChannel &ch, std::int64_t ssbFreq, int instanceId, const std::string &cwd)
+    {
+        entries_.push_back(Entry{&ch, ssbFreq, instanceId, cwd, 0, false});
+    }
+    // returns the number of frames delivered
+    int collect()
+    {
+        int n = 0;
+        for (Entry &e : entries_) {
+            std::vector<std::int16_t> audio;
+            std::uint64_t t0 = 0;
+            if (!e.ch->fetch(audio, t0)) continue;
+            if (e.seen && t0 == e.last) continue;            // that frame went out at an earlier boundary
+            e.seen = true;
+            e.last = t0;
+            cb_(std::move(audio), e.ch->mode(), t0, e.ssbFreq, e.instanceId, e.cwd, e.ch->trPeriod());
+            ++n;
+        }
+        return n;
+    }
+private:
+    struct Entry { SsbChannel *ch; std::int64_t ssbFreq; int instanceId; std::string cwd; std::uint64_t last; bool seen; };
+    Callback cb_;
+    std::vector<Entry> entries_;
 };
 
 } // namespace cwslgpu

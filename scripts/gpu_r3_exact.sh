@@ -7,7 +7,7 @@ run() { # label, env..., -- bench args
   label=$1; shift
   env "$@" > /dev/null 2>&1
 }
-for cfg in "exact3|CWSLG_LIB=|--sync 0" "exact2|CWSLG_LIB=lab CWSLG_DEMOD_VARIANT=21|--sync 0" "exact3|CWSLG_LIB=|--sync 0" "exact2|CWSLG_LIB=lab CWSLG_DEMOD_VARIANT=21|--sync 0" "exact3+sync|CWSLG_LIB=|--sync 1"; do
+for cfg in "exact3|CWSLG_LIB=|--sync 0" "exact2|CWSLG_LIB=lab CWSLG_DEMOD_VARIANT=21|--sync 0" "exact3|CWSLG_LIB=|--sync 0" "exact3+sync|CWSLG_LIB=|--sync 1"; do
   IFS='|' read label envs bargs <<< "$cfg"
   f=$O/r3_exact_${label}.json
   env $envs timeout 300 python3 bench.py --slots 512 --exact --steps 10 --warmup 3 --no-cpu-baseline --verify 8 $bargs > $f 2> $f.err || tail -5 $f.err

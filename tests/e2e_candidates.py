@@ -35,7 +35,8 @@ def make_slots(oracle, mode, n_slots, seed0):
 
 
 def run_gpu(ctx, mode, slots, exact, maxcand=200):
-    ctx.set_exact(exact)
+    if exact is not None:                 # None: leave the context as cwslg_create() made it
+        ctx.set_exact(exact)
     ctx.enable_sync(True, 1.5, maxcand, 200, 3000)
     res = []
     for f, iq in slots:

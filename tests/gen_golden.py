@@ -76,6 +76,31 @@ def gen_slot(name, mode, fs, f, seed, n_iq, iq_len, scale_ft=0.90, scale_wspr=0.
     print(name, "peak", float(peak), "factor", float(factor), "crc %08x" % O.crc32(i16))
 
 
+def gen_adversarial():
+    """tests/adversarial.py's inputs through the reference's own SSBD (oracle/_ref): the whole float frame as CRC32 + samples, the
+    restated prepareAudio / int16 on top (rows a8/a9 have no compilable reference)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import adversarial as A
+    for name in sorted(A.CASES):
+        iq = A.make_iq(name)
+        r = O.RefDemod(A.FS, float(np.float32(A.F)))
+        audio = r.run(iq)
+        nblk = len(iq) // 16
+        frame = np.zeros(O.frame_len("FT8"), np.float32)
+        frame[:nblk] = audio
+        scaled, factor, peak = O.prepare_audio(frame, "FT8", 0.90, 0.20)
+        i16 = O.to_int16(scaled)
+        np.savez_compressed(
+            os.path.join(OUT, f"adv_{name}.npz"), name=name, iq_crc32=A.iq_crc(iq), n_valid=nblk,
+            audio_crc32=O.crc32(audio.view(np.uint32)), audio_head_bits=audio[:2048].view(np.uint32),
+            audio_every_bits=audio[::97].view(np.uint32),
+            peak_bits=np.array([peak], np.float32).view(np.uint32), factor_bits=np.array([factor], np.float32).view(np.uint32),
+            i16_crc32=O.crc32(i16), i16_head=i16[:256], argmax=int(np.abs(audio).argmax()),
+            input_peak=float(np.abs(np.concatenate([iq.real, iq.imag])).max()))
+        print("adv", name, "frame peak %.6g at output %d, input peak %.6g, factor %.6g, i16 crc %08x"
+              % (float(peak), int(np.abs(audio).argmax()), float(np.abs(iq).max()), float(factor), O.crc32(i16)))
+
+
 def main():
     if not O.have_ref():
         raise SystemExit("oracle/_ref/libcwsl_ref.so missing: run `make -C oracle ref` where /root/reference exists")
@@ -91,6 +116,7 @@ def main():
     gen_slot("ft4_fs192000_f24000", "FT4", 192000, 24000, 0xF4, 1440000 // 2048 * 2048, 2048)
     gen_slot("wspr_fs192000_f1500", "WSPR", 192000, 1500, 0x3535, 23040000 // 2048 * 2048, 2048)
     gen_slot("fst4w120_fs192000_f1500", "FST4W-120", 192000, 1500, 0x3535, 23040000 // 2048 * 2048, 2048)
+    gen_adversarial()
 
 
 if __name__ == "__main__":

@@ -34,8 +34,34 @@ int main(int argc, char **argv)
         ctx.slotBoundary(CWSLG_GROUP_FT8, 1000);
         if (chan.fetch(audio, t0)) return 5;          // first (partial) slot: nothing to decode (Instance.cpp:224-227)
         while (std::fread(blk.data(), sizeof(blk[0]), blk.size(), f) == blk.size()) rx.push(blk.data(), 2048);
+        // every SSBD getter (SSBD.hpp:140-154) and a Tune that fails leaves the old tuning in force (:100-103)
+        if (chan.GetInRate() != 192000 || chan.GetBandwidth() != 6000 || chan.GetOutSize() != 4 || chan.GetDelay() != 8 ||
+            chan.GetCarrier() != -26000.0 || !chan.IsUSB()) return 8;
+        bool tune_threw = false;
+        try { chan.Tune(-97000.0, true); } catch (const std::invalid_argument &e) {
+            tune_threw = std::string(e.what()) == "Signal outside of band (high)" || std::string(e.what()) == "Signal outside of band (low)";
+        }
+        if (!tune_threw || chan.GetCarrier() != -26000.0) return 9;
+        // the frame goes out the way Instance hands it to DecoderPool::push (Instance.cpp:244-245)
+        int delivered = 0; std::uint64_t sink_t0 = 0; std::uint32_t sink_crc = 0; float sink_tr = 0; int sink_id = 0; std::int64_t sink_f = 0;
+        std::string sink_mode, sink_cwd;
+        cwslgpu::FrameSink sink([&](std::vector<std::int16_t> &&a, const std::string &mode, std::uint64_t epoch, std::int64_t base, int id,
+                                    const std::string &cwd, float trperiod) {
+            ++delivered; sink_t0 = epoch; sink_crc = crc32(a.data(), a.size() * 2); sink_tr = trperiod; sink_id = id; sink_f = base;
+            sink_mode = mode; sink_cwd = cwd;
+        });
+        sink.add(chan, 28074000, 3, "/tmp/cwd3");
+        if (sink.collect() != 0) return 10;           // nothing finalised yet
         ctx.slotBoundary(CWSLG_GROUP_FT8, 1015);
         if (!chan.fetch(audio, t0)) return 6;
+        if (sink.collect() != 1 || sink.collect() != 0) return 11;     // delivered once
+        if (delivered != 1 || sink_t0 != t0 || sink_crc != crc32(audio.data(), audio.size() * 2) || sink_tr != 15.0f || sink_id != 3 ||
+            sink_f != 28074000 || sink_mode != "FT8" || sink_cwd != "/tmp/cwd3") return 12;
+        std::vector<cwslg_candidate> cands; std::vector<cwslg_ft4_sync> recs;
+        bool cand_threw = false;                       // sync stage not enabled on this context: the C ABI reports it, the shim throws
+        try { chan.candidates(cands); } catch (const std::exception &) { cand_threw = true; }
+        try { (void)chan.ft4Sync(recs); } catch (const std::exception &) { cand_threw = true; }      // (not an FT4 channel)
+        (void)cand_threw;
         std::printf("OK %llu %zu %08x %zu %zu\n", (unsigned long long)t0, audio.size(), crc32(audio.data(), audio.size() * 2),
                     chan.GetInSize(), chan.GetOutRate());
     } catch (const std::exception &e) {

@@ -4,8 +4,9 @@
                         -> sync restatement on THAT frame
     product chain:   IQ -> cwslg_push_iq ... cwslg_fetch_candidates (+ cwslg_fetch_ft4_sync)
 
-Exact mode (cwslg_set_exact): the int16 frames are bit-identical, hence so is every list -- asserted.
-Default (throughput) mode: the float audio differs from the reference chain's by <= 4e-7 of frame peak, so the int16
+Exact mode (the default of a new context): the int16 frames are bit-identical, hence so is every list -- asserted, both on a
+context left exactly as cwslg_create() made it and on one switched explicitly.
+Fast mode (cwslg_set_exact(ctx, 0)): the float audio differs from the reference chain's by <= 4e-7 of frame peak, so the int16
 frames differ by 1 LSB at ~0.1 % of the samples (rounding ties); the sync arithmetic is float32 on those frames, so the
 lists can only be compared within a tolerance.  Asserted here (measured values: profiles/r2_e2e_candidates.json,
 DESIGN.md section 6d): the same (bin, lag) keys except keys whose sync sits within 1e-3 of a cut (syncmin, or the last
@@ -31,6 +32,20 @@ def chains(oracle):
 
 
 @pytest.mark.parametrize("mode", ["FT8", "FT4"])
+def test_a_new_context_gives_bit_identical_lists_end_to_end(chains, mode):
+    """No mode call at all: what cwslg_create() hands out is the bit-identical chain."""
+    import cwsl_digi_amd as P
+    slots, ref = chains[mode]
+    with P.Context(0) as fresh:
+        gpu = E.run_gpu(fresh, mode, slots, exact=None)
+    rep = E.compare(mode, gpu, ref, 1.5 if mode == "FT8" else 1.2)
+    assert rep["int16_mismatches"] == [0] * N_SLOTS
+    assert rep["identical_lists"] == N_SLOTS and min(rep["n_cands"]) >= 3
+    if mode == "FT4":
+        assert rep["ft4_records_identical"] == N_SLOTS
+
+
+@pytest.mark.parametrize("mode", ["FT8", "FT4"])
 def test_exact_mode_lists_bit_identical_end_to_end(ctx, chains, mode):
     slots, ref = chains[mode]
     gpu = E.run_gpu(ctx, mode, slots, exact=True)
@@ -42,7 +57,7 @@ def test_exact_mode_lists_bit_identical_end_to_end(ctx, chains, mode):
 
 
 @pytest.mark.parametrize("mode", ["FT8", "FT4"])
-def test_default_mode_lists_within_tolerance_end_to_end(ctx, chains, mode):
+def test_fast_mode_lists_within_tolerance_end_to_end(ctx, chains, mode):
     slots, ref = chains[mode]
     gpu = E.run_gpu(ctx, mode, slots, exact=False)
     rep = E.compare(mode, gpu, ref, 1.5 if mode == "FT8" else 1.2)

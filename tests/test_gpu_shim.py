@@ -22,7 +22,8 @@ def test_shim_program_end_to_end(ctx, oracle, tmp_path):
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     tag, t0, nsamp, crc, in_size, out_rate = out.stdout.split()
     assert (tag, int(t0), int(nsamp), int(in_size), int(out_rate)) == ("OK", 1000, 240000, 64, 12000)
-    # same input through the ctypes mirror of the same library
+    # same input through the ctypes mirror of the same library, in the mode a new context has (the shim program sets none)
+    ctx.set_exact(True)
     rx = ctx.receiver_open(192000, 2048, 28100000)
     ch = ctx.channel_open(rx, -26000, "FT8")
     ctx.slot_boundary("FT8", 1000); ctx.push_iq(rx, iq); ctx.slot_boundary("FT8", 1015)
