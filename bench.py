@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--fast-only", action="store_true", help="skip the second (exact-mode) record")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU tensors; for checking the N>1 path on a 1-GPU box)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses GPU 0")
+    ap.add_argument("--rendezvous", default="auto", choices=["auto", "builtin", "torch"],
+                    help="N > 1: the slot-boundary rendezvous inside cwslg_slot_boundary_end -- builtin = the library's own RCCL all-gather "
+                         "(cwslg_rccl_init; no Python inside the boundary), torch = a torch.distributed all-reduce handed in as a callback; "
+                         "auto = builtin on the nccl backend with one GPU per rank, torch otherwise (gloo, --same-device: RCCL refuses two ranks on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
     ap.add_argument("--verify", type=int, default=8, help="slots (spread over the whole range) checked against the oracle after the timed region")
@@ -112,8 +116,18 @@ def main():
 
     S = args.slots if args.slots > 0 else (4096 if world == 1 else 512)
     ctx = P.Context(local_rank)
+    rendezvous = None
     if world > 1:
-        shard.install_rendezvous(ctx, dev)     # cwslg_slot_boundary itself now ends in the all-reduce
+        rendezvous = args.rendezvous
+        if rendezvous == "auto":
+            rendezvous = "builtin" if (args.dist_backend == "nccl" and not args.same_device) else "torch"
+        if rendezvous == "builtin":
+            # the library's own RCCL communicator: rank 0 makes the ncclUniqueId, torch.distributed only carries its 128 bytes
+            box = [P.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.rccl_init(box[0], rank, world)
+        else:
+            shard.install_rendezvous(ctx, dev)  # cwslg_slot_boundary[_end] ends in torch.distributed's all-reduce (callback form)
     if args.sync:
         ctx.enable_sync(True, 1.5, 200, 200, 3000)    # jt9 -8 defaults used by the reference: syncmin 1.5, 200..3000 Hz (-H highestdecodefreq)
     ring_blocks = SLOT_SAMPLES // IQ_LEN + 2 + (SLOT_SAMPLES % IQ_LEN != 0)
@@ -191,9 +205,12 @@ def main():
         st_ = ctx.stats()
         if world > 1:
             assert st_["rendezvous_calls"] == args.steps and st_["rendezvous_frames"] == S * world, st_
-            tt = torch.tensor([dt_], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt_ = float(tt.item())
+            if rendezvous == "builtin":
+                assert st_["rccl_world"] == world, st_
+            every = [None] * world
+            dist.all_gather_object(every, dt_)
+            st_["rank_ms_per_step"] = [d / args.steps * 1e3 for d in every]
+            dt_ = max(every)                   # the job's time is the slowest rank's
         return dt_, st_, ctx.demod_kernel_name()
 
     def verify_against_oracle(exact):
@@ -307,8 +324,14 @@ def main():
                                    ("(north_star: 4096 concurrent FT8 slots on ONE MI355X, all inputs resident in HBM)" if S == 4096 and world == 1 else
                                     "(BASELINE configs[3]: 4096 slots sharded 512 per GPU)" if S == 512 else "(--slots override)"),
                        "slots_per_gpu": S, "channels_per_receiver": C, "fs_hz": FS, "iq_block": IQ_LEN, "stages": "nco-mix+polyphase-decimate, peak-normalise+int16" + (", ft8 symbol-spectra+costas-sync+candidates" if args.sync else ""),
-                       "sharding": f"slots x{world}, one 8-byte RCCL all-reduce per slot boundary inside cwslg_slot_boundary" if world > 1 else "single GPU"},
+                       "sharding": (f"slots x{world}, no data-path collective; per slot boundary one 24-byte-per-rank RCCL all-gather inside cwslg_slot_boundary_end "
+                                    f"(built-in rendezvous, cwslg_rccl_init)" if rendezvous == "builtin" else
+                                    f"slots x{world}, no data-path collective; per slot boundary one 8-byte {args.dist_backend} all-reduce called back from "
+                                    f"cwslg_slot_boundary_end (torch.distributed)") if world > 1 else "single GPU"},
             "realtime_ft8_slots": msps / 0.192,
+            "multi_gpu": None if world == 1 else {"rendezvous": rendezvous, "rccl_world": int(st.get("rccl_world", 0)),
+                                                  "rendezvous_calls": int(st["rendezvous_calls"]), "rendezvous_frames": int(st["rendezvous_frames"]),
+                                                  "rank_ms_per_step_min": min(st["rank_ms_per_step"]), "rank_ms_per_step_max": max(st["rank_ms_per_step"])},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "bytes_per_sample": bps, "samples_per_launch": samples_per_launch,

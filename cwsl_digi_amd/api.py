@@ -104,7 +104,7 @@ class Stats(C.Structure):
                 ("frames_discarded", C.c_uint64), ("blocks_dropped", C.c_uint64),
                 ("h2d_bytes", C.c_uint64), ("demod_ms", C.c_double), ("finalize_ms", C.c_double),
                 ("sync_ms", C.c_double), ("phasor_regrows", C.c_uint64), ("rendezvous_calls", C.c_uint64),
-                ("rendezvous_frames", C.c_uint64)]
+                ("rendezvous_frames", C.c_uint64), ("rccl_world", C.c_uint64), ("rendezvous_flags_and", C.c_uint64)]
 
 
 # int (*)(void *user, int group, uint64_t epoch_s, uint64_t frames_local, uint64_t *frames_total)
@@ -118,7 +118,7 @@ ABI_SYMBOLS = [
     "cwslg_set_scale_factors", "cwslg_set_exact", "cwslg_receiver_open", "cwslg_receiver_close", "cwslg_push_iq",
     "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_parse_decoder_line", "cwslg_channel_open_line", "cwslg_channel_open", "cwslg_channel_close", "cwslg_channel_tune", "cwslg_channel_tune_ex",
     "cwslg_channel_info", "cwslg_process", "cwslg_slot_boundary", "cwslg_slot_boundary_begin", "cwslg_slot_boundary_end", "cwslg_slot_boundary_channel",
-    "cwslg_set_boundary_rendezvous", "cwslg_rccl_unique_id", "cwslg_rccl_init",
+    "cwslg_set_boundary_rendezvous", "cwslg_set_rendezvous_flag", "cwslg_rccl_unique_id", "cwslg_rccl_init",
     "cwslg_enable_long_sync", "cwslg_fetch_wspr_candidates", "cwslg_fetch_fst4w_candidates", "cwslg_long_sync_debug_fetch",
     "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_write_wav", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
     "cwslg_enable_sync", "cwslg_fetch_candidates", "cwslg_set_ft4_syncmin", "cwslg_enable_ft4_coherent", "cwslg_fetch_ft4_sync", "cwslg_sync_debug_fetch", "cwslg_get_stats", "cwslg_reset_stats",
@@ -164,6 +164,7 @@ def load_library(build_if_missing=True):
     L.cwslg_set_exact.argtypes = [vp, i32]
     L.cwslg_demod_kernel_name.argtypes = [vp]; L.cwslg_demod_kernel_name.restype = C.c_char_p
     L.cwslg_set_boundary_rendezvous.argtypes = [vp, RENDEZVOUS_FN, vp]
+    L.cwslg_set_rendezvous_flag.argtypes = [vp, u64]
     L.cwslg_rccl_unique_id.argtypes = [vp]
     L.cwslg_rccl_init.argtypes = [vp, vp, i32, i32]
     L.cwslg_enable_long_sync.argtypes = [vp, i32, i32, i32, f32]
@@ -425,6 +426,10 @@ class Context:
                 return ERR_HIP
         self._rdv_cb = RENDEZVOUS_FN(tramp)                 # keep the trampoline alive as long as it is installed
         self._chk(self.L.cwslg_set_boundary_rendezvous(self.h, self._rdv_cb, None))
+
+    def set_rendezvous_flag(self, flag):
+        """The 64-bit word this process contributes to every later built-in rendezvous (stats()["rendezvous_flags_and"])."""
+        self._chk(self.L.cwslg_set_rendezvous_flag(self.h, int(flag)))
 
     def rccl_init(self, unique_id, rank, world):
         """Built-in RCCL rendezvous (what a C++ host uses): unique_id = bytes from rccl_unique_id() of rank 0."""

@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstdarg>
 #include <cstdio>
@@ -241,7 +242,9 @@ struct cwslg_ctx {
     cwslg_rendezvous_fn rdv_fn = nullptr;
     void *rdv_user = nullptr;
     ncclComm_t rccl_comm = nullptr;
-    uint64_t *d_rdv = nullptr, *h_rdv = nullptr;   // [2]: local count, sum over ranks
+    uint64_t *d_rdv = nullptr, *h_rdv = nullptr;   // [3]: this rank's (frames, group, epoch), then [world][3]: every rank's
+    int rccl_world = 0;
+    std::atomic<uint64_t> rdv_flag{0}, rdv_flags_and{0};   // cwslg_set_rendezvous_flag; AND over the ranks at the last built-in rendezvous
     // cwslg_slot_boundary_begin / _end: the rendezvous of a boundary whose device work is queued but not yet waited for
     bool rdv_pending = false;
     int rdv_group = 0;
@@ -1658,6 +1661,7 @@ int cwslg_slot_boundary(cwslg_ctx *c, int group, uint64_t epoch_s)
     uint64_t mine = 0;
     {
         std::lock_guard<std::mutex> g(c->mu);
+        if (c->rdv_pending) return fail(c, CWSLG_ERR_ARG, "cwslg_slot_boundary: a boundary opened by cwslg_slot_boundary_begin has not been ended");
         hipSetDevice(c->device);
         std::vector<int> ids;
         for (size_t k = 0; k < c->chans.size(); ++k)
@@ -1676,6 +1680,7 @@ int cwslg_slot_boundary(cwslg_ctx *c, int group, uint64_t epoch_s)
     if (rc < 0) return fail(c, rc, "slot-boundary rendezvous failed (%d)", rc);
     c->stats.rendezvous_calls++;
     c->stats.rendezvous_frames = total;
+    c->stats.rendezvous_flags_and = c->rccl_comm ? c->rdv_flags_and.load() : c->rdv_flag.load();
     return CWSLG_OK;
 }
 
@@ -1715,10 +1720,10 @@ int cwslg_slot_boundary_end(cwslg_ctx *c)
         std::lock_guard<std::mutex> g(c->mu);
         if (!c->rdv_pending) return CWSLG_OK;
         hipSetDevice(c->device);
+        c->rdv_pending = false;                                 // whatever happens below, the boundary is no longer open
         HIPCHK(c, hipEventSynchronize(c->rdv_ready));          // this GPU's frames of the epoch are final ...
         fn = c->rdv_fn; user = c->rdv_user;
         group = c->rdv_group; epoch = c->rdv_epoch; mine = c->rdv_mine;
-        c->rdv_pending = false;
         if (!fn) return CWSLG_OK;
     }
     uint64_t total = mine;                                      // ... and after the rendezvous so are every other GPU's
@@ -1727,6 +1732,7 @@ int cwslg_slot_boundary_end(cwslg_ctx *c)
     if (rc < 0) return fail(c, rc, "slot-boundary rendezvous failed (%d)", rc);
     c->stats.rendezvous_calls++;
     c->stats.rendezvous_frames = total;
+    c->stats.rendezvous_flags_and = c->rccl_comm ? c->rdv_flags_and.load() : c->rdv_flag.load();
     return CWSLG_OK;
 }
 
@@ -1933,6 +1939,7 @@ int cwslg_reset_stats(cwslg_ctx *c)
     if (!c) return CWSLG_ERR_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     c->stats = cwslg_stats{};
+    c->stats.rccl_world = (uint64_t)c->rccl_world;
     return CWSLG_OK;
 }
 

@@ -123,6 +123,11 @@ int main(int argc, char **argv)
     }
     if (cfg_path.empty() || rx_args.empty()) return usage();
     if (world < 1 || rank < 0 || rank >= world || (world > 1 && rccl_id_path.empty())) return usage();
+    if (world > 1 && !have_start) {
+        // the ranks fire the same sequence of slot boundaries (a collective) only if they count time from the same instant
+        std::fprintf(stderr, "--world %d needs --start-ms: every rank must derive the slot boundaries from the same start\n", world);
+        return 2;
+    }
 
     SkimmerConfig cfg;
     if (!load_config(cfg_path.c_str(), cfg)) { std::fprintf(stderr, "config: %s\n", cfg.error.c_str()); return 1; }
@@ -190,23 +195,34 @@ int main(int argc, char **argv)
         sync = 0;
     }
     if (world > 1) {
-        // ncclUniqueId hand-over through a file: rank 0 creates it (written whole, then renamed), the others wait for it
+        // ncclUniqueId hand-over through a file: rank 0 creates it (written whole, then renamed), the others wait for it.  The id is
+        // followed by a run tag (--start-ms, the same on every rank): a file left behind by an earlier run, or by a crash, carries
+        // another tag and is ignored instead of sending ncclCommInitRank into a rendezvous nobody else attends.
         unsigned char id[CWSLG_RCCL_ID_BYTES];
+        const uint64_t tag = start_ms;
         if (rank == 0) {
+            std::remove(rccl_id_path.c_str());                    // whatever an earlier run left there
             if ((rc = cwslg_rccl_unique_id(id)) != CWSLG_OK) die("rccl_unique_id", rc);
             const std::string tmp = rccl_id_path + ".tmp";
             FILE *f = std::fopen(tmp.c_str(), "wb");
-            if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id) { std::fprintf(stderr, "cannot write %s\n", tmp.c_str()); return 1; }
+            if (!f || std::fwrite(id, 1, sizeof id, f) != sizeof id || std::fwrite(&tag, 1, sizeof tag, f) != sizeof tag) {
+                std::fprintf(stderr, "cannot write %s\n", tmp.c_str());
+                return 1;
+            }
             std::fclose(f);
             std::rename(tmp.c_str(), rccl_id_path.c_str());
         } else {
             bool got = false;
             for (int tries = 0; tries < 600 && !got; ++tries) {
                 FILE *f = std::fopen(rccl_id_path.c_str(), "rb");
-                if (f) { got = std::fread(id, 1, sizeof id, f) == sizeof id; std::fclose(f); }
+                if (f) {
+                    uint64_t t = 0;
+                    got = std::fread(id, 1, sizeof id, f) == sizeof id && std::fread(&t, 1, sizeof t, f) == sizeof t && t == tag;
+                    std::fclose(f);
+                }
                 if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
             }
-            if (!got) { std::fprintf(stderr, "no RCCL id in %s after 60 s\n", rccl_id_path.c_str()); return 1; }
+            if (!got) { std::fprintf(stderr, "no RCCL id of this run (tag %" PRIu64 ") in %s after 60 s\n", tag, rccl_id_path.c_str()); cwslg_destroy(ctx); return 1; }
         }
         if ((rc = cwslg_rccl_init(ctx, id, rank, world)) != CWSLG_OK) die("rccl_init", rc);
     }
@@ -239,10 +255,17 @@ int main(int argc, char **argv)
     std::vector<cwslg_ft4_sync> ref4(1800);
     uint64_t frames_total = 0, boundaries = 0;
 
+    bool inputs_done = false, all_done = false;
     auto publish = [&](int group, uint64_t edge_ms) {
         const uint64_t epoch = edge_ms / 1000;                   // Instance.cpp:214: whole seconds
         if ((rc = cwslg_slot_boundary(ctx, group, epoch)) != CWSLG_OK) die("slot_boundary", rc);
         ++boundaries;
+        if (world > 1) {                                         // bit 0 of every rank's flag: "my inputs are exhausted"
+            cwslg_stats st;
+            cwslg_get_stats(ctx, &st);
+            all_done = (st.rendezvous_flags_and & 1u) != 0;
+        }
+        if (inputs_done) return;                                 // only here for the collective: this rank's last frames went out before
         for (Chan &c : chans) {
             if (c.spec.group != group) continue;
             pcm.resize(c.spec.frame_len);
@@ -292,6 +315,23 @@ int main(int argc, char **argv)
         std::fflush(log);
     };
 
+    // due edges fire in TIME order across the groups (ties: lower group first), so that every rank makes the same sequence of
+    // (collective) boundary calls however far its own clock has jumped since the last look
+    auto fire_next = [&]() {
+        size_t k = 0;
+        for (size_t q = 1; q < next_edge.size(); ++q)
+            if (next_edge[q].second < next_edge[k].second || (next_edge[q].second == next_edge[k].second && next_edge[q].first < next_edge[k].first)) k = q;
+        publish(next_edge[k].first, next_edge[k].second);
+        next_edge[k].second = cwslg_slot_clock_next(next_edge[k].first, next_edge[k].second);
+    };
+    auto fire_due = [&](uint64_t now_ms) {
+        for (;;) {
+            uint64_t first = ~0ull;
+            for (const auto &ge : next_edge) first = std::min(first, ge.second);
+            if (next_edge.empty() || first > now_ms) break;
+            fire_next();
+        }
+    };
     for (Rx &r : rxs) {
         r.queue.reset(new BlockQueue);
         if (r.eof) { r.queue->finish(); continue; }            // not this rank's band
@@ -337,8 +377,15 @@ int main(int argc, char **argv)
             if (t < 0) t = (double)r.samples / r.spec.fs;
             now_ms = start_ms + (uint64_t)(t * 1000.0);
         }
-        for (auto &ge : next_edge)
-            while (ge.second <= now_ms) { publish(ge.first, ge.second); ge.second = cwslg_slot_clock_next(ge.first, ge.second); }
+        fire_due(now_ms);
+    }
+    if (world > 1) {
+        // The end of a run is collective: a rank whose bands ended (EOF, --max-seconds) goes on making the boundary calls, in the same
+        // global order and without publishing anything, until EVERY rank has said so through the rendezvous flag -- the others are
+        // blocked inside exactly these collectives and would otherwise wait for ever.
+        inputs_done = true;
+        cwslg_set_rendezvous_flag(ctx, 1);
+        while (!all_done) fire_next();
     }
     for (Rx &r : rxs) r.queue->abort();
     for (Rx &r : rxs) if (r.reader.joinable()) r.reader.join();

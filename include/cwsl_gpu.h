@@ -169,7 +169,8 @@ int cwslg_process(cwslg_ctx *ctx);
  * per-Instance reaction to it (Instance.cpp:203-253): swap frames, stamp the new frame with epoch_s,
  * finalise (peak-normalise + int16) the finished one unless its start time is 0, restart the demodulator. */
 int cwslg_slot_boundary(cwslg_ctx *ctx, int group, uint64_t epoch_s);
-/* The same boundary in two halves, for a throughput host that keeps the GPU busy across boundaries (bench.py with N > 1): _begin queues
+/* (cwslg_slot_boundary and _begin fail with CWSLG_ERR_ARG while a boundary opened by _begin has not been ended.)
+ * The same boundary in two halves, for a throughput host that keeps the GPU busy across boundaries (bench.py with N > 1): _begin queues
  * the boundary's device work and returns; the host queues the next slot's demodulation; _end waits for the boundary's own kernels
  * (not for the stream) and runs the rendezvous, which thereby overlaps the next demod launch.  Without a rendezvous installed _end
  * does nothing.  Do not fetch the epoch's frames or candidates before _end has returned; one boundary may be open at a time. */
@@ -190,10 +191,17 @@ int cwslg_synchronize(cwslg_ctx *ctx);
  * not call back into the same context.  Return 0 or a negative CWSLG_ERR_*; the total is kept in the stats. */
 typedef int (*cwslg_rendezvous_fn)(void *user, int group, uint64_t epoch_s, uint64_t frames_local, uint64_t *frames_total);
 int cwslg_set_boundary_rendezvous(cwslg_ctx *ctx, cwslg_rendezvous_fn fn, void *user);
-/* Built-in rendezvous for C/C++ hosts: a 1-element uint64 sum all-reduce on RCCL over xGMI, enqueued on the context
- * stream.  librccl is opened on first use (a process that already carries one, e.g. torch's, shares it).
+/* Built-in rendezvous (C/C++ hosts; bench.py's default for N > 1): ONE all-gather of 24 bytes per rank on RCCL over xGMI -- (frames,
+ * group, epoch) -- enqueued on the context's SIDE stream (the context stream may already hold the next slot's demodulation): every
+ * rank sums the frames and checks that all ranks are at the same group and epoch; a mismatch fails the boundary on every rank with
+ * CWSLG_ERR_ARG.  librccl is opened on first use (a process that already carries one, e.g. torch's, shares it).
  * cwslg_rccl_unique_id fills the 128-byte ncclUniqueId on rank 0; the host program hands it to the other ranks by any
  * means (cwsl_gpu_skimmer: a file); every rank then calls cwslg_rccl_init, which installs the rendezvous. */
+/* A 64-bit flag word this process contributes to every later built-in rendezvous; stats.rendezvous_flags_and is the AND over all ranks
+ * at the last one.  cwsl_gpu_skimmer sets bit 0 when its inputs are exhausted and leaves its loop when every rank has: a rank whose
+ * band ends early keeps making the (collective) boundary calls until then instead of leaving the others blocked.  Only the built-in
+ * form carries it (a callback rendezvous sees this process's own value). */
+int cwslg_set_rendezvous_flag(cwslg_ctx *ctx, uint64_t flag);
 #define CWSLG_RCCL_ID_BYTES 128
 int cwslg_rccl_unique_id(void *id_out);
 int cwslg_rccl_init(cwslg_ctx *ctx, const void *id, int rank, int world);
@@ -350,6 +358,8 @@ typedef struct {
     uint64_t phasor_regrows;       /* checkpoint tables extended because a channel kept discarding frames */
     uint64_t rendezvous_calls;     /* slot boundaries that went through the multi-GPU rendezvous          */
     uint64_t rendezvous_frames;    /* frames over ALL processes at the last rendezvous                    */
+    uint64_t rccl_world;           /* ranks of the built-in RCCL communicator (cwslg_rccl_init), 0 without one */
+    uint64_t rendezvous_flags_and; /* AND over all ranks of cwslg_set_rendezvous_flag's value at the last built-in rendezvous */
 } cwslg_stats;
 int cwslg_get_stats(cwslg_ctx *ctx, cwslg_stats *out);
 int cwslg_reset_stats(cwslg_ctx *ctx);

@@ -108,6 +108,17 @@ def test_builtin_rccl_rendezvous_world_1():
         ctx.rccl_init(uid, 0, 1)
         first, st, crcs = _run_slots(ctx, range(3))
         assert first == 0 and st["rendezvous_calls"] == 2 and st["rendezvous_frames"] == 3 == st["frames_emitted"]
+        assert st["rccl_world"] == 1 and st["rendezvous_flags_and"] == 0
+        # the flag word every rank contributes ("my inputs are exhausted"): AND over the ranks after the next boundary
+        ctx.set_rendezvous_flag(1)
+        ctx.slot_boundary("FT8", 99)
+        assert ctx.stats()["rendezvous_flags_and"] == 1
+        # a one-call boundary while a split one is open is refused, and ending it clears the state
+        ctx.slot_boundary_begin("FT8", 100)
+        with pytest.raises(Exception):
+            ctx.slot_boundary("FT8", 101)
+        ctx.slot_boundary_end()
+        ctx.slot_boundary("FT8", 102)
     with P.Context(0) as ctx:                          # the two-halves form: the all-reduce runs beside the next slot's demod launch
         ctx.rccl_init(P.rccl_unique_id(), 0, 1)
         first2, st2, crcs2 = _run_slots(ctx, range(3), split=True)

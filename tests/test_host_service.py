@@ -160,12 +160,14 @@ def test_skimmer_shards_decoders_by_receiver(tmp_path):
     whole = json.loads(subprocess.run(base, capture_output=True, text=True).stdout)["plan"]
     shares = []
     for rank in range(2):
-        out = subprocess.run(base + ["--world", "2", "--rank", str(rank), "--rccl-id", str(tmp_path / "id")], capture_output=True, text=True)
+        out = subprocess.run(base + ["--world", "2", "--rank", str(rank), "--rccl-id", str(tmp_path / "id"), "--start-ms", "1700000000000"],
+                             capture_output=True, text=True)
         assert out.returncode == 0, out.stderr
         plan = json.loads(out.stdout)["plan"]
         assert plan and all(p["rx"] % 2 == rank for p in plan)
         shares += plan
     assert sorted(shares, key=lambda p: (p["rx"], p["freq_hz"])) == sorted(whole, key=lambda p: (p["rx"], p["freq_hz"]))
-    # a world larger than the number of receivers, a rank outside the world, or no id file: usage errors
-    for bad in (["--world", "2", "--rank", "2", "--rccl-id", "x"], ["--world", "2", "--rank", "0"]):
+    # a rank outside the world, no id file, or no common --start-ms (the ranks must fire the same boundary sequence): usage errors
+    for bad in (["--world", "2", "--rank", "2", "--rccl-id", "x", "--start-ms", "1"], ["--world", "2", "--rank", "0", "--start-ms", "1"],
+                ["--world", "2", "--rank", "0", "--rccl-id", "x"]):
         assert subprocess.run(base + bad, capture_output=True, text=True).returncode == 2
