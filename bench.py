@@ -35,6 +35,16 @@ SLOT_SAMPLES = 2880000                    # 15 s FT8 slot at 192 kHz
 HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_SAMPLE_DEMOD = 8.0 + 4.0 / 16   # demod kernel: 8 B IQ read + 0.25 B float audio write
 BYTES_PER_SAMPLE_PATH = 8.625             # + finalise: 0.25 B read + 0.125 B int16 write
+VALU_PEAK_TFLOPS = 157.3                  # MI355X_MICROARCH.md: FP32 vector peak (spec), an FMA counted as 2
+# FT8 sync stage, floating-point operations of the "spec v2" arithmetic (oracle/sync_oracle.c; an FMA = 2), per 3840-point symbol transform:
+#   scale by 1/300                                  3 840
+#   stage 1: 128 columns x (output 0: 14; 7 conjugate pairs x (4 chains x 7 FMA = 56, combine 8, two twiddle products 12))  = 128 x 546 = 69 888
+#   stage 2: 15 rows x 7 radix-2 stages x 64 butterflies x 10                                                               = 67 200
+#   real-input unpack + |X|^2 of the stored bins:   20 per bin
+# and per searched bin of the Costas stage: 7-tone sums 6 x 378 adds, 125 lags x (42 adds + 30 for the two sync ratios) = 11 268
+def sync_flops_per_slot(nbins, n_search_bins):
+    per_transform = 3840 + 69888 + 67200 + 20 * nbins
+    return 372 * per_transform + n_search_bins * 11268, per_transform
 
 
 def host_cores():
@@ -274,6 +284,30 @@ def main():
     total_samples = float(world) * S * SLOT_SAMPLES * args.steps
     msps = total_samples / dt / 1e6
 
+    def roofline_sync(st_):
+        """The FT8 sync stage (symbol spectra + Costas search + candidate selection) against the FP32 vector peak: it is VALU-bound
+        (AI ~ 1e2 flop/B on its compulsory traffic).  Flops are the algorithm's (counted above), time is HIP events
+        around the stage's launches; the bytes the stage moves through the fabric are replayed from the committed PMC summary."""
+        if not args.sync or not st_["sync_launches"]:
+            return None
+        nbins, nsearch = 992, 897                     # jt9 -8 defaults: bins 64..960 searched, rows of 992 bins stored
+        per_slot, per_transform = sync_flops_per_slot(nbins, nsearch)
+        ms = st_["sync_ms"] / st_["sync_launches"]
+        tfl = per_slot * S / (ms * 1e-3) / 1e12
+        fabric, src = None, None
+        tp = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
+        if os.path.isfile(tp):
+            try:
+                for tj in json.load(open(tp)).get("sync_runs", []):
+                    if tj.get("slots") == S:
+                        fabric, src = tj.get("fabric_bytes_per_boundary"), "replayed: " + tj.get("source", "")
+            except Exception:
+                pass
+        return {"bound": "valu", "kernels": "symbol_spectra_v2_kernel + ft8_sync2d_v2_kernel + ft8_candidates_kernel<1024>",
+                "avg_ms": ms, "transforms": 372 * S, "flop_per_transform": per_transform, "flop_per_slot": per_slot,
+                "achieved_tflops": tfl, "peak_tflops": VALU_PEAK_TFLOPS, "frac": tfl / VALU_PEAK_TFLOPS,
+                "algorithmic_bytes": S * (240000 * 2 + 200 * 20), "fabric_bytes": fabric, "fabric_source": src}
+
     # ---- CPU baseline: the oracle in the reference's shape, on this box's host cores (rank 0, N=1 only)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -340,6 +374,7 @@ def main():
                          "finalize_avg_ms": st["finalize_ms"] / max(1, st["finalize_launches"]),
                          "sync_avg_ms": st["sync_ms"] / max(1, st["sync_launches"]),
                          "whole_path_frac": BYTES_PER_SAMPLE_PATH * samples_per_launch * args.steps / dt / 1e9 / HBM_PEAK_GBS},
+            "roofline_sync": roofline_sync(st),
             "mode": ("exact: reference-order arithmetic, bit-identical (the product default)" if args.exact else
                      "fast: fused polyphase arithmetic (cwslg_set_exact(ctx, 0)), float audio within 1e-5 of frame peak"),
             "exact": exact_rec,

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void symbol_spectra_kernel(const SyncWork *__r
 //       K = NA (q + 64) + r   A = v1', B = conj u2'        K = NA (127 - q) + NA - r     A = v2', B = conj u1'
 //     (Z[c + NA d] = y[c][d], X[K] pairs Z[K] with Z[NZ - K]); bins >= nbins are skipped.  That removes 15 KB of stores and
 //     15 KB of loads per transform, the loop over residues and one barrier.
-// Needs nbins <= NIN (the power row is staged in LDS); wider searches use the first version.
+// Needs nbins <= NIN + 32 (the power row is staged in LDS).
 template <int HALF, int NA, int AMAX>
 __device__ __forceinline__ void spectra_stage1_regs(const float2 (&z)[AMAX], float2 (*s_y)[SY_PITCH], const SyncTables &tb,
                                                     const Stage1Tw<NA> &twp, int b)
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     constexpr int NH = NA / 2;                            // row pairs (r, NA - r), r = 1..NH; row 0 pairs with itself
     constexpr int NITEM = (NH + 1) * 64, IPT = (NITEM + 255) / 256;
     static_assert(NGRP <= 256, "geometry");
-    __shared__ __attribute__((aligned(16))) float s_pw[NIN + 16];
+    __shared__ __attribute__((aligned(16))) float s_pw[NIN + 32];     // one power row: nbins <= NIN + 32 (FT8: the widest search stores 1952)
     __shared__ float2 s_y[NA][SY_PITCH];
     __shared__ float2 s_w128[64];
     const SyncWork *w = works + blockIdx.y;
@@ -966,18 +966,13 @@ __global__ __launch_bounds__(SYNC2D_NT, 4) void ft8_sync2d_v2_kernel(const SyncW
             for (int mp = lane; mp < PP; mp += 64) {
                 v2f acc = {0.0f, 0.0f};
 #pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    const v2f x = s_s2[(rr + 2 * k) * PP + mp];
-                    acc.x = acc.x + x.x;
-                    acc.y = acc.y + x.y;
-                }
+                for (int k = 0; k < 7; ++k) acc = acc + s_s2[(rr + 2 * k) * PP + mp];      // two steps per lane: one v_pk_add_f32 each
                 c02[mp] = acc;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            float ta0 = 0, tb0 = 0, tc0 = 0, ua0 = 0, ub0 = 0, uc0 = 0;      // lag j:     t sums, t0 sums
-            float ta1 = 0, tb1 = 0, tc1 = 0, ua1 = 0, ub1 = 0, uc1 = 0;      // lag j + 1
+            v2f ta = {0, 0}, tb = {0, 0}, tc = {0, 0}, ua = {0, 0}, ub = {0, 0}, uc = {0, 0};   // t sums, t0 sums of lags (j, j + 1): packed adds
 #pragma unroll
             for (int n = 0; n < 7; ++n) {
                 const v2f *row = s_s2 + (rr + 2 * icos[n]) * PP;
@@ -987,12 +982,12 @@ __global__ __launch_bounds__(SYNC2D_NT, 4) void ft8_sync2d_v2_kernel(const SyncW
                 const v2f va = row[pa], wa = c02[pa];
                 const v2f vb = row[pb], wb = c02[pb];
                 const v2f vc = row[pc], wc = c02[pc];
-                ta0 = ta0 + va.x; ua0 = ua0 + wa.x; ta1 = ta1 + va.y; ua1 = ua1 + wa.y;
-                tb0 = tb0 + vb.x; ub0 = ub0 + wb.x; tb1 = tb1 + vb.y; ub1 = ub1 + wb.y;
-                tc0 = tc0 + vc.x; uc0 = uc0 + wc.x; tc1 = tc1 + vc.y; uc1 = uc1 + wc.y;
+                ta = ta + va; ua = ua + wa;
+                tb = tb + vb; ub = ub + wb;
+                tc = tc + vc; uc = uc + wc;
             }
-            const float sa = ok0 ? sync_finish(ta0, tb0, tc0, ua0, ub0, uc0) : ninf;
-            const float sb = ok1 ? sync_finish(ta1, tb1, tc1, ua1, ub1, uc1) : ninf;
+            const float sa = ok0 ? sync_finish(ta.x, tb.x, tc.x, ua.x, ub.x, uc.x) : ninf;
+            const float sb = ok1 ? sync_finish(ta.y, tb.y, tc.y, ua.y, ub.y, uc.y) : ninf;
             // +-62: the lane's own first maximum (lag j before j + 1), then the wavefront's
             const bool b2 = sb > sa;
             float r2; int l2;
@@ -1043,23 +1038,34 @@ __device__ void bitonic_sort_n(float *kv, int *ki, int n, int tid)
 // grid (n_channels), NT threads.  The kernel is a chain of ~165 barrier-separated stages on <= 1024 keys: with 1024 threads every
 // stage is one pass (one compare-exchange per thread), so its length is the barrier count, not the key count (round 1 ran it
 // with 256 threads: 0.15 ms per 512 channels, now NT = 1024).
+// LDS of the candidate selection, carved from one pool so that ft8_sync_chan_kernel can overlay it on its band image.
 template <int NT>
-__global__ __launch_bounds__(NT) void ft8_candidates_kernel(const SyncWork *__restrict__ works, int ia, int ib,
-                                                              float syncmin, int maxcand)
+struct CandLds {
+    static constexpr size_t kv = 0, ki = kv + 2048 * 4, red = ki + 2048 * 4, red2 = red + (FT8_NH1 + 1) * 4 + 12, jp = red2 + (FT8_NH1 + 1) * 4 + 12,
+                            jp2 = jp + (FT8_NH1 + 1) * 2 + 14, first = jp2 + (FT8_NH1 + 1) * 2 + 14, second = first + (FT8_NH1 + 2) * 2 + 12,
+                            desc = second + (FT8_NH1 + 2) * 2 + 12, scan = desc + SYNC_MAXPRE * 4, scan_lo = scan + NT * 4, cbin = scan_lo + 1024 * 4,
+                            clag = cbin + SYNC_MAXPRE * 4, csync = clag + SYNC_MAXPRE * 4, cf = csync + SYNC_MAXPRE * 4, ct = cf + SYNC_MAXPRE * 4,
+                            base = ct + SYNC_MAXPRE * 4, n = base + 16, bytes = n + 16;
+};
+
+// The candidate selection of one channel by the NT threads of a workgroup: red / jpeak come from global memory (written by this
+// workgroup or by an earlier kernel), `lds` holds CandLds<NT>::bytes bytes (16-byte aligned).
+template <int NT>
+__device__ void ft8_candidates_body(const SyncWork *w, int ia, int ib, float syncmin, int maxcand, char *lds)
 {
-    __shared__ float s_kv[2048];
-    __shared__ int s_ki[2048];
-    __shared__ float s_red[FT8_NH1 + 1], s_red2[FT8_NH1 + 1];
-    __shared__ short s_jp[FT8_NH1 + 1], s_jp2[FT8_NH1 + 1];
-    __shared__ short s_first[FT8_NH1 + 2], s_second[FT8_NH1 + 2];   // bin -> pre-candidate index (or -1)
-    __shared__ int s_desc[SYNC_MAXPRE];                 // bins in descending red order
-    __shared__ int s_scan[NT];
-    __shared__ unsigned s_scan_lo[1024];
-    __shared__ int s_cbin[SYNC_MAXPRE], s_clag[SYNC_MAXPRE];
-    __shared__ float s_csync[SYNC_MAXPRE], s_cf[SYNC_MAXPRE], s_ct[SYNC_MAXPRE];
-    __shared__ float s_base[2];
-    __shared__ int s_n;
-    const SyncWork *w = works + blockIdx.x;
+    using L = CandLds<NT>;
+    float *s_kv = reinterpret_cast<float *>(lds + L::kv);
+    int *s_ki = reinterpret_cast<int *>(lds + L::ki);
+    float *s_red = reinterpret_cast<float *>(lds + L::red), *s_red2 = reinterpret_cast<float *>(lds + L::red2);
+    short *s_jp = reinterpret_cast<short *>(lds + L::jp), *s_jp2 = reinterpret_cast<short *>(lds + L::jp2);
+    short *s_first = reinterpret_cast<short *>(lds + L::first), *s_second = reinterpret_cast<short *>(lds + L::second);   // bin -> pre-candidate index (or -1)
+    int *s_desc = reinterpret_cast<int *>(lds + L::desc);                 // bins in descending red order
+    int *s_scan = reinterpret_cast<int *>(lds + L::scan);
+    unsigned *s_scan_lo = reinterpret_cast<unsigned *>(lds + L::scan_lo);
+    int *s_cbin = reinterpret_cast<int *>(lds + L::cbin), *s_clag = reinterpret_cast<int *>(lds + L::clag);
+    float *s_csync = reinterpret_cast<float *>(lds + L::csync), *s_cf = reinterpret_cast<float *>(lds + L::cf), *s_ct = reinterpret_cast<float *>(lds + L::ct);
+    float *s_base = reinterpret_cast<float *>(lds + L::base);
+    int &s_n = *reinterpret_cast<int *>(lds + L::n);
     const int tid = threadIdx.x;
     const int iz = ib - ia + 1;
     const float df = 12000.0f / 3840.0f, tstep = 480.0f / 12000.0f;
@@ -1246,6 +1252,173 @@ __global__ __launch_bounds__(NT) void ft8_candidates_kernel(const SyncWork *__re
     if (nout) atomicAdd(&s_n, nout);
     __syncthreads();
     if (tid == 0) *w->ncand = min(s_n, maxcand);
+}
+
+// grid (n_channels), NT threads: the candidate selection as its own launch (lab build; the product fuses it into ft8_sync_chan_kernel).
+template <int NT>
+__global__ __launch_bounds__(NT) void ft8_candidates_kernel(const SyncWork *__restrict__ works, int ia, int ib,
+                                                              float syncmin, int maxcand)
+{
+    __shared__ __attribute__((aligned(16))) char s_pool[CandLds<NT>::bytes];
+    ft8_candidates_body<NT>(works + blockIdx.x, ia, ib, syncmin, maxcand, s_pool);
+}
+
+// ---------------------------------------------------------------------------------------------
+// ft8_sync_chan_kernel: the Costas search AND the candidate selection of one channel in one workgroup (grid = channels, 512 threads).
+// Same sums in the same order as ft8_sync2d_v2_kernel + ft8_candidates_kernel (bit-identical lists); what changes is how the
+// spectra reach the CU.  Round-2 form: one workgroup per 32-bin band staged the band's 44 rows as 372 runs of 176 bytes, 3904 bytes
+// apart (each run 2-3 partial cache lines; neighbouring bands fetched 12 of the 44 rows again): 2.74 ms per 4096 slots for 5.9 GB,
+// then a third launch whose ~165 barrier-separated stages left the chip idle for 0.6 ms.  Now:
+//   * the workgroup walks ALL bands of its channel with a sliding LDS window: a band's last 12 rows become the next band's first 12
+//     (an LDS move), and only the 32 NEW bins are fetched -- exactly one 128-byte line per symbol step (bands start at bins = 20 mod
+//     32 and the spectra rows have a pitch of 32 floats, so bins i0 + 12 .. i0 + 43 are a whole line): every spectrum element leaves
+//     HBM once, in whole lines;
+//   * the next band's 372 lines are in flight, in 24 registers per lane, while the current band is searched;
+//   * when the last band is done the same workgroup runs the candidate selection on the red / jpeak values it has just written
+//     (its LDS overlays the band image); other workgroups of the CU are in their search phase meanwhile, so the selection's
+//     barrier chains no longer hold the chip.
+constexpr int SYNCC_NT = 512;
+__global__ __launch_bounds__(SYNCC_NT, 4) void ft8_sync_chan_kernel(const SyncWork *__restrict__ works, int ia, int ib, int nbins,
+                                                                     float syncmin, int maxcand)
+{
+    constexpr int ROWS = SYNC_BAND + 12, NW = SYNCC_NT / 64;
+    constexpr int UN = (FT8_NHSYM + NW - 1) / NW;                              // symbol steps per wave when one step = one load: 47
+    constexpr int PF = (FT8_NHSYM + 2 * NW - 1) / (2 * NW);                    // ... when one load carries two steps (32 bins each): 24
+    constexpr size_t IMG_BYTES = (size_t)(ROWS + NW) * S2_PITCH * sizeof(float);
+    constexpr size_t POOL_BYTES = IMG_BYTES > CandLds<SYNCC_NT>::bytes ? IMG_BYTES : CandLds<SYNCC_NT>::bytes;
+    __shared__ __attribute__((aligned(16))) char s_pool[POOL_BYTES];
+    float (*s_s)[S2_PITCH] = reinterpret_cast<float (*)[S2_PITCH]>(s_pool);                       // s_s[r][m + 2] = s(i0 + r, m)
+    float (*s_c0)[S2_PITCH] = reinterpret_cast<float (*)[S2_PITCH]>(s_pool + (size_t)ROWS * S2_PITCH * sizeof(float));
+    const SyncWork *w = works + blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // first band: the largest start = 20 (mod 32) that is <= ia (bins below ia are staged but not searched)
+    const int i_first = ia - (((ia - 20) % 32) + 32) % 32;
+    const int nbands = (ib - i_first) / SYNC_BAND + 1;
+    const CWSLG_GLOBAL float *spec = as_global(w->spectra);
+    {   // band 0: all 44 rows, one step per load (lanes 0..43), every load of the wave issued before the first LDS write
+        const int col = i_first + lane;
+        const bool on = lane < ROWS && col >= 0 && col < nbins;
+        const CWSLG_GLOBAL float *sp = spec + (on ? col : 0);
+        float v[UN];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const int m = wv + NW * q;
+            v[q] = (on && m < FT8_NHSYM) ? sp[(size_t)m * nbins] : 0.0f;
+        }
+        float *dst = &s_s[lane < ROWS ? lane : 0][S2_COL0 + 1 + wv];
+#pragma unroll
+        for (int q = 0; q < UN; ++q)
+            if (lane < ROWS && wv + NW * q < FT8_NHSYM) dst[NW * q] = v[q];
+        if (tid < ROWS) {
+            float *row = s_s[tid];
+            row[0] = 0.0f; row[1] = 0.0f; row[2] = 0.0f;                        // m = -2, -1, 0
+            row[S2_COL0 + 373] = 0.0f; row[S2_COL0 + 374] = 0.0f; row[S2_COL0 + 375] = 0.0f;
+        }
+    }
+    __syncthreads();
+    float *c0 = s_c0[wv];
+    constexpr unsigned ICOS = 0x2560413u;                  // the Costas array 3,1,4,0,6,5,2, one nibble per symbol
+    const int j = 2 * lane - FT8_JZ;                       // this lane's lag pair (j, j + 1); lane 63 has none
+    const bool ok0 = j <= FT8_JZ, ok1 = j + 1 <= FT8_JZ;
+    const bool near0 = j >= -10 && j <= 10, near1 = j + 1 >= -10 && j + 1 <= 10;
+    const float ninf = -__builtin_huge_valf();
+    const int pa0 = lane - 24, pb0 = pa0 + 72, pc0 = pa0 + 144;
+    constexpr int PP = S2_PITCH / 2;                       // float2 per row
+    const v2f *s_s2 = reinterpret_cast<const v2f *>(&s_s[0][0]);
+    v2f *c02 = reinterpret_cast<v2f *>(c0);
+    const int half = lane >> 5, c32 = lane & 31;           // the prefetch: lanes 0-31 one step, lanes 32-63 the next; lane = bin
+    for (int band = 0; band < nbands; ++band) {
+        const int i0 = i_first + band * SYNC_BAND;
+        // ---- the NEXT band's 32 new bins (i0 + 44 .. i0 + 75) of every symbol step: one whole 128-byte line per step
+        float pf[PF];
+        const bool more = band + 1 < nbands;               // workgroup-uniform
+        if (more) {
+            // one uniform base + a 32-bit lane offset per load (a pointer per load would be 48 more registers)
+            const int col = i0 + ROWS + c32;
+            const bool on = col < nbins;
+            const unsigned o0 = (unsigned)((on ? col : 0) + (2 * wv + half) * nbins);
+            const unsigned ostep = (unsigned)(2 * NW * nbins);
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int m = 2 * (wv + NW * q) + half;
+                pf[q] = (on && m < FT8_NHSYM) ? spec[o0 + (unsigned)q * ostep] : 0.0f;
+            }
+        }
+        // ---- search this band: one wave per bin at a time, each wave owns s_c0[wv] (see ft8_sync2d_v2_kernel)
+        for (int rr = wv; rr < SYNC_BAND; rr += NW) {
+            const int bin = i0 + rr;
+            if (bin > ib) break;                            // wave-uniform
+            if (bin < ia) continue;
+            for (int mp = lane; mp < PP; mp += 64) {
+                v2f acc = {0.0f, 0.0f};
+#pragma unroll
+                for (int k = 0; k < 7; ++k) acc = acc + s_s2[(rr + 2 * k) * PP + mp];      // two steps per lane: one v_pk_add_f32 each
+                c02[mp] = acc;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            v2f ta = {0, 0}, tb = {0, 0}, tc = {0, 0}, ua = {0, 0}, ub = {0, 0}, uc = {0, 0};   // t sums, t0 sums of lags (j, j + 1): packed adds
+            // (not unrolled: with all 42 reads of a lag pair in flight at once the search alone needs 118 VGPRs, and the 24 prefetch
+            // registers on top of that spill at four waves per SIMD; partly unrolled forms -- 4 + 3, 3 + 2 + 2 symbols -- spilled too)
+#pragma unroll 1
+            for (int n = 0; n < 7; ++n) {
+                const v2f *row = s_s2 + (rr + 2 * (int)((ICOS >> (4 * n)) & 7u)) * PP;
+                int pa = pa0 + 2 * n; pa = pa < 0 ? 0 : pa;                   // m < -2  -> the zero pair (m = -2, -1)
+                int pc = pc0 + 2 * n; pc = pc > PP - 1 ? PP - 1 : pc;         // m > 374 -> the zero pair (m = 374, 375)
+                const int pb = pb0 + 2 * n;
+                const v2f va = row[pa], wa = c02[pa];
+                const v2f vb = row[pb], wb = c02[pb];
+                const v2f vc = row[pc], wc = c02[pc];
+                ta = ta + va; ua = ua + wa;
+                tb = tb + vb; ub = ub + wb;
+                tc = tc + vc; uc = uc + wc;
+            }
+            const float sa = ok0 ? sync_finish(ta.x, tb.x, tc.x, ua.x, ub.x, uc.x) : ninf;
+            const float sb = ok1 ? sync_finish(ta.y, tb.y, tc.y, ua.y, ub.y, uc.y) : ninf;
+            const bool b2 = sb > sa;
+            float r2; int l2;
+            wave_first_max(b2 ? sb : sa, b2 ? j + 1 : j, r2, l2);
+            const float na = near0 ? sa : ninf, nb = near1 ? sb : ninf;
+            const bool b1 = nb > na;
+            float r1; int l1;
+            wave_first_max(b1 ? nb : na, b1 ? j + 1 : j, r1, l1);
+            if (lane == 0) {
+                w->red[bin] = r1;  w->jpeak[bin] = l1;
+                w->red2[bin] = r2; w->jpeak2[bin] = l2;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();               // c0 is rewritten by the next bin
+        }
+        if (!more) break;
+        __syncthreads();                                    // every wave has finished reading the image
+        // ---- slide the window: rows 32..43 become rows 0..11, then the prefetched lines fill rows 12..43
+        float mv[(12 * S2_PITCH + SYNCC_NT - 1) / SYNCC_NT];
+#pragma unroll
+        for (int q = 0; q < (12 * S2_PITCH + SYNCC_NT - 1) / SYNCC_NT; ++q) {
+            const int e = tid + SYNCC_NT * q;
+            mv[q] = (e < 12 * S2_PITCH) ? (&s_s[SYNC_BAND][0])[e] : 0.0f;
+        }
+        __syncthreads();                                    // (rows 32..43 are also among the rows the prefetch overwrites)
+#pragma unroll
+        for (int q = 0; q < (12 * S2_PITCH + SYNCC_NT - 1) / SYNCC_NT; ++q) {
+            const int e = tid + SYNCC_NT * q;
+            if (e < 12 * S2_PITCH) (&s_s[0][0])[e] = mv[q];
+        }
+        {
+            float *dst = &s_s[12 + c32][S2_COL0 + 1 + half];
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int m = 2 * (wv + NW * q) + half;
+                if (m < FT8_NHSYM) dst[2 * (wv + NW * q)] = pf[q];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- candidate selection on the values this workgroup has just written (global memory, same CU: visible once the stores have
+    // retired, which the barrier's vmcnt(0) ensures)
+    __syncthreads();
+    ft8_candidates_body<SYNCC_NT>(w, ia, ib, syncmin, maxcand, s_pool);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -1,9 +1,9 @@
 #!/bin/bash
 # kernel stats + SQ counters of the sync kernels (bench, 512 slots)
 mkdir -p gpurun_out/pmcs; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- python3 $R/bench.py --no-cpu-baseline --verify 0 --steps 3 --warmup 1 > $R/gpurun_out/prof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -- python3 $R/bench.py --no-cpu-baseline --verify 0 --steps 3 --warmup 1 --fast-only > $R/gpurun_out/prof.log 2>&1
 run() { name=$1; shift
-  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmcs/$name -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --verify 0 > $R/gpurun_out/pmcs/$name.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmcs/$name -- python3 $R/bench.py --steps 2 --warmup 1 --fast-only --no-cpu-baseline --verify 0 > $R/gpurun_out/pmcs/$name.log 2>&1
 }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
 run sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM
@@ -16,6 +16,6 @@ for d in sorted(glob.glob('gpurun_out/pmcs/*/')):
         for row in csv.DictReader(open(f)):
             agg[row['Kernel_Name'][:40]][row['Counter_Name']].append(float(row['Counter_Value']))
         for k,v in agg.items():
-            if 'spectra' in k or 'sync2d' in k or 'candidates' in k:
+            if 'spectra' in k or 'sync' in k or 'candidates' in k:
                 print(d.split('/')[-2], k, {c:'%.4g'%(sum(x)/len(x)) for c,x in v.items()})
 PY
