@@ -50,6 +50,12 @@ namespace cwslg {
 #ifndef CWSLG_FIR_PK
 #define CWSLG_FIR_PK 0
 #endif
+// -DCWSLG_DIAG_NOHALO=1 (timing only, results are garbage; scripts/gpu_nohalo.sh): the tile kernels neither load nor mix the first
+// 2 NT samples of a tile -- about the 31-block halo a workgroup that STREAMED a channel's tiles would still hold in LDS -- to bound
+// from above what such a streaming form could gain.
+#ifndef CWSLG_DIAG_NOHALO
+#define CWSLG_DIAG_NOHALO 0
+#endif
 #define CWSLG_GLOBAL __attribute__((address_space(1)))
 template <typename T>
 __device__ __forceinline__ const CWSLG_GLOBAL T *as_global(const T *p)
@@ -380,13 +386,13 @@ __device__ __forceinline__ void issue_tile_loads(const TileCtx<D, T> &c, int tid
         // tid, no per-load wrap arithmetic (it was 6 VALU instructions per load)
         const CWSLG_GLOBAL v4f *p = ring4 + (c.base >> 1);
 #pragma unroll
-        for (int it = 0; it < NIT - 1; ++it) xs[it] = p[tid + it * NT];
+        for (int it = CWSLG_DIAG_NOHALO; it < NIT - 1; ++it) xs[it] = p[tid + it * NT];
         int r = 2 * tid + (NIT - 1) * 2 * NT;
         if (r > Geo::NSAMP - 2) r = Geo::NSAMP - 2;            // clamp: the load is unconditional
         xs[NIT - 1] = p[r >> 1];
     } else {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
+        for (int it = CWSLG_DIAG_NOHALO; it < NIT; ++it) {
             int r = 2 * tid + it * 2 * NT;
             if (r > Geo::NSAMP - 2) r = Geo::NSAMP - 2;
             unsigned idx = c.base + (unsigned)r;
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
         {
             float2 ph[NIT];
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
+            for (int it = CWSLG_DIAG_NOHALO; it < NIT; ++it) {
                 int blk = (2 * tid) / D + it * (2 * NT / D);
                 if (blk > Geo::NBLK - 1) blk = Geo::NBLK - 1;
                 ph[it] = s_phase[blk];
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
             auto mix = [&](auto slow_tag) {
                 constexpr bool SLOW = decltype(slow_tag)::value;
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) {
+                for (int it = CWSLG_DIAG_NOHALO; it < NIT; ++it) {
                     const int r = 2 * tid + it * 2 * NT;
                     const v4f x = xs[it];
                     if (has_next) {                                  // in-place prefetch: xs[it] is free from here on
@@ -1155,7 +1161,7 @@ __global__ __launch_bounds__(NT, 4) void ring_probe_kernel(const ChanWork *__res
     issue_tile_loads<D, T, NT>(cur, tid, xs, ck, tn);
     float s = ck.x + tn.x + taps[tid & 15];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) s += xs[it].x + xs[it].y + xs[it].z + xs[it].w;
+    for (int it = CWSLG_DIAG_NOHALO; it < NIT; ++it) s += xs[it].x + xs[it].y + xs[it].z + xs[it].w;
     if (FLAVOUR >= 2) s += s_pad[(threadIdx.x * 7) % 9900];
     if (FLAVOUR >= 3) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

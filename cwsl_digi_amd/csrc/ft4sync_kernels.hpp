@@ -52,6 +52,7 @@ __device__ __forceinline__ float2 cmulc_f(float2 v, float2 w)         // v * con
 }
 __device__ __forceinline__ int rev6(int b) { return (int)(__brev((unsigned)b) >> 26); }
 
+#if CWSLG_LAB      // the VALU form of the 567-point DFTs (CWSLG_FT4_DFT=valu), lab library only
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ft4_dft567_kernel(const Ft4Work *__restrict__ works, Ft4Tables tb)
 {
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(256) void ft4_dft567_kernel(const Ft4Work *__restri
         if (c < F4C_NA) w->y[c * 64 + rev6(b)] = cmul_f(make_float2(yr[i], yi[i]), tb.wn2[b * c]);
     }
 }
+#endif  // CWSLG_LAB
 
 // The same 567-point DFTs on the matrix cores.  Y[c][b] = sum_a W567^(ac) z[a][b] is a dense 567 x 567 by 567 x 64
 // complex product, and gfx950's f32 MFMA is bit for bit a k-ordered fmaf chain (cdna_hip_programming.md, 'FP32-input

@@ -689,6 +689,7 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     }
 }
 
+constexpr int SYNC2D_NT = 512;          // 8 waves: one bin per wave at a time, 4 bins per wave per band
 // ---------------------------------------------------------------------------------------------
 // Costas correlation + lag peak search.  grid (ceil((ib-ia+1)/32), n_channels), 256 threads.
 // LDS: the band's 44 spectrum rows [44][376] (66 KB) + per-bin 7-tone sums for the 2 bins in flight => 2 WG/CU.
@@ -737,6 +738,7 @@ __device__ __forceinline__ float key_value(unsigned long long k)
 // even-aligned are ONE 8-byte read: half the LDS instructions of a lag-per-read search and ds_read_b64's 256 B/clk instead
 // of ds_read_b32's 128.  A term the restatement skips (m < 1 or m > NHSYM) is read from a clamped address and replaced by
 // +0.0: adding +0.0 to a non-negative float sum is exact, so the sums are the restatement's bit for bit.
+#if CWSLG_LAB      // round 1's Costas search (CWSLG_SYNC_VARIANT bit 0), lab library only
 struct SyncPair { float a, b; };
 __device__ __forceinline__ SyncPair costas_sync2(const float (*s_s)[376], const float *s_c0, int rr, int j)
 {
@@ -783,7 +785,6 @@ __device__ __forceinline__ SyncPair costas_sync2(const float (*s_s)[376], const 
     return SyncPair{finish(ta0, tb0, tc0, ua0, ub0, uc0), finish(ta1, tb1, tc1, ua1, ub1, uc1)};
 }
 
-constexpr int SYNC2D_NT = 512;          // 8 waves: one bin per wave at a time, 4 bins per wave per band
 __global__ __launch_bounds__(SYNC2D_NT) void ft8_sync2d_kernel(const SyncWork *__restrict__ works, int ia, int ib, int nbins)
 {
     constexpr int ROWS = SYNC_BAND + 12, PITCH = 376;
@@ -858,6 +859,7 @@ __global__ __launch_bounds__(SYNC2D_NT) void ft8_sync2d_kernel(const SyncWork *_
     }
 }
 
+#endif  // CWSLG_LAB
 // ---------------------------------------------------------------------------------------------
 // ft8_sync2d_v2_kernel: the same search, same sums in the same order (bit-identical results), restructured after the
 // round-1 counters (LDS 53 % busy with 28 % of it bank conflicts, 2232 VALU instructions per wave):
@@ -1263,6 +1265,7 @@ __global__ __launch_bounds__(NT) void ft8_candidates_kernel(const SyncWork *__re
     ft8_candidates_body<NT>(works + blockIdx.x, ia, ib, syncmin, maxcand, s_pool);
 }
 
+#if CWSLG_LAB      // measured alternative (CWSLG_SYNC_VARIANT bit 7), lab library only
 // ---------------------------------------------------------------------------------------------
 // ft8_sync_chan_kernel: the Costas search AND the candidate selection of one channel in one workgroup (grid = channels, 512 threads).
 // Same sums in the same order as ft8_sync2d_v2_kernel + ft8_candidates_kernel (bit-identical lists); what changes is how the
@@ -1421,6 +1424,7 @@ __global__ __launch_bounds__(SYNCC_NT, 4) void ft8_sync_chan_kernel(const SyncWo
     ft8_candidates_body<SYNCC_NT>(w, ia, ib, syncmin, maxcand, s_pool);
 }
 
+#endif  // CWSLG_LAB
 // ---------------------------------------------------------------------------------------------
 // FT4 candidate search (getcandidates4.f90 + ft4_baseline.f90), one workgroup per channel.  PARITY UNPINNED by the
 // reference; bit-exact against oracle/sync_oracle.c, whose builder-defined pieces are mirrored here operation for

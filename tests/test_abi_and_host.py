@@ -92,3 +92,35 @@ def test_shim_header_compiles():
     import subprocess
     subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror",
                            os.path.join(ROOT, "tests", "shim_compile_check.cpp")])
+
+
+def _kernel_names(path):
+    """Names of the gfx950 kernels in a shared library's code object (their .kd descriptors appear in its text)."""
+    data = open(path, "rb").read()
+    names = set(m.decode() for m in re.findall(rb"(_Z[A-Za-z0-9_]+)\.kd", data))
+    return names
+
+
+def test_product_library_has_one_kernel_per_job_and_no_lab_switches():
+    """The shipped libcwslgpu.so carries ONE kernel per job and reads no environment switch that changes a kernel or the order of its
+    arithmetic; the measured alternatives (round-1/-2 kernels, matrix-core and persistent variants, probes) and the CWSLG_*_VARIANT
+    switches live in libcwslgpu_lab.so only."""
+    from cwsl_digi_amd import build as B
+    B.build()
+    prod, lab = open(B.LIB, "rb").read(), open(B.LAB_LIB, "rb").read()
+    for switch in (b"CWSLG_DEMOD_VARIANT", b"CWSLG_SYNC_VARIANT", b"CWSLG_LONG_VARIANT", b"CWSLG_FT4_DFT", b"CWSLG_ITEM_ORDER",
+                   b"CWSLG_UPLOAD", b"CWSLG_COPY_ON_MAIN", b"CWSLG_PERSIST_WGS_PER_CU"):
+        assert switch not in prod, switch
+        assert switch in lab, switch
+    kp, kl = _kernel_names(B.LIB), _kernel_names(B.LAB_LIB)
+    assert kp < kl                                      # the lab library has everything the product has, and more
+    for lab_only in ("ring_probe_kernel", "demod_mfma1p_kernel", "demod_mfma_bf16_kernel", "demod_exact_kernel", "demod_exact2_kernel",
+                     "ft8_sync2d_kernelE", "ft8_sync_chan_kernel", "symbol_spectra_kernelI", "ft4_dft567_kernelE"):
+        assert not any(lab_only in k for k in kp), lab_only
+        assert any(lab_only in k for k in kl), lab_only
+    # one demod kernel per mode and sample rate (D = 16, 8, 4), nothing persistent or alternative
+    demod = sorted(k for k in kp if "demod_kernel" in k)
+    assert len(demod) == 3 and all("ELi256ELi256ELi0E" in k for k in demod), demod
+    exact = sorted(k for k in kp if "demod_exact" in k)
+    assert len(exact) == 3 and all("demod_exact3_kernel" in k and "ELi512ELi256E" in k for k in exact), exact
+    assert len(kp) <= 36, sorted(kp)
