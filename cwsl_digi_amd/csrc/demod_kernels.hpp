@@ -36,6 +36,7 @@
 // explicit __builtin_fmaf, every bit-exact sequence is plain * and +/-.
 #pragma once
 #include <type_traits>
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -303,8 +304,18 @@ __device__ unsigned long long g_stamps[8 * 65536];
             g_stamps[8 * blockIdx.x + (slot)] = t_;                                                 \
         }                                                                                           \
     } while (0)
+// ... by lane 0 of EVERY wave, into slot base + wave (how far apart the waves of a workgroup reach a point)
+#define STAMP_WAVE(base)                                                                            \
+    do {                                                                                            \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 65536 && stamp_on) {                            \
+            unsigned long long t_;                                                                  \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+            g_stamps[8 * blockIdx.x + (base) + (threadIdx.x >> 6)] = t_;                            \
+        }                                                                                           \
+    } while (0)
 #else
 #define STAMP(slot) do { } while (0)
+#define STAMP_WAVE(base) do { } while (0)
 #endif
 
 __device__ __forceinline__ void lds_barrier()
@@ -1482,35 +1493,55 @@ struct ExactTaps<4> {
 // words of 8 bytes.  Early-clobber outputs: the address operands are read by every instruction of the statement.  `pin` is the first
 // sample of the block about to be COMPUTED, passed through untouched: its sums start from it, so the step's arithmetic cannot be
 // scheduled ahead of this statement (hipcc otherwise sinks the statement, whose many results lengthen live ranges, below most of it).
-#define X3_RD(i) "ds_read_b64 %" #i ", %[row] offset:8*" #i "\n\t"
-__device__ __forceinline__ void exact_issue(ExactBlock<16> &b, ExactTaps<16> &h, unsigned row_addr, const CWSLG_CONST float *taps_row, v2f &pin)
+// ROFF / TOFF: compile-time byte offsets of the row within the lane's LDS window and of the tap row within the table -- the FIR is
+// straight-line code (33 steps unrolled), so neither address ever needs an instruction.
+#define X3_RD(i) "ds_read_b64 %" #i ", %[row] offset:%c[ro]+8*" #i "\n\t"
+template <int ROFF, int TOFF>
+__device__ __forceinline__ void exact_issue(ExactBlock<16> &b, ExactTaps<16> &h, unsigned row_addr, const CWSLG_CONST float *taps, v2f &pin)
 {
-    asm volatile("s_load_dwordx16 %[tl], %[tp], 0x0\n\ts_load_dwordx16 %[th], %[tp], 0x40\n\t"
+    asm volatile("s_load_dwordx16 %[tl], %[tp], %c[to]\n\ts_load_dwordx16 %[th], %[tp], %c[to]+0x40\n\t"
                  X3_RD(0) X3_RD(1) X3_RD(2) X3_RD(3) X3_RD(4) X3_RD(5) X3_RD(6) X3_RD(7) X3_RD(8) X3_RD(9) X3_RD(10) X3_RD(11)
                  X3_RD(12) X3_RD(13) X3_RD(14) X3_RD(15) X3_RD(16)
                  : "=&v"(b.q[0]), "=&v"(b.q[1]), "=&v"(b.q[2]), "=&v"(b.q[3]), "=&v"(b.q[4]), "=&v"(b.q[5]), "=&v"(b.q[6]), "=&v"(b.q[7]),
                    "=&v"(b.q[8]), "=&v"(b.q[9]), "=&v"(b.q[10]), "=&v"(b.q[11]), "=&v"(b.q[12]), "=&v"(b.q[13]), "=&v"(b.q[14]),
                    "=&v"(b.q[15]), "=&v"(b.php), [tl] "=&s"(h.lo), [th] "=&s"(h.hi), "+v"(pin)
-                 : [row] "v"(row_addr), [tp] "s"(taps_row) : "memory");
+                 : [row] "v"(row_addr), [tp] "s"(taps), [ro] "n"(ROFF), [to] "n"(TOFF) : "memory");
 }
-__device__ __forceinline__ void exact_issue(ExactBlock<8> &b, ExactTaps<8> &h, unsigned row_addr, const CWSLG_CONST float *taps_row, v2f &pin)
+template <int ROFF, int TOFF>
+__device__ __forceinline__ void exact_issue(ExactBlock<8> &b, ExactTaps<8> &h, unsigned row_addr, const CWSLG_CONST float *taps, v2f &pin)
 {
-    asm volatile("s_load_dwordx16 %[tl], %[tp], 0x0\n\t"
+    asm volatile("s_load_dwordx16 %[tl], %[tp], %c[to]\n\t"
                  X3_RD(0) X3_RD(1) X3_RD(2) X3_RD(3) X3_RD(4) X3_RD(5) X3_RD(6) X3_RD(7) X3_RD(8)
                  : "=&v"(b.q[0]), "=&v"(b.q[1]), "=&v"(b.q[2]), "=&v"(b.q[3]), "=&v"(b.q[4]), "=&v"(b.q[5]), "=&v"(b.q[6]), "=&v"(b.q[7]),
                    "=&v"(b.php), [tl] "=&s"(h.lo), "+v"(pin)
-                 : [row] "v"(row_addr), [tp] "s"(taps_row) : "memory");
+                 : [row] "v"(row_addr), [tp] "s"(taps), [ro] "n"(ROFF), [to] "n"(TOFF) : "memory");
 }
-__device__ __forceinline__ void exact_issue(ExactBlock<4> &b, ExactTaps<4> &h, unsigned row_addr, const CWSLG_CONST float *taps_row, v2f &pin)
+template <int ROFF, int TOFF>
+__device__ __forceinline__ void exact_issue(ExactBlock<4> &b, ExactTaps<4> &h, unsigned row_addr, const CWSLG_CONST float *taps, v2f &pin)
 {
-    asm volatile("s_load_dwordx8 %[tl], %[tp], 0x0\n\t"
+    asm volatile("s_load_dwordx8 %[tl], %[tp], %c[to]\n\t"
                  X3_RD(0) X3_RD(1) X3_RD(2) X3_RD(3) X3_RD(4)
                  : "=&v"(b.q[0]), "=&v"(b.q[1]), "=&v"(b.q[2]), "=&v"(b.q[3]), "=&v"(b.php), [tl] "=&s"(h.lo), "+v"(pin)
-                 : [row] "v"(row_addr), [tp] "s"(taps_row) : "memory");
+                 : [row] "v"(row_addr), [tp] "s"(taps), [ro] "n"(ROFF), [to] "n"(TOFF) : "memory");
+}
+// D = 16: the wait for step n's loads and the issue of step n + 1's as ONE statement (hipcc pads every statement boundary with an
+// s_nop: one issue slot of ~90 per step).  `cur_php`, the only loaded register the compiler's own code reads (the sums are assembly
+// statements of their own, kept in order behind this one), is tied so that no such read is scheduled above the wait.
+template <int ROFF, int TOFF>
+__device__ __forceinline__ void exact_wait_issue(v2f &cur_php, ExactBlock<16> &b, ExactTaps<16> &h, unsigned row_addr, const CWSLG_CONST float *taps, v2f &pin)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                 "s_load_dwordx16 %[tl], %[tp], %c[to]\n\ts_load_dwordx16 %[th], %[tp], %c[to]+0x40\n\t"
+                 X3_RD(0) X3_RD(1) X3_RD(2) X3_RD(3) X3_RD(4) X3_RD(5) X3_RD(6) X3_RD(7) X3_RD(8) X3_RD(9) X3_RD(10) X3_RD(11)
+                 X3_RD(12) X3_RD(13) X3_RD(14) X3_RD(15) X3_RD(16)
+                 : "=&v"(b.q[0]), "=&v"(b.q[1]), "=&v"(b.q[2]), "=&v"(b.q[3]), "=&v"(b.q[4]), "=&v"(b.q[5]), "=&v"(b.q[6]), "=&v"(b.q[7]),
+                   "=&v"(b.q[8]), "=&v"(b.q[9]), "=&v"(b.q[10]), "=&v"(b.q[11]), "=&v"(b.q[12]), "=&v"(b.q[13]), "=&v"(b.q[14]),
+                   "=&v"(b.q[15]), "=&v"(b.php), [tl] "=&s"(h.lo), [th] "=&s"(h.hi), "+v"(pin), "+v"(cur_php)
+                 : [row] "v"(row_addr), [tp] "s"(taps), [ro] "n"(ROFF), [to] "n"(TOFF) : "memory");
 }
 #undef X3_RD
 // Wait for everything the wave has in flight on the LDS / scalar-memory counter; the tied operands make every later use of the
-// registers the hand-issued loads fill depend on this statement -- and the statement depend on `w`, the running result of the step
+// registers the hand-issued loads fill depend on this statement -- and the statement depend on `w`, the running sum of the step
 // before: without that hipcc hoists the wait to just behind the loads it covers and sinks the whole step's arithmetic below it.
 __device__ __forceinline__ void exact_wait(ExactBlock<16> &b, ExactTaps<16> &h, v2f &w)
 {
@@ -1528,6 +1559,110 @@ __device__ __forceinline__ void exact_wait(ExactBlock<8> &b, ExactTaps<8> &h, v2
 __device__ __forceinline__ void exact_wait(ExactBlock<4> &b, ExactTaps<4> &h, v2f &w)
 {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(b.q[0]), "+v"(b.q[1]), "+v"(b.q[2]), "+v"(b.q[3]), "+v"(b.php), "+s"(h.lo), "+v"(w) :: "memory");
+}
+
+// The state a FIR step leaves for its "tail" -- sum * phase and the accumulation into the workspace slots (:170) -- which is computed
+// one step LATER, interleaved with the next step's sums: the tail is a chain of four dependent packed operations (~11 cycles each from
+// one wave), and run at the end of its own step it sat, with nothing to overlap it, in front of the next step's wait.
+struct ExactTail { v2f sX, sY, ph; };
+
+// D = 16: the 64 packed operations of a step's sums, and the 4 of the previous step's tail, in a HAND-WRITTEN order (two assembly
+// statements, samples 0-7 and 8-15).  A wave issues one instruction per ~5 cycles and a dependent packed operation waits ~11
+// (scripts/micro/pk_latency.hip), so an operation must sit at least three instructions behind the one it depends on; hipcc's own orders
+// of this code put each add right behind its multiply (and an s_nop between them), or one whole chain behind the other.  Here every
+// product is made four instructions ahead of the add that consumes it (two product register pairs per chain, alternating), the two
+// chains alternate, and the tail's four operations are dropped into the first gaps.  Same IEEE operations on the same operands.
+#define X3_MX(P, m) "v_pk_mul_f32 %[" #P "], %[h" #m "], %[q" #m "] op_sel_hi:[1,0]\n\t"      /* (q.x * h.lo, q.x * h.hi) */
+#define X3_MY(P, m) "v_pk_mul_f32 %[" #P "], %[h" #m "], %[q" #m "] op_sel:[0,1]\n\t"         /* (q.y * h.lo, q.y * h.hi) */
+#define X3_AX(P) "v_pk_add_f32 %[sx], %[sx], %[" #P "]\n\t"
+#define X3_AY(P) "v_pk_add_f32 %[sy], %[sy], %[" #P "]\n\t"
+#define X3_QH(b, h, m) [q##m] "v"(b.q[m]), [h##m] "s"(h.pair(m))
+template <bool TAIL>
+__device__ __forceinline__ void exact_sums16_lo(const ExactBlock<16> &b, const ExactTaps<16> &h, v2f &sX, v2f &sY, const ExactTail &prev, v2f &W)
+{
+    v2f xa, ya, xb, yb, ta, tb;
+    if (TAIL) {
+        asm volatile(X3_MX(sx, 0) X3_MY(sy, 0)
+                     "v_pk_mul_f32 %[ta], %[sxp], %[ph]\n\t"                              /* (ac of o0, ad of o0 + 1) */
+                     X3_MX(xb, 1) X3_MY(yb, 1)
+                     "v_pk_mul_f32 %[tb], %[syp], %[ph] op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"   /* (Im sum_o0 * -ph.y, Im sum_o1 * ph.x) = (-(bd), bc) */
+                     X3_MX(xa, 2) X3_MY(ya, 2) X3_AX(xb) X3_AY(yb)
+                     "v_pk_add_f32 %[ta], %[ta], %[tb]\n\t"                               /* (ac - bd, ad + bc) */
+                     X3_MX(xb, 3) X3_MY(yb, 3) X3_AX(xa) X3_AY(ya)
+                     "v_pk_add_f32 %[w], %[w], %[ta]\n\t"                                 /* workspace slots += */
+                     X3_MX(xa, 4) X3_MY(ya, 4) X3_AX(xb) X3_AY(yb)
+                     X3_MX(xb, 5) X3_MY(yb, 5) X3_AX(xa) X3_AY(ya)
+                     X3_MX(xa, 6) X3_MY(ya, 6) X3_AX(xb) X3_AY(yb)
+                     X3_MX(xb, 7) X3_MY(yb, 7) X3_AX(xa) X3_AY(ya)
+                     X3_AX(xb) X3_AY(yb)
+                     : [sx] "=&v"(sX), [sy] "=&v"(sY), [xa] "=&v"(xa), [ya] "=&v"(ya), [xb] "=&v"(xb), [yb] "=&v"(yb), [ta] "=&v"(ta),
+                       [tb] "=&v"(tb), [w] "+v"(W)
+                     : X3_QH(b, h, 0), X3_QH(b, h, 1), X3_QH(b, h, 2), X3_QH(b, h, 3), X3_QH(b, h, 4), X3_QH(b, h, 5), X3_QH(b, h, 6), X3_QH(b, h, 7),
+                       [sxp] "v"(prev.sX), [syp] "v"(prev.sY), [ph] "v"(prev.ph));
+    } else {
+        asm volatile(X3_MX(sx, 0) X3_MY(sy, 0) X3_MX(xb, 1) X3_MY(yb, 1)
+                     X3_MX(xa, 2) X3_MY(ya, 2) X3_AX(xb) X3_AY(yb)
+                     X3_MX(xb, 3) X3_MY(yb, 3) X3_AX(xa) X3_AY(ya)
+                     X3_MX(xa, 4) X3_MY(ya, 4) X3_AX(xb) X3_AY(yb)
+                     X3_MX(xb, 5) X3_MY(yb, 5) X3_AX(xa) X3_AY(ya)
+                     X3_MX(xa, 6) X3_MY(ya, 6) X3_AX(xb) X3_AY(yb)
+                     X3_MX(xb, 7) X3_MY(yb, 7) X3_AX(xa) X3_AY(ya)
+                     X3_AX(xb) X3_AY(yb)
+                     : [sx] "=&v"(sX), [sy] "=&v"(sY), [xa] "=&v"(xa), [ya] "=&v"(ya), [xb] "=&v"(xb), [yb] "=&v"(yb)
+                     : X3_QH(b, h, 0), X3_QH(b, h, 1), X3_QH(b, h, 2), X3_QH(b, h, 3), X3_QH(b, h, 4), X3_QH(b, h, 5), X3_QH(b, h, 6), X3_QH(b, h, 7));
+    }
+}
+#undef X3_QH
+#define X3_QH(b, h, m, k) [q##k] "v"(b.q[m]), [h##k] "s"(h.pair(m))
+__device__ __forceinline__ void exact_sums16_hi(const ExactBlock<16> &b, const ExactTaps<16> &h, v2f &sX, v2f &sY)
+{
+    v2f xa, ya, xb, yb;
+    asm volatile(X3_MX(xa, 0) X3_MY(ya, 0) X3_MX(xb, 1) X3_MY(yb, 1) X3_AX(xa) X3_AY(ya)
+                 X3_MX(xa, 2) X3_MY(ya, 2) X3_AX(xb) X3_AY(yb)
+                 X3_MX(xb, 3) X3_MY(yb, 3) X3_AX(xa) X3_AY(ya)
+                 X3_MX(xa, 4) X3_MY(ya, 4) X3_AX(xb) X3_AY(yb)
+                 X3_MX(xb, 5) X3_MY(yb, 5) X3_AX(xa) X3_AY(ya)
+                 X3_MX(xa, 6) X3_MY(ya, 6) X3_AX(xb) X3_AY(yb)
+                 X3_MX(xb, 7) X3_MY(yb, 7) X3_AX(xa) X3_AY(ya)
+                 X3_AX(xb) X3_AY(yb)
+                 : [sx] "+v"(sX), [sy] "+v"(sY), [xa] "=&v"(xa), [ya] "=&v"(ya), [xb] "=&v"(xb), [yb] "=&v"(yb)
+                 : X3_QH(b, h, 8, 0), X3_QH(b, h, 9, 1), X3_QH(b, h, 10, 2), X3_QH(b, h, 11, 3), X3_QH(b, h, 12, 4), X3_QH(b, h, 13, 5),
+                   X3_QH(b, h, 14, 6), X3_QH(b, h, 15, 7));
+}
+#undef X3_QH
+#undef X3_MX
+#undef X3_MY
+#undef X3_AX
+#undef X3_AY
+
+// Steps 2 P and 2 P + 1 of demod_exact3_kernel's FIR for P = 0..15 (step 32 follows in the kernel): wait for the step's loads, issue the
+// next step's, compute this step's sums (D = 16: with the previous step's tail inside them).  Even steps use buffers A (row P of the
+// even-block array), odd steps buffers B (row P of the odd-block array).
+template <int D, int ROW, int TROW, int P, typename Sums, typename Tail>
+__device__ __forceinline__ void exact3_step_pair(ExactBlock<D> &bA, ExactBlock<D> &bB, ExactTaps<D> &hA, ExactTaps<D> &hB, unsigned lds0, unsigned lds1,
+                                                 const CWSLG_CONST float *h2, ExactTail &t, v2f &W, Sums &sums, Tail &tail)
+{
+    if constexpr (D == 16) {
+        exact_wait_issue<P * ROW, (2 * P + 1) * TROW>(bA.php, bB, hB, lds1, h2, t.sY);   // step 2 P: its loads have landed; loads of step 2 P + 1
+    } else {
+        exact_wait(bA, hA, t.sY);
+        exact_issue<P * ROW, (2 * P + 1) * TROW>(bB, hB, lds1, h2, bA.q[0]);
+    }
+    sums(bA, hA, t, std::integral_constant<bool, (P > 0)>{});                    // ... and the tail of step 2 P - 1
+    if constexpr (D == 16) {
+        exact_wait_issue<(P + 1) * ROW, (2 * P + 2) * TROW>(bB.php, bA, hA, lds0, h2, t.sY);   // step 2 P + 1; loads of step 2 P + 2
+    } else {
+        exact_wait(bB, hB, t.sY);
+        exact_issue<(P + 1) * ROW, (2 * P + 2) * TROW>(bA, hA, lds0, h2, bB.q[0]);
+    }
+    if (P == 0) { tail(t, true, false); sums(bB, hB, t, std::false_type{}); }    // step 0's tail: tap block -1 does not exist
+    else sums(bB, hB, t, std::true_type{});
+}
+template <int D, int ROW, int TROW, typename Sums, typename Tail, int... Ps>
+__device__ __forceinline__ void exact3_steps(std::integer_sequence<int, Ps...>, ExactBlock<D> &bA, ExactBlock<D> &bB, ExactTaps<D> &hA, ExactTaps<D> &hB,
+                                             unsigned lds0, unsigned lds1, const CWSLG_CONST float *h2, ExactTail &t, v2f &W, Sums &sums, Tail &tail)
+{
+    (exact3_step_pair<D, ROW, TROW, Ps>(bA, bB, hA, hB, lds0, lds1, h2, t, W, sums, tail), ...);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1566,8 +1701,13 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
     __shared__ __attribute__((aligned(16))) float2 s_t[2][NBH * BP];
     static_assert(sizeof(float2) * 2 * NBH * BP <= 81920, "at least two tiles per CU");
 #ifdef CWSLG_STAMP
+#ifdef CWSLG_STAMP_TOPS
+    bool stamp_on = false;
+#else
     bool stamp_on = true;              // a workgroup that walks a run of tiles stamps its 100th only
+#endif
     int stamp_iter = 0;
+#ifndef CWSLG_STAMP_WAVES
     if (threadIdx.x == 0 && blockIdx.x < 65536) {          // where and when the workgroup started
         unsigned hw, xcc;
         unsigned long long t_;
@@ -1576,6 +1716,7 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
         g_stamps[8 * blockIdx.x + 6] = ((unsigned long long)xcc << 32) | hw;
         g_stamps[8 * blockIdx.x + 7] = t_;
     }
+#endif
 #endif
     STAMP(0);
 
@@ -1593,6 +1734,10 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
     // draw per tile would bound large launches; small ones use shorter runs so that every CU gets work)
     const int kRun = run_len;
     __shared__ int s_draw;
+    // (A start offset of half a tile for the CU's second workgroup -- the one in the odd wave slots -- was tried, to put one
+    // workgroup's mix and barriers into the other's FIR: no change at 1, 2 or 3 x 8 k cycles.  The tile period is the same 19.8 k ticks
+    // from the tenth tile of a run to the last: the workgroups de-phase by themselves, and the FIR is bound by what ONE wave can issue,
+    // ~5 cycles per instruction, not by the pipe the two waves of a SIMD share -- scripts/micro/pk_latency.hip.)
     CWSLG_GLOBAL unsigned *ctr = as_global_rw(xcd_next) + xcd;
     if (tid == 0) s_draw = (int)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -1687,53 +1832,54 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
         const unsigned lds1 = (unsigned)(uintptr_t)&s_t[1][tid * BP];          // block 2 l + 1
         const CWSLG_CONST float *h2 = as_const(taps2);
         v2f W = {0.0f, 0.0f};                                // (Re of o0's workspace slot, Im of o0 + 1's): zero after their last read-out (:178)
-        auto step = [&](const ExactBlock<D> &b, const ExactTaps<D> &h, bool first, bool last) {
-            // the running sums live TRANSPOSED: sX = (Re sum_o0, Re sum_{o0+1}), sY = (Im sum_o0, Im sum_{o0+1}); the tap pair
-            // (h[m + D n], h[m + D (n-1)]) is an SGPR pair the packed multiply reads as it is, the sample word is broadcast (op_sel)
-            const v2f t0 = b.t(0);
-            v2f sX = v2f{t0.x, t0.x} * h.pair(0);
-            v2f sY = v2f{t0.y, t0.y} * h.pair(0);
-#pragma unroll
-            for (int m = 1; m < D; ++m) {
-                const v2f t = b.t(m);
-                sX = sX + v2f{t.x, t.x} * h.pair(m);         // sr += t.x*h   (:167-168), both outputs
-                sY = sY + v2f{t.y, t.y} * h.pair(m);         // si += t.y*h
-            }
-            const v2f A = sX * b.ph();                       // (ac of o0, ad of o0 + 1)
-            const v2f B = sY * b.phn();                      // (-(bd) of o0, bc of o0 + 1): negation commutes with rounding
+        auto tail = [&](const ExactTail &t, bool first, bool last) {
+            const v2f A = t.sX * t.ph;                       // (ac of o0, ad of o0 + 1)
+            const v2f B = t.sY * v2f{-t.ph.y, t.ph.x};       // (-(bd) of o0, bc of o0 + 1): negation commutes with rounding
             v2f R = A + B;                                   // (ac - bd, ad + bc)   (:170)
             if (first) R.y = 0.0f;                           // tap block -1 does not exist
             if (last) R.x = 0.0f;                            // tap block 32 does not exist
             W = W + R;
         };
-        // step n reads block o0 + n = row (n >> 1) of the parity-(n & 1) array relative to this lane's row, and tap row n
-        constexpr unsigned ROW = BP * sizeof(float2);        // bytes per LDS row
-        { v2f none = {0.0f, 0.0f}; exact_issue(bA, hA, lds0, h2, none); }
-        // step 0
-        exact_wait(bA, hA, W);
-        exact_issue(bB, hB, lds1, h2 + 2 * D, bA.q[0]);
-        step(bA, hA, true, false);
-        // steps 1 .. 30 in pairs (odd, even)
-        unsigned a0 = lds0 + ROW, a1 = lds1;                 // even / odd array rows of the NEXT even / CURRENT odd step
-        const CWSLG_CONST float *hp = h2 + 4 * D;           // tap row of the next even step
-#pragma unroll 1
-        for (int it = 0; it < 15; ++it) {
-            exact_wait(bB, hB, W);                              // step 2 it + 1
-            exact_issue(bA, hA, a0, hp, bB.q[0]);
-            step(bB, hB, false, false);
-            exact_wait(bA, hA, W);                              // step 2 it + 2
-            a1 += ROW;
-            exact_issue(bB, hB, a1, hp + 2 * D, bA.q[0]);
-            step(bA, hA, false, false);
-            a0 += ROW; hp += 4 * D;
-        }
-        // steps 31, 32
-        exact_wait(bB, hB, W);
-        exact_issue(bA, hA, a0, hp, bB.q[0]);
-        step(bB, hB, false, false);
-        exact_wait(bA, hA, W);
-        step(bA, hA, false, true);
+        // One step's sums; with_tail: the tail of the step before goes first (D = 16: inside the hand-ordered statements).
+        // The running sums live TRANSPOSED: sX = (Re sum_o0, Re sum_{o0+1}), sY = (Im sum_o0, Im sum_{o0+1}); the tap pair
+        // (h[m + D n], h[m + D (n-1)]) is an SGPR pair the packed multiply reads as it is, the sample word is broadcast (op_sel).
+        auto sums = [&](const ExactBlock<D> &b, const ExactTaps<D> &h, ExactTail &t, auto with_tail) {
+            constexpr bool TAIL = decltype(with_tail)::value;
+            const v2f ph_now = b.ph();
+            v2f sX, sY;
+            if constexpr (D == 16) {
+                exact_sums16_lo<TAIL>(b, h, sX, sY, t, W);
+                exact_sums16_hi(b, h, sX, sY);
+            } else {
+                if (TAIL) tail(t, false, false);
+                const v2f t0 = b.t(0);
+                sX = v2f{t0.x, t0.x} * h.pair(0);
+                sY = v2f{t0.y, t0.y} * h.pair(0);
+#pragma unroll
+                for (int m = 1; m < D; ++m) {
+                    const v2f tm = b.t(m);
+                    sX = sX + v2f{tm.x, tm.x} * h.pair(m);   // sr += t.x*h   (:167-168), both outputs
+                    sY = sY + v2f{tm.y, tm.y} * h.pair(m);   // si += t.y*h
+                }
+            }
+            t.sX = sX; t.sY = sY; t.ph = ph_now;
+        };
+        // step n reads block o0 + n = row (n >> 1) of the parity-(n & 1) array relative to this lane's row, and tap row n; the 33 steps
+        // are straight-line code (every offset an immediate: no loop counter, no address arithmetic)
+        constexpr int ROW = BP * (int)sizeof(float2);       // bytes per LDS row
+        constexpr int TROW = 2 * D * (int)sizeof(float);    // bytes per tap row
+        ExactTail tl;
+        tl.sX = v2f{0.0f, 0.0f}; tl.sY = v2f{0.0f, 0.0f}; tl.ph = v2f{0.0f, 0.0f};
+        { v2f none = {0.0f, 0.0f}; exact_issue<0, 0>(bA, hA, lds0, h2, none); }
+        exact3_steps<D, ROW, TROW>(std::make_integer_sequence<int, 16>{}, bA, bB, hA, hB, lds0, lds1, h2, tl, W, sums, tail);
+        // step 32 (its loads were issued by step 31) with the tail of step 31, then its own tail
+        exact_wait(bA, hA, tl.sY);
+        sums(bA, hA, tl, std::true_type{});
+        tail(tl, false, true);                               // tap block 32 does not exist
         STAMP(4);
+#ifdef CWSLG_STAMP_WAVES
+        STAMP_WAVE(4);          // slots 4..7: the end of the FIR on waves 0..3 (overwrites slots 5..7 of the other diagnostics)
+#endif
         const float wr0 = W.x, wi1 = W.y;
         // Iterate(): out[k] for block index mod 4 (qs and T are multiples of 4; o0 is even)
         const float v0 = (o0 & 2) ? -wr0 : wr0;
@@ -1746,16 +1892,29 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
         for (int msk = 32; msk >= 1; msk >>= 1) mx = fmaxf(mx, __shfl_xor(mx, msk, 64));
         if ((tid & 63) == 0) publish_peak(cur.peak, mx);
     }
+#ifndef CWSLG_STAMP_WAVES
     STAMP(5);
+#endif
     if (!has_next) break;
     lds_barrier();                                           // every wave has finished reading the image the next mix overwrites
     cur = nxt;
     item = nitem;
 #ifdef CWSLG_STAMP
+#ifdef CWSLG_STAMP_TOPS                  // diagnostic: the loop-top times of eight consecutive tiles (CWSLG_STAMP_TOPS ... + 7), nothing else
+    ++stamp_iter;
+    if (stamp_iter >= CWSLG_STAMP_TOPS && stamp_iter < CWSLG_STAMP_TOPS + 8 && threadIdx.x == 0 && blockIdx.x < 65536) {
+        unsigned long long t_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        g_stamps[8 * blockIdx.x + (stamp_iter - CWSLG_STAMP_TOPS)] = t_;
+    }
+    stamp_on = false;
+    if (stamp_iter == CWSLG_STAMP_TOPS + 8) break;
+#else
     if (stamp_iter == 100) break;
     ++stamp_iter;
     stamp_on = (stamp_iter == 100);
     STAMP(0); STAMP(1);
+#endif
 #endif
     }
 }

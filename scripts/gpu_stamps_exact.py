@@ -32,6 +32,16 @@ key = xcc * 256 + cu
 vals, cnt = np.unique(key, return_counts=True)
 print("workgroups started:", int(used.sum()), " distinct (xcc, se/sh/cu):", len(vals), " workgroups per CU: min %d max %d" % (cnt.min(), cnt.max()),
       " histogram", dict(zip(*np.unique(cnt, return_counts=True))))
+lo = hw & 0xFFFFFFFF
+wid, simd, tg = lo & 0xF, (lo >> 4) & 3, (lo >> 16) & 0xF
+for nm, fld in (("wave_id", wid), ("simd_id", simd), ("tg_id", tg)):
+    per_cu = {}
+    for k_, f_ in zip(key.tolist(), fld.tolist()):
+        per_cu.setdefault(k_, []).append(int(f_))
+    pats = {}
+    for v in per_cu.values():
+        pats[tuple(sorted(v))] = pats.get(tuple(sorted(v)), 0) + 1
+    print("HW_ID.%s of wave 0 of the workgroups sharing a CU:" % nm, dict(sorted(pats.items(), key=lambda kv: -kv[1])[:6]))
 print("start spread (ticks): p50 %d p90 %d max %d" % tuple(np.percentile(t_start - t_start.min(), [50, 90, 100]).astype(int)))
 st = raw.astype(np.int64)[:, :6]
 el = (st[used, 5] - t_start)
