@@ -308,6 +308,19 @@ def main():
                 "achieved_tflops": tfl, "peak_tflops": VALU_PEAK_TFLOPS, "frac": tfl / VALU_PEAK_TFLOPS,
                 "algorithmic_bytes": S * (240000 * 2 + 200 * 20), "fabric_bytes": fabric, "fabric_source": src}
 
+    def replay_traffic(kname):
+        """HBM bytes per launch of `kname` at this slot count from the committed PMC summary (latest matching entry), or (None, None)."""
+        t_, src_ = None, None
+        tp = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
+        if os.path.isfile(tp) and C == 1:
+            try:
+                for tj in json.load(open(tp)).get("runs", []):
+                    if tj.get("slots") == S and tj.get("kernel") == kname:
+                        t_, src_ = tj.get("hbm_bytes_per_launch"), "replayed: " + tj.get("source", "profiles/traffic_per_launch.json")
+            except Exception:
+                t_, src_ = None, None
+        return t_, src_
+
     # ---- CPU baseline: the oracle in the reference's shape, on this box's host cores (rank 0, N=1 only)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -339,16 +352,9 @@ def main():
         achieved = bps * samples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM traffic cannot be counted from inside the process (PMC counters need rocprofv3): the figure is REPLAYED
         # from the committed PMC summary of this same command and slot count, and labelled so
-        traffic, traffic_source = None, None
-        tp = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
-        if os.path.isfile(tp):
-            try:
-                for tj in json.load(open(tp)).get("runs", []):
-                    if tj.get("slots") == S and C == 1 and not args.exact:
-                        traffic = tj.get("hbm_bytes_per_launch")
-                        traffic_source = "replayed: " + tj.get("source", "profiles/traffic_per_launch.json")
-            except Exception:
-                traffic = None
+        traffic, traffic_source = replay_traffic(kernel_name)
+        if exact_rec is not None:
+            exact_rec["roofline"]["traffic"], exact_rec["roofline"]["traffic_source"] = replay_traffic(exact_rec["roofline"]["kernel"])
         out = {
             "metric": "IQ Msamples/s demod+sync per GPU; concurrent FT8 slots at real-time; % HBM roofline",
             "value": msps, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
