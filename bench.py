@@ -303,7 +303,7 @@ def main():
                         fabric, src = tj.get("fabric_bytes_per_boundary"), "replayed: " + tj.get("source", "")
             except Exception:
                 pass
-        return {"bound": "valu", "kernels": "symbol_spectra_v2_kernel + ft8_sync2d_v2_kernel + ft8_candidates_kernel<1024>",
+        return {"bound": "valu", "kernels": "symbol_spectra_v2_kernel + ft8_sync_chan_kernel",
                 "avg_ms": ms, "transforms": 372 * S, "flop_per_transform": per_transform, "flop_per_slot": per_slot,
                 "achieved_tflops": tfl, "peak_tflops": VALU_PEAK_TFLOPS, "frac": tfl / VALU_PEAK_TFLOPS,
                 "algorithmic_bytes": S * (240000 * 2 + 200 * 20), "fabric_bytes": fabric, "fabric_source": src}

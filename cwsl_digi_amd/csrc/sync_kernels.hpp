@@ -897,21 +897,62 @@ __device__ __forceinline__ void wave_first_max(float v, int lag, float &best, in
     best_lag = __builtin_amdgcn_readlane(lag, src);
 }
 
+// x / 6.0f, correctly rounded, in three operations instead of the ten of the IEEE division sequence: q0 = x * fl(1/6), the residual
+// x - 6 q0 is exact in one fmaf, one more fmaf corrects q0.  Checked against the division for EVERY float (tests/div6_check.c,
+// tests/test_div6_shortcut.py): identical for all x with 2^-125 <= |x| < inf and for +-0; below that range the quotient is denormal
+// (double rounding) and at inf the residual is NaN -- those inputs (and, with margin, everything below 2^-95) take the division itself.
+__device__ __forceinline__ float div6_exact(float x)
+{
+    const float r = 0x1.555556p-3f;                     // fl(1/6)
+    const float q0 = x * r;
+    const float e = __builtin_fmaf(-6.0f, q0, x);
+    float q = __builtin_fmaf(e, r, q0);
+    const unsigned ex = __float_as_uint(x) & 0x7f800000u;
+    if (__builtin_expect(ex - 0x10000000u > 0x6f000000u && x != 0.0f, 0)) q = x / 6.0f;
+    return q;
+}
+
 __device__ __forceinline__ float sync_finish(float ta, float tb, float tc, float t0a, float t0b, float t0c)
 {
     float t = ta + tb + tc;
     float t0 = t0a + t0b + t0c;
-    t0 = (t0 - t) / 6.0f;
+    t0 = div6_exact(t0 - t);
     const float sync_abc = t / t0;
     t = tb + tc;
     t0 = t0b + t0c;
-    t0 = (t0 - t) / 6.0f;
+    t0 = div6_exact(t0 - t);
     const float sync_bc = t / t0;
     float sy = (sync_abc > sync_bc) ? sync_abc : sync_bc;
     if (!(sy == sy)) sy = 0.0f;                        // 0/0 on all-zero windows: defined as 0 (as the oracle)
     return sy;
 }
 
+#if defined(CWSLG_STAMP) && defined(CWSLG_STAMP_SYNC)
+// diagnostic build only (scripts/gpu_stamps_sync.py): s_memtime of wave 0 at the phase seams of the workgroup's staging and FIRST bin
+#define SSTAMP(slot)                                                                                \
+    do {                                                                                            \
+        const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                   \
+        if (threadIdx.x == 0 && wg_ < 65536) {                                                      \
+            unsigned long long t_;                                                                  \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+            g_stamps[8 * wg_ + (slot)] = t_;                                                        \
+        }                                                                                           \
+    } while (0)
+// ... without waiting for outstanding global loads (a prefetch is in flight)
+#define SSTAMP1(slot)                                                                               \
+    do {                                                                                            \
+        const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                   \
+        if (threadIdx.x == 0 && wg_ < 65536) {                                                      \
+            unsigned long long t_;                                                                  \
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+            g_stamps[8 * wg_ + (slot)] = t_;                                                        \
+        }                                                                                           \
+    } while (0)
+#else
+#define SSTAMP(slot) do { } while (0)
+#define SSTAMP1(slot) do { } while (0)
+#endif
+#if CWSLG_LAB      // round 2's search (CWSLG_SYNC_VARIANT bit 6), lab library only
 __global__ __launch_bounds__(SYNC2D_NT, 4) void ft8_sync2d_v2_kernel(const SyncWork *__restrict__ works, int ia, int ib, int nbins)
 {
     constexpr int ROWS = SYNC_BAND + 12, NW = SYNC2D_NT / 64;
@@ -1007,6 +1048,131 @@ __global__ __launch_bounds__(SYNC2D_NT, 4) void ft8_sync2d_v2_kernel(const SyncW
         }
     }
 }
+
+#endif  // CWSLG_LAB
+// ---------------------------------------------------------------------------------------------
+// The hand-scheduled band search (round 3).  Round-3 stamps of ft8_sync2d_v2_kernel (scripts/gpu_stamps_sync.py): a workgroup lives
+// ~22 700 ticks, 7300 staging and ~3200 per bin, of which the arithmetic is a fraction: the wave sat through EIGHT LDS round trips per
+// bin (three for the 7-tone sums c0, whose loop hipcc does not unroll, five for the 42 reads of the search, which it issues in
+// batches each closed by lgkmcnt(0)) at ~400 ticks each under load; asked for all reads up front (arrays + sched_barrier) it spills.
+// Here one inline-assembly stream per bin (sync2d_asm.inc, generated by scripts/gen_sync2d_asm.py) issues the 42 reads of this bin's
+// Costas sums and the 21 reads of the NEXT bin's c0 in order, twelve to fifteen in flight, every group of three adds waiting only for
+// its own operands; temporaries live in fixed registers v94..v127.  The first read of every sum lands in the accumulator itself
+// (0 + x = x exactly: powers are never -0).  Same band image, same sums in the same order, same peak rules: bit-identical results.
+#include "sync2d_asm.inc"
+// The search of one band by one wave (bins i0 + wvu, i0 + wvu + NW, ... inside [ia, ib]): shared by ft8_sync2d_v3_kernel and
+// ft8_sync_chan_kernel.  s_base = LDS address of the band image (row pitch S2_PITCH floats), sC = LDS address of this wave's c0 row.
+template <int NW>
+__device__ __forceinline__ void sync2d_search_band(const SyncWork *w, unsigned s_base, unsigned sC, int wvu, int lane, int i0, int ia, int ib)
+{
+    constexpr int PP = S2_PITCH / 2, RB = S2_PITCH * 4;
+    static_assert(S2_PITCH == 378, "sync2d_asm.inc is generated for this row pitch");
+    const int j = 2 * lane - FT8_JZ;                       // this lane's lag pair (j, j + 1); lane 63 has none
+    const bool ok0 = j <= FT8_JZ, ok1 = j + 1 <= FT8_JZ;
+    const bool near0 = j >= -10 && j <= 10, near1 = j + 1 >= -10 && j + 1 <= 10;
+    const float ninf = -__builtin_huge_valf();
+    // byte offsets of this lane's operand pairs inside a row (lane - 24 + 2 n clamped below to the zero pair 0, lane + 120 + 2 n
+    // clamped above to the zero pair PP - 1, see v2) and of its c0 columns
+    unsigned vA[7], vC[3];
+#pragma unroll
+    for (int n = 0; n < 7; ++n) { const int p = lane - 24 + 2 * n; vA[n] = 8u * (unsigned)(p < 0 ? 0 : p); }
+#pragma unroll
+    for (int n = 4; n < 7; ++n) { const int p = lane + 120 + 2 * n; vC[n - 4] = 8u * (unsigned)(p > PP - 1 ? PP - 1 : p); }
+    const unsigned vU = 8u * (unsigned)lane, vL2 = 8u * (unsigned)(lane + 128 > PP - 1 ? PP - 1 : lane + 128);
+    int rr = wvu;
+    while (rr < SYNC_BAND && i0 + rr < ia) rr += NW;       // (a band may start below the first searched bin)
+    bool live = rr < SYNC_BAND && i0 + rr <= ib;           // wave-uniform
+    if (live) {
+        const unsigned sN = (unsigned)__builtin_amdgcn_readfirstlane((int)(s_base + (unsigned)rr * RB));
+        asm volatile(SYNC2D_ASM_C0_ONLY : : [vU] "v"(vU), [vL2] "v"(vL2), [sC] "s"(sC), [sN] "s"(sN) : SYNC2D_ASM_CLOBBERS);
+    }
+    SSTAMP(2);
+    const int rr0 = rr;
+    while (live) {
+        const int bin = i0 + rr;
+        const int rn = rr + NW;
+        const bool more = rn < SYNC_BAND && i0 + rn <= ib;               // wave-uniform
+        const unsigned sS = (unsigned)__builtin_amdgcn_readfirstlane((int)(s_base + (unsigned)rr * RB));
+        const unsigned sN = sS + NW * RB;
+        v2f ta, tb, tc, ua, ub, uc;                                      // t sums, t0 sums of lags (j, j + 1)
+        if (more)
+            asm volatile(SYNC2D_ASM_SEARCH_NEXT
+                         : [ta] "=&v"(ta), [ua] "=&v"(ua), [tb] "=&v"(tb), [ub] "=&v"(ub), [tc] "=&v"(tc), [uc] "=&v"(uc)
+                         : [vA0] "v"(vA[0]), [vA1] "v"(vA[1]), [vA2] "v"(vA[2]), [vA3] "v"(vA[3]), [vA4] "v"(vA[4]), [vA5] "v"(vA[5]), [vA6] "v"(vA[6]),
+                           [vC4] "v"(vC[0]), [vC5] "v"(vC[1]), [vC6] "v"(vC[2]), [vU] "v"(vU), [vL2] "v"(vL2), [sS] "s"(sS), [sC] "s"(sC), [sN] "s"(sN)
+                         : SYNC2D_ASM_CLOBBERS);
+        else
+            asm volatile(SYNC2D_ASM_SEARCH_LAST
+                         : [ta] "=&v"(ta), [ua] "=&v"(ua), [tb] "=&v"(tb), [ub] "=&v"(ub), [tc] "=&v"(tc), [uc] "=&v"(uc)
+                         : [vA0] "v"(vA[0]), [vA1] "v"(vA[1]), [vA2] "v"(vA[2]), [vA3] "v"(vA[3]), [vA4] "v"(vA[4]), [vA5] "v"(vA[5]), [vA6] "v"(vA[6]),
+                           [vC4] "v"(vC[0]), [vC5] "v"(vC[1]), [vC6] "v"(vC[2]), [vU] "v"(vU), [sS] "s"(sS), [sC] "s"(sC)
+                         : SYNC2D_ASM_CLOBBERS);
+        if (rr == rr0) SSTAMP(3);
+        const float sa = ok0 ? sync_finish(ta.x, tb.x, tc.x, ua.x, ub.x, uc.x) : ninf;
+        const float sb = ok1 ? sync_finish(ta.y, tb.y, tc.y, ua.y, ub.y, uc.y) : ninf;
+        if (rr == rr0) { asm volatile("" :: "v"(sa), "v"(sb)); SSTAMP(4); }
+        // +-62: the lane's own first maximum (lag j before j + 1), then the wavefront's
+        const bool b2 = sb > sa;
+        float r2; int l2;
+        wave_first_max(b2 ? sb : sa, b2 ? j + 1 : j, r2, l2);
+        const float na = near0 ? sa : ninf, nb = near1 ? sb : ninf;
+        const bool b1 = nb > na;
+        float r1; int l1;
+        wave_first_max(b1 ? nb : na, b1 ? j + 1 : j, r1, l1);
+        if (lane == 0) {
+            w->red[bin] = r1;  w->jpeak[bin] = l1;
+            w->red2[bin] = r2; w->jpeak2[bin] = l2;
+        }
+        if (rr == rr0) SSTAMP(5);
+        rr = rn;
+        live = more;
+    }
+}
+
+#if CWSLG_LAB      // the band search as its own launch (CWSLG_SYNC_VARIANT bit 7: with ft8_candidates_kernel, three launches), lab library only
+// ft8_sync2d_v3_kernel: one workgroup per (32-bin band, channel), staging as in v2, then sync2d_search_band.  2.74 against v2's 2.92-2.96 ms
+// per 4096 slots (same box); the product runs the same search inside ft8_sync_chan_kernel, which also hides the staging.
+__global__ __launch_bounds__(SYNC2D_NT, 4) void ft8_sync2d_v3_kernel(const SyncWork *__restrict__ works, int ia, int ib, int nbins)
+{
+    constexpr int ROWS = SYNC_BAND + 12, NW = SYNC2D_NT / 64;
+    constexpr int UN = (FT8_NHSYM + NW - 1) / NW;                              // symbol steps per wave: 47
+    __shared__ __attribute__((aligned(16))) float s_s[ROWS][S2_PITCH];       // s_s[r][m + 2] = s(i0 + r, m)
+    __shared__ __attribute__((aligned(16))) float s_c0[NW][S2_PITCH];
+    const SyncWork *w = works + blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int i0 = ia + blockIdx.x * SYNC_BAND;
+    SSTAMP(0);
+    {   // staging as in v2: every load of the wave is issued before the first LDS write
+        const CWSLG_GLOBAL float *sp = as_global(w->spectra) + i0 + lane;
+        const bool on = lane < ROWS && i0 + lane < nbins;
+        float v[UN];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const int m = wv + NW * q;
+            v[q] = (on && m < FT8_NHSYM) ? sp[(size_t)m * nbins] : 0.0f;
+        }
+        float *dst = &s_s[lane < ROWS ? lane : 0][S2_COL0 + 1 + wv];
+#pragma unroll
+        for (int q = 0; q < UN; ++q)
+            if (lane < ROWS && wv + NW * q < FT8_NHSYM) dst[NW * q] = v[q];
+        if (tid < ROWS) {
+            float *row = s_s[tid];
+            row[0] = 0.0f; row[1] = 0.0f; row[2] = 0.0f;
+            row[S2_COL0 + 373] = 0.0f; row[S2_COL0 + 374] = 0.0f; row[S2_COL0 + 375] = 0.0f;
+        }
+    }
+    __syncthreads();
+    SSTAMP(1);
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const unsigned s_base = (unsigned)(uintptr_t)&s_s[0][0];
+    const unsigned sC = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)&s_c0[0][0] + (unsigned)wvu * (S2_PITCH * 4)));
+#ifdef CWSLG_SYNC_STAGGER
+    if (wvu >= NW / 2) __builtin_amdgcn_s_sleep(CWSLG_SYNC_STAGGER);
+#endif
+    sync2d_search_band<NW>(w, s_base, sC, wvu, lane, i0, ia, ib);
+    SSTAMP(6);
+}
+#endif  // CWSLG_LAB
 
 // ---------------------------------------------------------------------------------------------
 // Bitonic sort of (value, index) keys, ascending, ties by ascending index.  n = 2048, 256 threads.
@@ -1256,7 +1422,8 @@ __device__ void ft8_candidates_body(const SyncWork *w, int ia, int ib, float syn
     if (tid == 0) *w->ncand = min(s_n, maxcand);
 }
 
-// grid (n_channels), NT threads: the candidate selection as its own launch (lab build; the product fuses it into ft8_sync_chan_kernel).
+#if CWSLG_LAB
+// grid (n_channels), NT threads: the candidate selection as its own launch (lab library; the product fuses it into ft8_sync_chan_kernel).
 template <int NT>
 __global__ __launch_bounds__(NT) void ft8_candidates_kernel(const SyncWork *__restrict__ works, int ia, int ib,
                                                               float syncmin, int maxcand)
@@ -1264,22 +1431,26 @@ __global__ __launch_bounds__(NT) void ft8_candidates_kernel(const SyncWork *__re
     __shared__ __attribute__((aligned(16))) char s_pool[CandLds<NT>::bytes];
     ft8_candidates_body<NT>(works + blockIdx.x, ia, ib, syncmin, maxcand, s_pool);
 }
+#endif  // CWSLG_LAB
 
-#if CWSLG_LAB      // measured alternative (CWSLG_SYNC_VARIANT bit 7), lab library only
 // ---------------------------------------------------------------------------------------------
 // ft8_sync_chan_kernel: the Costas search AND the candidate selection of one channel in one workgroup (grid = channels, 512 threads).
-// Same sums in the same order as ft8_sync2d_v2_kernel + ft8_candidates_kernel (bit-identical lists); what changes is how the
-// spectra reach the CU.  Round-2 form: one workgroup per 32-bin band staged the band's 44 rows as 372 runs of 176 bytes, 3904 bytes
-// apart (each run 2-3 partial cache lines; neighbouring bands fetched 12 of the 44 rows again): 2.74 ms per 4096 slots for 5.9 GB,
-// then a third launch whose ~165 barrier-separated stages left the chip idle for 0.6 ms.  Now:
+// Same sums in the same order as the three-launch forms (ft8_sync2d_v2 / v3_kernel + ft8_candidates_kernel): bit-identical lists.
+// Round-2 form: one workgroup per 32-bin band staged the band's 44 rows as 372 runs of 176 bytes, 3904 bytes apart (each run 2-3
+// partial cache lines; neighbouring bands fetched 12 of the 44 rows again: 11.1 GB fetched for a 6.05 GB plane), the workgroup idle
+// for a third of its life while they arrived, then a third launch whose ~165 barrier-separated stages left the chip idle for 0.6 ms.
+// Here:
 //   * the workgroup walks ALL bands of its channel with a sliding LDS window: a band's last 12 rows become the next band's first 12
 //     (an LDS move), and only the 32 NEW bins are fetched -- exactly one 128-byte line per symbol step (bands start at bins = 20 mod
 //     32 and the spectra rows have a pitch of 32 floats, so bins i0 + 12 .. i0 + 43 are a whole line): every spectrum element leaves
 //     HBM once, in whole lines;
 //   * the next band's 372 lines are in flight, in 24 registers per lane, while the current band is searched;
+//   * the search is the hand-scheduled LDS stream of sync2d_search_band (its temporaries are fixed registers, so the 24 prefetch
+//     registers no longer make it spill -- with hipcc's own schedule of the search this kernel was 1.5 % SLOWER than three launches);
 //   * when the last band is done the same workgroup runs the candidate selection on the red / jpeak values it has just written
 //     (its LDS overlays the band image); other workgroups of the CU are in their search phase meanwhile, so the selection's
 //     barrier chains no longer hold the chip.
+// Measured (4096 slots, same box, scripts/gpu_r3_sync2d.sh): 3.02 ms against 2.74 + 0.57 (v3 + candidates) and 2.92 + 0.55 (round 2).
 constexpr int SYNCC_NT = 512;
 __global__ __launch_bounds__(SYNCC_NT, 4) void ft8_sync_chan_kernel(const SyncWork *__restrict__ works, int ia, int ib, int nbins,
                                                                      float syncmin, int maxcand)
@@ -1319,22 +1490,16 @@ __global__ __launch_bounds__(SYNCC_NT, 4) void ft8_sync_chan_kernel(const SyncWo
         }
     }
     __syncthreads();
-    float *c0 = s_c0[wv];
-    constexpr unsigned ICOS = 0x2560413u;                  // the Costas array 3,1,4,0,6,5,2, one nibble per symbol
-    const int j = 2 * lane - FT8_JZ;                       // this lane's lag pair (j, j + 1); lane 63 has none
-    const bool ok0 = j <= FT8_JZ, ok1 = j + 1 <= FT8_JZ;
-    const bool near0 = j >= -10 && j <= 10, near1 = j + 1 >= -10 && j + 1 <= 10;
-    const float ninf = -__builtin_huge_valf();
-    const int pa0 = lane - 24, pb0 = pa0 + 72, pc0 = pa0 + 144;
-    constexpr int PP = S2_PITCH / 2;                       // float2 per row
-    const v2f *s_s2 = reinterpret_cast<const v2f *>(&s_s[0][0]);
-    v2f *c02 = reinterpret_cast<v2f *>(c0);
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    const unsigned s_base = (unsigned)(uintptr_t)&s_s[0][0];
+    const unsigned sC = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)&s_c0[0][0] + (unsigned)wvu * (S2_PITCH * 4)));
     const int half = lane >> 5, c32 = lane & 31;           // the prefetch: lanes 0-31 one step, lanes 32-63 the next; lane = bin
     for (int band = 0; band < nbands; ++band) {
         const int i0 = i_first + band * SYNC_BAND;
         // ---- the NEXT band's 32 new bins (i0 + 44 .. i0 + 75) of every symbol step: one whole 128-byte line per step
         float pf[PF];
         const bool more = band + 1 < nbands;               // workgroup-uniform
+        if (band == 1) SSTAMP(0);
         if (more) {
             // one uniform base + a 32-bit lane offset per load (a pointer per load would be 48 more registers)
             const int col = i0 + ROWS + c32;
@@ -1347,52 +1512,10 @@ __global__ __launch_bounds__(SYNCC_NT, 4) void ft8_sync_chan_kernel(const SyncWo
                 pf[q] = (on && m < FT8_NHSYM) ? spec[o0 + (unsigned)q * ostep] : 0.0f;
             }
         }
-        // ---- search this band: one wave per bin at a time, each wave owns s_c0[wv] (see ft8_sync2d_v2_kernel)
-        for (int rr = wv; rr < SYNC_BAND; rr += NW) {
-            const int bin = i0 + rr;
-            if (bin > ib) break;                            // wave-uniform
-            if (bin < ia) continue;
-            for (int mp = lane; mp < PP; mp += 64) {
-                v2f acc = {0.0f, 0.0f};
-#pragma unroll
-                for (int k = 0; k < 7; ++k) acc = acc + s_s2[(rr + 2 * k) * PP + mp];      // two steps per lane: one v_pk_add_f32 each
-                c02[mp] = acc;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            v2f ta = {0, 0}, tb = {0, 0}, tc = {0, 0}, ua = {0, 0}, ub = {0, 0}, uc = {0, 0};   // t sums, t0 sums of lags (j, j + 1): packed adds
-            // (not unrolled: with all 42 reads of a lag pair in flight at once the search alone needs 118 VGPRs, and the 24 prefetch
-            // registers on top of that spill at four waves per SIMD; partly unrolled forms -- 4 + 3, 3 + 2 + 2 symbols -- spilled too)
-#pragma unroll 1
-            for (int n = 0; n < 7; ++n) {
-                const v2f *row = s_s2 + (rr + 2 * (int)((ICOS >> (4 * n)) & 7u)) * PP;
-                int pa = pa0 + 2 * n; pa = pa < 0 ? 0 : pa;                   // m < -2  -> the zero pair (m = -2, -1)
-                int pc = pc0 + 2 * n; pc = pc > PP - 1 ? PP - 1 : pc;         // m > 374 -> the zero pair (m = 374, 375)
-                const int pb = pb0 + 2 * n;
-                const v2f va = row[pa], wa = c02[pa];
-                const v2f vb = row[pb], wb = c02[pb];
-                const v2f vc = row[pc], wc = c02[pc];
-                ta = ta + va; ua = ua + wa;
-                tb = tb + vb; ub = ub + wb;
-                tc = tc + vc; uc = uc + wc;
-            }
-            const float sa = ok0 ? sync_finish(ta.x, tb.x, tc.x, ua.x, ub.x, uc.x) : ninf;
-            const float sb = ok1 ? sync_finish(ta.y, tb.y, tc.y, ua.y, ub.y, uc.y) : ninf;
-            const bool b2 = sb > sa;
-            float r2; int l2;
-            wave_first_max(b2 ? sb : sa, b2 ? j + 1 : j, r2, l2);
-            const float na = near0 ? sa : ninf, nb = near1 ? sb : ninf;
-            const bool b1 = nb > na;
-            float r1; int l1;
-            wave_first_max(b1 ? nb : na, b1 ? j + 1 : j, r1, l1);
-            if (lane == 0) {
-                w->red[bin] = r1;  w->jpeak[bin] = l1;
-                w->red2[bin] = r2; w->jpeak2[bin] = l2;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();               // c0 is rewritten by the next bin
-        }
+        // ---- search this band: one wave per bin at a time, each wave owns s_c0[wv]; the hand-scheduled LDS stream of ft8_sync2d_v3_kernel
+        if (band == 1) { asm volatile("" :: "v"(pf[0])); SSTAMP1(1); }
+        sync2d_search_band<NW>(w, s_base, sC, wvu, lane, i0, ia, ib);
+        if (band == 1) SSTAMP1(6);
         if (!more) break;
         __syncthreads();                                    // every wave has finished reading the image
         // ---- slide the window: rows 32..43 become rows 0..11, then the prefetched lines fill rows 12..43
@@ -1417,6 +1540,7 @@ __global__ __launch_bounds__(SYNCC_NT, 4) void ft8_sync_chan_kernel(const SyncWo
             }
         }
         __syncthreads();
+        if (band == 1) SSTAMP(7);
     }
     // ---- candidate selection on the values this workgroup has just written (global memory, same CU: visible once the stores have
     // retired, which the barrier's vmcnt(0) ensures)
@@ -1424,7 +1548,6 @@ __global__ __launch_bounds__(SYNCC_NT, 4) void ft8_sync_chan_kernel(const SyncWo
     ft8_candidates_body<SYNCC_NT>(w, ia, ib, syncmin, maxcand, s_pool);
 }
 
-#endif  // CWSLG_LAB
 // ---------------------------------------------------------------------------------------------
 // FT4 candidate search (getcandidates4.f90 + ft4_baseline.f90), one workgroup per channel.  PARITY UNPINNED by the
 // reference; bit-exact against oracle/sync_oracle.c, whose builder-defined pieces are mirrored here operation for
