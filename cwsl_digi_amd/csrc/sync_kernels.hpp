@@ -538,6 +538,19 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         w3[i][0] = (live && K1 < nbins) ? tb.w3840[K1] : make_float2(0.f, 0.f);
         w3[i][1] = (live && K2 < nbins) ? tb.w3840[K2] : make_float2(0.f, 0.f);
     }
+    // "sparse upper half": the stored row ends at most 32 bins above NA * 64 (FT8's default search: 992 against 960).  Then bins K1, K2
+    // of every item are inside the row (no tests, no exec masking), and the few bins above NA * 64 -- K3 of the columns q <= 2, K4 of
+    // q >= 62 -- are the job of ONE wave after the item loop, one (row pair, column) slot per lane, instead of two more unpacks in
+    // every item of every wave that serve two or three lanes each (round-3 ISA count: ~80 of a wave's ~690 VALU instructions per
+    // transform).  Same butterflies, same unpack on the same operands: the same bits.
+    const bool sparse = nbins >= NA * 64 && nbins <= NA * 64 + 32 && NH == 7;          // wave-uniform (kernel argument)
+    const int ul_ = tid_ & 63, ur_ = ul_ & 7, usel_ = ul_ >> 3;
+    const bool uk3_ = usel_ < 3;
+    const int uq_ = uk3_ ? usel_ : 63 - (usel_ - 3);
+    const int ur2_ = (ur_ == 0) ? 0 : NA - ur_, uk2_ = (ur_ == 0) ? ((64 - uq_) & 63) : 63 - uq_;
+    const int uK_ = uk3_ ? NA * (uq_ + 64) + ur_ : NA * (uk2_ + 64) + ur2_;
+    const bool ulive_ = sparse && (tid_ >> 6) == 3 && usel_ < 5 && !(ur_ == 0 && (uq_ == 0 || !uk3_)) && uK_ < nbins;
+    const float2 w3u = ulive_ ? tb.w3840[uK_] : make_float2(0.f, 0.f);
     if (tid_ >= 64 && tid_ < 128) s_w128[tid_ - 64] = tb.w128[tid_ - 64];
     // every loop-invariant load (twiddles, window) is waited for HERE, with the builtin the compiler's wait-count pass
     // understands: otherwise it keeps conservative vmcnt waits for them inside the loop (the first iteration could still
@@ -674,11 +687,25 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
             continue;
         }
         const int K1 = NA * q + r, K2 = NA * k2 + r2;
+        if (sparse) {
+            s_pw[K1] = unpack_power(u1, v2, w3[i][0]);
+            s_pw[K2] = unpack_power(u2, v1, w3[i][1]);
+            continue;
+        }
         const int K3 = K1 + NA * 64, K4 = K2 + NA * 64;
         if (K1 < nbins) s_pw[K1] = unpack_power(u1, v2, w3[i][0]);
         if (K2 < nbins) s_pw[K2] = unpack_power(u2, v1, w3[i][1]);
         if (K3 < nbins) s_pw[K3] = unpack_power(v1, u2, tb.w3840[K3]);
         if (K4 < nbins) s_pw[K4] = unpack_power(v2, u1, tb.w3840[K4]);
+    }
+    if (sparse && (tid >> 6) == 3) {                        // wave-uniform: the bins above NA * 64, one slot per lane
+        if (ulive_) {
+            float2 u1 = s_y[ur_][sy_col(uq_)], v1 = s_y[ur_][sy_col(uq_ + 64)];
+            float2 u2 = s_y[ur2_][sy_col(uk2_)], v2 = s_y[ur2_][sy_col(uk2_ + 64)];
+            bfly(u1, v1, s_w128[uq_]);
+            bfly(u2, v2, s_w128[uk2_]);
+            s_pw[uK_] = uk3_ ? unpack_power(v1, u2, w3u) : unpack_power(v2, u1, w3u);
+        }
     }
     for (int k = NZ + 1 + tid; k < nbins; k += 256) s_pw[k] = 0.0f;          // padding beyond the Nyquist bin
     lds_barrier();
@@ -1457,7 +1484,7 @@ __global__ __launch_bounds__(SYNCC_NT, 4) void ft8_sync_chan_kernel(const SyncWo
 {
     constexpr int ROWS = SYNC_BAND + 12, NW = SYNCC_NT / 64;
     constexpr int UN = (FT8_NHSYM + NW - 1) / NW;                              // symbol steps per wave when one step = one load: 47
-    constexpr int PF = (FT8_NHSYM + 2 * NW - 1) / (2 * NW);                    // ... when one load carries two steps (32 bins each): 24
+    constexpr int PF = (FT8_NHSYM + 8 * NW - 1) / (8 * NW);                    // ... 16-byte loads, one wave-level load = eight steps x 128 bytes: 6
     constexpr size_t IMG_BYTES = (size_t)(ROWS + NW) * S2_PITCH * sizeof(float);
     constexpr size_t POOL_BYTES = IMG_BYTES > CandLds<SYNCC_NT>::bytes ? IMG_BYTES : CandLds<SYNCC_NT>::bytes;
     __shared__ __attribute__((aligned(16))) char s_pool[POOL_BYTES];
@@ -1493,50 +1520,53 @@ __global__ __launch_bounds__(SYNCC_NT, 4) void ft8_sync_chan_kernel(const SyncWo
     const int wvu = __builtin_amdgcn_readfirstlane(wv);
     const unsigned s_base = (unsigned)(uintptr_t)&s_s[0][0];
     const unsigned sC = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)&s_c0[0][0] + (unsigned)wvu * (S2_PITCH * 4)));
-    const int half = lane >> 5, c32 = lane & 31;           // the prefetch: lanes 0-31 one step, lanes 32-63 the next; lane = bin
+    const int s8 = lane >> 3, g4 = 4 * (lane & 7);         // the prefetch: eight lanes x 16 bytes = the 128-byte line of one step, eight steps per wave-level load
     for (int band = 0; band < nbands; ++band) {
         const int i0 = i_first + band * SYNC_BAND;
         // ---- the NEXT band's 32 new bins (i0 + 44 .. i0 + 75) of every symbol step: one whole 128-byte line per step
-        float pf[PF];
+        v4f pf[PF];
         const bool more = band + 1 < nbands;               // workgroup-uniform
         if (band == 1) SSTAMP(0);
         if (more) {
-            // one uniform base + a 32-bit lane offset per load (a pointer per load would be 48 more registers)
-            const int col = i0 + ROWS + c32;
-            const bool on = col < nbins;
-            const unsigned o0 = (unsigned)((on ? col : 0) + (2 * wv + half) * nbins);
-            const unsigned ostep = (unsigned)(2 * NW * nbins);
+            // one uniform base + a 32-bit lane offset per load (a pointer per load would be 12 more registers)
+            const int col = i0 + ROWS + g4;
+            const bool on = col < nbins;                   // (the row pitch is a multiple of 32 bins: a quad is inside the row or outside it)
+            const unsigned o0 = (unsigned)((on ? col : 0) + (8 * wv + s8) * nbins);
+            const unsigned ostep = (unsigned)(8 * NW * nbins);
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
-                const int m = 2 * (wv + NW * q) + half;
-                pf[q] = (on && m < FT8_NHSYM) ? spec[o0 + (unsigned)q * ostep] : 0.0f;
+                const int m = 8 * (wv + NW * q) + s8;
+                pf[q] = (on && m < FT8_NHSYM) ? *reinterpret_cast<const CWSLG_GLOBAL v4f *>(spec + o0 + (unsigned)q * ostep) : v4f{0.f, 0.f, 0.f, 0.f};
             }
         }
-        // ---- search this band: one wave per bin at a time, each wave owns s_c0[wv]; the hand-scheduled LDS stream of ft8_sync2d_v3_kernel
-        if (band == 1) { asm volatile("" :: "v"(pf[0])); SSTAMP1(1); }
+        if (band == 1) SSTAMP1(1);
         sync2d_search_band<NW>(w, s_base, sC, wvu, lane, i0, ia, ib);
         if (band == 1) SSTAMP1(6);
         if (!more) break;
         __syncthreads();                                    // every wave has finished reading the image
-        // ---- slide the window: rows 32..43 become rows 0..11, then the prefetched lines fill rows 12..43
-        float mv[(12 * S2_PITCH + SYNCC_NT - 1) / SYNCC_NT];
+        // ---- slide the window: rows 32..43 become rows 0..11 (16 bytes per lane and move), then the prefetched lines fill rows 12..43
+        constexpr int NMV = 12 * S2_PITCH / 4, MVT = (NMV + SYNCC_NT - 1) / SYNCC_NT;       // 1134 float4, 3 per lane
+        static_assert((12 * S2_PITCH) % 4 == 0 && (SYNC_BAND * S2_PITCH) % 4 == 0, "16-byte moves");
+        v4f mv[MVT];
 #pragma unroll
-        for (int q = 0; q < (12 * S2_PITCH + SYNCC_NT - 1) / SYNCC_NT; ++q) {
+        for (int q = 0; q < MVT; ++q) {
             const int e = tid + SYNCC_NT * q;
-            mv[q] = (e < 12 * S2_PITCH) ? (&s_s[SYNC_BAND][0])[e] : 0.0f;
+            mv[q] = (e < NMV) ? reinterpret_cast<const v4f *>(&s_s[SYNC_BAND][0])[e] : v4f{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();                                    // (rows 32..43 are also among the rows the prefetch overwrites)
 #pragma unroll
-        for (int q = 0; q < (12 * S2_PITCH + SYNCC_NT - 1) / SYNCC_NT; ++q) {
+        for (int q = 0; q < MVT; ++q) {
             const int e = tid + SYNCC_NT * q;
-            if (e < 12 * S2_PITCH) (&s_s[0][0])[e] = mv[q];
+            if (e < NMV) reinterpret_cast<v4f *>(&s_s[0][0])[e] = mv[q];
         }
         {
-            float *dst = &s_s[12 + c32][S2_COL0 + 1 + half];
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
-                const int m = 2 * (wv + NW * q) + half;
-                if (m < FT8_NHSYM) dst[2 * (wv + NW * q)] = pf[q];
+                const int m = 8 * (wv + NW * q) + s8;
+                if (m < FT8_NHSYM) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s_s[12 + g4 + e][S2_COL0 + 1 + m] = pf[q][e];
+                }
             }
         }
         __syncthreads();

@@ -4,7 +4,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["CWSLG_LIB"] = os.path.join(ROOT, "cwsl_digi_amd/lib/libcwslgpu_stamp.so")
-os.environ["CWSLG_SYNC_VARIANT"] = "128"
+os.environ["CWSLG_SYNC_VARIANT"] = "0"
 import cwsl_digi_amd as P
 ctx = P.Context(0)
 ctx.set_exact(False)
