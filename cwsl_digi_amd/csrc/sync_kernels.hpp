@@ -551,6 +551,31 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     const int uK_ = uk3_ ? NA * (uq_ + 64) + ur_ : NA * (uk2_ + 64) + ur2_;
     const bool ulive_ = sparse && (tid_ >> 6) == 3 && usel_ < 5 && !(ur_ == 0 && (uq_ == 0 || !uk3_)) && uK_ < nbins;
     const float2 w3u = ulive_ ? tb.w3840[uK_] : make_float2(0.f, 0.f);
+    // LDS byte offsets of the last stage's operands and of pass B's eight points, computed ONCE (from the real thread index): the
+    // opaque copy below keeps everything else out of registers, but these 24 are worth theirs -- recomputed per transform they were
+    // ~90 of a wave's ~610 VALU instructions (swizzle, row pitch products, shifts).
+    unsigned au1[IPT], av1[IPT], au2[IPT], av2[IPT], aw1[IPT], aw2[IPT], ap1[IPT], ap2[IPT];
+    bool iskip[IPT], izero[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) {
+        const int it = tid_ + 256 * i;
+        const int r = it >> 6, q = it & 63;
+        const int r2 = (r == 0) ? 0 : NA - r;
+        const int k2 = (r == 0) ? ((64 - q) & 63) : 63 - q;
+        iskip[i] = it >= NITEM || (r == 0 && q > 32);
+        izero[i] = r == 0 && q == 0;
+        const int rr = iskip[i] ? 0 : r, rr2 = iskip[i] ? 0 : r2;
+        au1[i] = 8u * (unsigned)(rr * SY_PITCH + sy_col(q));   av1[i] = 8u * (unsigned)(rr * SY_PITCH + sy_col(q + 64));
+        au2[i] = 8u * (unsigned)(rr2 * SY_PITCH + sy_col(k2)); av2[i] = 8u * (unsigned)(rr2 * SY_PITCH + sy_col(k2 + 64));
+        aw1[i] = 8u * (unsigned)q; aw2[i] = 8u * (unsigned)k2;
+        ap1[i] = 4u * (unsigned)(NA * q + r); ap2[i] = 4u * (unsigned)(NA * k2 + r2);
+    }
+    unsigned aB[8];
+    {
+        const int c = tid_ >> 4, g = tid_ & 15, blk = g >> 3, r = g & 7;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) aB[q] = 8u * (unsigned)((tid_ < NGRP ? c : 0) * SY_PITCH + sy_col(64 * blk + r + 8 * q));
+    }
     if (tid_ >= 64 && tid_ < 128) s_w128[tid_ - 64] = tb.w128[tid_ - 64];
     // every loop-invariant load (twiddles, window) is waited for HERE, with the builtin the compiler's wait-count pass
     // understands: otherwise it keeps conservative vmcnt waits for them inside the loop (the first iteration could still
@@ -563,6 +588,9 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     int t = tid_;
     asm volatile("" : "+v"(t));
     const int tid = t, b = S1MFMA ? 32 * (t >> 6) + (t & 31) : (t & 127);
+    char *const sy_bytes = reinterpret_cast<char *>(&s_y[0][0]);
+    const char *const w128_bytes = reinterpret_cast<const char *>(&s_w128[0]);
+    char *const pw_bytes = reinterpret_cast<char *>(&s_pw[0]);
     float2 z[AMAX];
     float zk[AMAX];                                       // S1MFMA: Re (lanes 0-31) or Im (lanes 32-63) of z_a, the B operand of step a
 #pragma unroll
@@ -646,11 +674,10 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     lds_barrier();
     // pass B: stages len = 16,32,64
     if (tid < NGRP) {
-        const int c = tid >> 4, g = tid & 15;
-        const int blk = g >> 3, r = g & 7;
+        const int r = tid & 7;
         float2 e[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) e[q] = s_y[c][sy_col(64 * blk + r + 8 * q)];
+        for (int q = 0; q < 8; ++q) e[q] = *reinterpret_cast<const float2 *>(sy_bytes + aB[q]);
         {
             const float2 w0 = s_w128[r * 8];
             bfly(e[0], e[1], w0); bfly(e[2], e[3], w0); bfly(e[4], e[5], w0); bfly(e[6], e[7], w0);
@@ -664,34 +691,30 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
             bfly(e[2], e[6], s_w128[(r + 16) * 2]); bfly(e[3], e[7], s_w128[(r + 24) * 2]);
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) s_y[c][sy_col(64 * blk + r + 8 * q)] = e[q];
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<float2 *>(sy_bytes + aB[q]) = e[q];
     }
     lds_barrier();
 
     // last stage (len = 128) fused with the unpack: see the header of this kernel
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
-        const int it = tid + 256 * i;
-        const int r = it >> 6, q = it & 63;                // r is wave-uniform
-        if (it >= NITEM || (r == 0 && q > 32)) continue;
-        const int r2 = (r == 0) ? 0 : NA - r;
-        const int k2 = (r == 0) ? ((64 - q) & 63) : 63 - q;
-        float2 u1 = s_y[r][sy_col(q)], v1 = s_y[r][sy_col(q + 64)];
-        float2 u2 = s_y[r2][sy_col(k2)], v2 = s_y[r2][sy_col(k2 + 64)];
-        bfly(u1, v1, s_w128[q]);
-        bfly(u2, v2, s_w128[k2]);
-        if (r == 0 && q == 0) {                             // Z[0] and Z[NZ/2] pair with themselves
+        if (iskip[i]) continue;
+        float2 u1 = *reinterpret_cast<const float2 *>(sy_bytes + au1[i]), v1 = *reinterpret_cast<const float2 *>(sy_bytes + av1[i]);
+        float2 u2 = *reinterpret_cast<const float2 *>(sy_bytes + au2[i]), v2 = *reinterpret_cast<const float2 *>(sy_bytes + av2[i]);
+        bfly(u1, v1, *reinterpret_cast<const float2 *>(w128_bytes + aw1[i]));
+        bfly(u2, v2, *reinterpret_cast<const float2 *>(w128_bytes + aw2[i]));
+        if (izero[i]) {                                     // Z[0] and Z[NZ/2] pair with themselves
             s_pw[0] = unpack_power(u1, u1, w3[i][0]);
             if (NA * 64 < nbins) s_pw[NA * 64] = unpack_power(v1, v1, tb.w3840[NA * 64]);
             if (NZ < nbins) s_pw[NZ] = unpack_power(u1, u1, tb.w3840[NZ]);
             continue;
         }
-        const int K1 = NA * q + r, K2 = NA * k2 + r2;
         if (sparse) {
-            s_pw[K1] = unpack_power(u1, v2, w3[i][0]);
-            s_pw[K2] = unpack_power(u2, v1, w3[i][1]);
+            *reinterpret_cast<float *>(pw_bytes + ap1[i]) = unpack_power(u1, v2, w3[i][0]);
+            *reinterpret_cast<float *>(pw_bytes + ap2[i]) = unpack_power(u2, v1, w3[i][1]);
             continue;
         }
+        const int K1 = (int)(ap1[i] >> 2), K2 = (int)(ap2[i] >> 2);
         const int K3 = K1 + NA * 64, K4 = K2 + NA * 64;
         if (K1 < nbins) s_pw[K1] = unpack_power(u1, v2, w3[i][0]);
         if (K2 < nbins) s_pw[K2] = unpack_power(u2, v1, w3[i][1]);
