@@ -1179,9 +1179,10 @@ __device__ __forceinline__ void sync2d_search_band(const SyncWork *w, unsigned s
     }
 }
 
-#if CWSLG_LAB      // the band search as its own launch (CWSLG_SYNC_VARIANT bit 7: with ft8_candidates_kernel, three launches), lab library only
 // ft8_sync2d_v3_kernel: one workgroup per (32-bin band, channel), staging as in v2, then sync2d_search_band.  2.74 against v2's 2.92-2.96 ms
-// per 4096 slots (same box); the product runs the same search inside ft8_sync_chan_kernel, which also hides the staging.
+// per 4096 slots (same box).  The product runs it (followed by ft8_candidates_kernel) when a boundary carries FEWER channels than the
+// chip has workgroup slots for ft8_sync_chan_kernel (two per CU): 29 workgroups per channel fill the chip where one per channel
+// walking its 29 bands in turn would not (64 slots: sync stage 0.26 against 0.36 ms).  Same search, same selection: same bits.
 __global__ __launch_bounds__(SYNC2D_NT, 4) void ft8_sync2d_v3_kernel(const SyncWork *__restrict__ works, int ia, int ib, int nbins)
 {
     constexpr int ROWS = SYNC_BAND + 12, NW = SYNC2D_NT / 64;
@@ -1222,7 +1223,6 @@ __global__ __launch_bounds__(SYNC2D_NT, 4) void ft8_sync2d_v3_kernel(const SyncW
     sync2d_search_band<NW>(w, s_base, sC, wvu, lane, i0, ia, ib);
     SSTAMP(6);
 }
-#endif  // CWSLG_LAB
 
 // ---------------------------------------------------------------------------------------------
 // Bitonic sort of (value, index) keys, ascending, ties by ascending index.  n = 2048, 256 threads.
@@ -1472,8 +1472,7 @@ __device__ void ft8_candidates_body(const SyncWork *w, int ia, int ib, float syn
     if (tid == 0) *w->ncand = min(s_n, maxcand);
 }
 
-#if CWSLG_LAB
-// grid (n_channels), NT threads: the candidate selection as its own launch (lab library; the product fuses it into ft8_sync_chan_kernel).
+// grid (n_channels), NT threads: the candidate selection as its own launch (behind ft8_sync2d_v3_kernel; ft8_sync_chan_kernel runs the same body itself).
 template <int NT>
 __global__ __launch_bounds__(NT) void ft8_candidates_kernel(const SyncWork *__restrict__ works, int ia, int ib,
                                                               float syncmin, int maxcand)
@@ -1481,7 +1480,6 @@ __global__ __launch_bounds__(NT) void ft8_candidates_kernel(const SyncWork *__re
     __shared__ __attribute__((aligned(16))) char s_pool[CandLds<NT>::bytes];
     ft8_candidates_body<NT>(works + blockIdx.x, ia, ib, syncmin, maxcand, s_pool);
 }
-#endif  // CWSLG_LAB
 
 // ---------------------------------------------------------------------------------------------
 // ft8_sync_chan_kernel: the Costas search AND the candidate selection of one channel in one workgroup (grid = channels, 512 threads).
