@@ -598,7 +598,10 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
 #if CWSLG_LAB
         if (tile == 256) go(demod_exact3_kernel<D, 256, 128>, 128, occ_cache[di][1]);
         else if (tile == 128) go(demod_exact3_kernel<D, 128, 64>, 64, occ_cache[di][2]);
-        else
+        else if (c->demod_variant == 25) {                   // the FIR as C++ with hand-issued 8-byte loads (round 3's first form; same bits)
+            static int occ25[3] = {};
+            go(demod_exact3_kernel<D, kTileExact, kExactThreads, false>, kExactThreads, occ25[di]);
+        } else
 #endif
         go(demod_exact3_kernel<D, kTileExact, kExactThreads>, kExactThreads, occ_cache[di][0]);
     } else if (!launched) {

@@ -1452,6 +1452,7 @@ __global__ __launch_bounds__(NT, 2) void demod_exact2_kernel(const ChanWork *__r
     }
 }
 
+#include "exact3_asm.inc"
 // ---------------------------------------------------------------------------------------------
 // Registers of demod_exact3_kernel's software pipeline, filled by hand-issued loads (see the kernel).
 typedef float v8f __attribute__((ext_vector_type(8)));
@@ -1686,7 +1687,7 @@ __device__ __forceinline__ void exact3_steps(std::integer_sequence<int, Ps...>, 
 //   Steps 0 and 32 touch one output only (tap blocks -1 and 32 do not exist): the other output's addend is replaced by +0 there.
 //   The loop's LDS reads and scalar loads are issued BY HAND one step ahead (see the loop), and a workgroup walks a run of tiles with
 //   the next tile's HBM loads in flight under its FIR.
-template <int D, int T, int NT>
+template <int D, int T, int NT, bool ASMFIR = true>
 __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__restrict__ works,
                                                               const float *__restrict__ taps2,
                                                               int tiles_x, int n_ch, unsigned *__restrict__ xcd_next, int run_len)
@@ -1696,7 +1697,9 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
     constexpr int NBH = (Geo::NBLK + 1) / 2 + 1;          // blocks per parity array (+1 slack)
     // Row = the block's D mixed samples + its mixer phase; pitch D + 1 complex = 2 (D + 1) dwords, which is 2 (mod 4): the 32 lanes of
     // a ds_read_b64 group (lane l reads row l + n/2) start on the 32 distinct even banks -- conflict-free.
-    constexpr int BP = D + 1;
+    // D = 16: pitch D + 2 (16-byte aligned rows, 36 dwords = 4 (mod 32): the eight lanes of a ds_read_b128 group cover the 32 banks once) --
+    // the whole FIR is one generated assembly statement there (exact3_asm.inc) that reads the samples sixteen bytes at a time.
+    constexpr int BP = (D == 16 && ASMFIR) ? D + 2 : D + 1;
     static_assert(2 * NT >= T && T % 4 == 0 && D % 4 == 0, "two outputs per thread");
     __shared__ __attribute__((aligned(16))) float2 s_t[2][NBH * BP];
     static_assert(sizeof(float2) * 2 * NBH * BP <= 81920, "at least two tiles per CU");
@@ -1826,12 +1829,19 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
         // other step sank to their first use -- loop form -- or, fully unrolled, every ds_read was followed by its own wait.)
         // hipcc does not track these operations; the wait statement also "rewrites" every register they fill (tied operands), so no
         // use of a loaded value can be scheduled above it.
-        ExactBlock<D> bA, bB;
-        ExactTaps<D> hA, hB;
         const unsigned lds0 = (unsigned)(uintptr_t)&s_t[0][tid * BP];          // block 2 l of this lane's window
         const unsigned lds1 = (unsigned)(uintptr_t)&s_t[1][tid * BP];          // block 2 l + 1
         const CWSLG_CONST float *h2 = as_const(taps2);
         v2f W = {0.0f, 0.0f};                                // (Re of o0's workspace slot, Im of o0 + 1's): zero after their last read-out (:178)
+        if constexpr (D == 16 && ASMFIR) {
+            // All 33 steps as ONE assembly statement with every register fixed (scripts/gen_exact3_asm.py): same operations in the same
+            // order as the C++ form below, which stays for D = 8 and 4; the samples arrive through eight ds_read_b128 per step instead of
+            // seventeen ds_read_b64 (inline assembly cannot name the upper pair of a 128-bit operand; fixed registers can).
+            static_assert(EXACT3_ASM_ROW_BYTES == BP * (int)sizeof(float2), "exact3_asm.inc is generated for this row pitch");
+            asm volatile(EXACT3_FIR16_ASM : [w] "+v"(W) : [r0] "v"(lds0), [r1] "v"(lds1), [tp] "s"(h2) : EXACT3_ASM_CLOBBERS);
+        } else {
+        ExactBlock<D> bA, bB;
+        ExactTaps<D> hA, hB;
         auto tail = [&](const ExactTail &t, bool first, bool last) {
             const v2f A = t.sX * t.ph;                       // (ac of o0, ad of o0 + 1)
             const v2f B = t.sY * v2f{-t.ph.y, t.ph.x};       // (-(bd) of o0, bc of o0 + 1): negation commutes with rounding
@@ -1876,6 +1886,7 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
         exact_wait(bA, hA, tl.sY);
         sums(bA, hA, tl, std::true_type{});
         tail(tl, false, true);                               // tap block 32 does not exist
+        }
         STAMP(4);
 #ifdef CWSLG_STAMP_WAVES
         STAMP_WAVE(4);          // slots 4..7: the end of the FIR on waves 0..3 (overwrites slots 5..7 of the other diagnostics)

@@ -56,6 +56,10 @@ def main():
             ch = ctx.channel_open(rx, f, mode)
             for _ in range(int(rng.integers(0, 3))):            # neighbours sharing the receiver's IQ (must not matter)
                 ctx.channel_open(rx, int(rng.integers(-half, half - 6000)), str(rng.choice(["FT8", "FT4"])))
+            if mode == "FT8" and rng.random() < 0.2:            # enough FT8 channels for the per-channel form of the sync stage (>= 2 per CU)
+                for _ in range(520):
+                    ctx.channel_open(rx, int(rng.integers(-half, half - 6000)), "FT8")
+                st["many_channel_iterations"] = st.get("many_channel_iterations", 0) + 1
             oc = O.Channel(mode, fs, blk, f)
             ctx.slot_boundary(mode, 10); oc.boundary(10)
             retune_at = int(rng.integers(1, max(2, n // blk))) * blk if rng.random() < 0.25 else -1
