@@ -72,35 +72,38 @@ def gen():
             e("v_pk_add_f32 %s, %s, %s" % (v2(sy), v2(sy), v2(p)))
 
         tail = n >= 1
+        if n >= 1:
+            # the last accumulation of the step before (its products of sample 15), kept back so that it does not sit two instructions
+            # behind the accumulation of sample 14 on the same register: here the eleven load instructions above separate them
+            e("v_pk_add_f32 %s, %s, %s" % (v2(sxp), v2(sxp), v2(XA)))
+            e("v_pk_add_f32 %s, %s, %s" % (v2(syp), v2(syp), v2(YA)))
+        # one software pipeline over the sixteen samples: products alternate between two register sets, every accumulation four
+        # instructions behind its product; the previous step's four-operation tail is dropped into the first gaps
         MX(sx, 0); MY(sy, 0)
+        MX(XA, 1); MY(YA, 1)
         if tail:
             e("v_pk_mul_f32 %s, %s, %s" % (v2(TA), v2(sxp), v2(php)))
-        MX(XB, 1); MY(YB, 1)
-        if tail:
-            e("v_pk_mul_f32 %s, %s, %s op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" % (v2(TB), v2(syp), v2(php)))
-        MX(XA, 2); MY(YA, 2); AX(XB); AY(YB)
-        if tail:
-            e("v_pk_add_f32 %s, %s, %s" % (v2(TA), v2(TA), v2(TB)))
-            if n == 1:
-                e("v_mov_b32 v%d, 0" % (TA + 1))          # step 0's tail: tap block -1 does not exist (output o0 + 1 gets +0)
-        MX(XB, 3); MY(YB, 3); AX(XA); AY(YA)
-        if tail:
-            e("v_pk_add_f32 %[w], %[w], " + v2(TA))
-        MX(XA, 4); MY(YA, 4); AX(XB); AY(YB)
-        MX(XB, 5); MY(YB, 5); AX(XA); AY(YA)
-        MX(XA, 6); MY(YA, 6); AX(XB); AY(YB)
-        MX(XB, 7); MY(YB, 7); AX(XA); AY(YA)
-        AX(XB); AY(YB)
-        MX(XA, 8); MY(YA, 8); MX(XB, 9); MY(YB, 9); AX(XA); AY(YA)
-        MX(XA, 10); MY(YA, 10); AX(XB); AY(YB)
-        MX(XB, 11); MY(YB, 11); AX(XA); AY(YA)
-        MX(XA, 12); MY(YA, 12); AX(XB); AY(YB)
-        MX(XB, 13); MY(YB, 13); AX(XA); AY(YA)
-        MX(XA, 14); MY(YA, 14); AX(XB); AY(YB)
-        MX(XB, 15); MY(YB, 15); AX(XA); AY(YA)
-        AX(XB); AY(YB)
-    # the tail of step 32: tap block 32 does not exist (output o0 gets +0)
+        sets = [(XB, YB), (XA, YA)]                       # sample m (>= 2) uses sets[m % 2]; sample 1 used (XA, YA)
+        for m in range(2, 16):
+            px, py = sets[m % 2]
+            MX(px, m); MY(py, m)
+            ox, oy = sets[(m - 1) % 2]
+            AX(ox); AY(oy)
+            if tail and m == 2:
+                e("v_pk_mul_f32 %s, %s, %s op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" % (v2(TB), v2(syp), v2(php)))
+            if tail and m == 4:
+                e("v_pk_add_f32 %s, %s, %s" % (v2(TA), v2(TA), v2(TB)))
+                if n == 1:
+                    e("v_mov_b32 v%d, 0" % (TA + 1))      # step 0's tail: tap block -1 does not exist (output o0 + 1 gets +0)
+            if tail and m == 6:
+                e("v_pk_add_f32 %[w], %[w], " + v2(TA))
+        assert sets[15 % 2] == (XA, YA)                   # sample 15's products: accumulated at the top of the next step
+    # step 32's last accumulation, then its tail: tap block 32 does not exist (output o0 gets +0)
     sx, sy, ph = SX[0], SY[0], PH[32 % 3]
+    e("s_nop 1")
+    e("v_pk_add_f32 %s, %s, %s" % (v2(sx), v2(sx), v2(XA)))
+    e("v_pk_add_f32 %s, %s, %s" % (v2(sy), v2(sy), v2(YA)))
+    e("s_nop 3")
     e("v_pk_mul_f32 %s, %s, %s" % (v2(TA), v2(sx), v2(ph)))
     e("v_pk_mul_f32 %s, %s, %s op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" % (v2(TB), v2(sy), v2(ph)))
     e("s_nop 3")

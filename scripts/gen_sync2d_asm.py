@@ -14,7 +14,7 @@ ICOS = [3, 1, 4, 0, 6, 5, 2]
 RING0 = 104                       # v104..v127: 12 ring temporaries (v2f each)
 KACC0 = 98                        # v98..v103: accumulators of the three c0 columns
 ADDR0 = 94                        # v94, v95: persistent unclamped bases; v96, v97: rotating clamped-address temporaries
-DEPTH = 3                         # units (3 reads each) in flight behind the one being consumed
+DEPTH = 3                         # units (3 reads each) in flight behind the one being consumed: twelve ring temporaries, twelve reads outstanding
 
 
 def reg2(base):
@@ -25,20 +25,25 @@ class Gen:
     def __init__(self):
         self.lines = []
         self.issued = 0            # reads issued so far
+        self.done = 0              # reads known to have landed
         self.rot = 0
 
     def emit(self, s):
         self.lines.append(s)
 
     def read(self, dst, addr, off):
+        assert self.issued - self.done < 15, "the LDS counter of a wave holds 15"
         self.emit("ds_read_b64 %s, %s%s" % (dst, addr, (" offset:%d" % off) if off else ""))
         self.issued += 1
         return self.issued         # 1-based index of this read in the in-order stream
 
     def wait_for(self, idx):
+        if idx <= self.done:
+            return                 # an earlier wait already covered it (LDS returns in order)
         n = self.issued - idx      # reads issued after it may still be outstanding
         assert 0 <= n <= 15
         self.emit("s_waitcnt lgkmcnt(%d)" % n)
+        self.done = idx
 
     def clamped(self, sbase, voff):
         t = "v%d" % (ADDR0 + 2 + self.rot)
@@ -81,6 +86,7 @@ def build(with_search, with_c0):
                     dst = acc[ty][which]
                 else:
                     dst = reg2(RING0 + 2 * ring); ring = (ring + 1) % 12
+                    assert not any(dst == r for _, rs in pending for _, r in rs), "ring temporary still holds an unconsumed operand"
                 base_s, base_x = ("%[sS]", XS) if ty == "t" else ("%[sC]", XC)
                 rowoff = row if ty == "t" else 0
                 if which == 0:
@@ -102,6 +108,7 @@ def build(with_search, with_c0):
                     dst = reg2(KACC0 + 2 * col)
                 else:
                     dst = reg2(RING0 + 2 * ring); ring = (ring + 1) % 12
+                    assert not any(dst == r for _, rs in pending for _, r in rs), "ring temporary still holds an unconsumed operand"
                 if col < 2:
                     a = XN; off = 2 * k * RB + 512 * col
                 else:
@@ -112,9 +119,9 @@ def build(with_search, with_c0):
     def consume():
         u, regs = pending.pop(0)
         kind, n, ty = u
-        if n == 0:
-            return                                                    # read straight into its accumulator
         g.wait_for(regs[-1][0])                                       # LDS returns in order: the unit's last read covers all three
+        if n == 0:
+            return                                                    # read straight into its accumulator: nothing to add
         for which, (idx, reg) in enumerate(regs):
             if kind == "S":
                 a = acc[ty][which]
