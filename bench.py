@@ -8,15 +8,16 @@ rounded to int16 [and, once enabled, the FT8 sync stage runs on every frame].  I
 in HBM before the timed region (each receiver's ring holds a full slot, filled by the device-side
 synthetic source; the timed region re-commits it lap after lap without copying).
 
-Workload.  N = 1 (the default): the north-star single-GPU workload, 4096 FT8 slots resident on ONE MI355X
-(94 GB of IQ + 20 GB of frames, checkpoints and spectra).  N > 1: BASELINE configs[3], 512 slots per GPU
-(4096 / 8), fixed per GPU as N grows ("weak").  --slots overrides either.
+Workload.  The north-star single-GPU workload -- 4096 FT8 slots resident on ONE MI355X (94 GB of IQ + 20 GB of frames,
+checkpoints and spectra) -- PER GPU at every N: the per-GPU work is fixed as N grows ("weak"; N = 8 carries 32 768 slots).
+--slots overrides it (--slots 512 at N = 8 is BASELINE configs[3], the north star's 4096 slots sharded over eight GPUs).
 
 One process per GPU.  N>1 is launched by torch.distributed.run; slots shard across ranks
-(slot s of rank r is global slot r*S+s) with no data-path collective; the only collective is an
-8-byte all-reduce on RCCL at every slot boundary (the north_star's "barrier on the mode's slot
-boundary"), issued from INSIDE cwslg_slot_boundary through the C ABI's rendezvous hook
-(cwslg_set_boundary_rendezvous).  value = all ranks' samples / max-over-ranks time.
+(slot s of rank r is global slot r*S+s) with no data-path collective; the only collective is one
+32-byte-per-rank all-gather on RCCL at every slot boundary (the north_star's "barrier on the mode's slot
+boundary"), issued from INSIDE cwslg_slot_boundary_end by the library's own communicator (cwslg_rccl_init;
+--rendezvous torch hands torch.distributed in through cwslg_set_boundary_rendezvous instead), one boundary late so that it
+overlaps the next slot's demod launch.  value = all ranks' samples / max-over-ranks time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -85,7 +86,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--slots", type=int, default=0, help="FT8 slots per GPU (default: 4096 on one GPU = the north-star workload; 512 per GPU when N > 1 = configs[3])")
+    ap.add_argument("--slots", type=int, default=0, help="FT8 slots per GPU (default: 4096 = the north-star workload, at every N; 512 at N = 8 is configs[3])")
     ap.add_argument("--sync", type=int, default=1, help="run the FT8 sync stage (symbol spectra + Costas search) at every boundary")
     ap.add_argument("--channels-per-rx", type=int, default=1,
                     help="1 = private IQ stream per slot (BASELINE configs); C>1 = the reference's topology, C decoders share one receiver's IQ (<=8)")
@@ -124,7 +125,7 @@ def main():
             dist.init_process_group(args.dist_backend)
     dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
 
-    S = args.slots if args.slots > 0 else (4096 if world == 1 else 512)
+    S = args.slots if args.slots > 0 else 4096
     ctx = P.Context(local_rank)
     rendezvous = None
     if world > 1:
@@ -362,6 +363,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{S} FT8 slots/GPU x 15 s (2.88 M IQ samples) at 192 kHz, " + ("private IQ stream per slot " if C == 1 else f"{C} slots share each receiver's IQ (reference topology) ") +
                                    ("(north_star: 4096 concurrent FT8 slots on ONE MI355X, all inputs resident in HBM)" if S == 4096 and world == 1 else
+                                    f"(the north-star workload per GPU, x{world} GPUs: weak scaling)" if S == 4096 else
                                     "(BASELINE configs[3]: 4096 slots sharded 512 per GPU)" if S == 512 else "(--slots override)"),
                        "slots_per_gpu": S, "channels_per_receiver": C, "fs_hz": FS, "iq_block": IQ_LEN, "stages": "nco-mix+polyphase-decimate, peak-normalise+int16" + (", ft8 symbol-spectra+costas-sync+candidates" if args.sync else ""),
                        "sharding": (f"slots x{world}, no data-path collective; per slot boundary one 24-byte-per-rank RCCL all-gather inside cwslg_slot_boundary_end "
