@@ -908,7 +908,7 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s,
     if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
     std::memcpy(w->h, fin.data(), fin.size() * sizeof(FinWork));
     HIPCHK(c, upload_workbuf(c, w, fin.size() * sizeof(FinWork)));
-    const unsigned gx = (unsigned)((max_len + kFinThreads * 8 - 1) / (kFinThreads * 8));
+    const unsigned gx = (unsigned)((max_len + kFinThreads * 8 * kFinChunks - 1) / (kFinThreads * 8 * kFinChunks));
     hipEvent_t ea, eb;
     span_begin(c, 1, &ea, &eb);
     hipLaunchKernelGGL((finalize_kernel<kFinThreads>), dim3(gx, (unsigned)fin.size()), dim3(kFinThreads), 0, c->stream,

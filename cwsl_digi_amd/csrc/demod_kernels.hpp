@@ -1982,6 +1982,7 @@ __global__ __launch_bounds__(64) void demod_transition_kernel(const TransWork *_
 //   factor = 32767.0f / (peak + 1.0f); factor *= scale;  buf[k] *= factor;  (int16)(buf[k] + 0.5f)
 // The peak is max|audio| (max(maxVal, |minVal|) == max|x| for every frame).
 // Samples at and beyond n_valid are the reference's zero tail.
+constexpr int kFinChunks = 4;          // 8-sample chunks per thread of finalize_kernel: four 32-byte reads in flight per lane
 template <int NT>
 __global__ __launch_bounds__(NT) void finalize_kernel(const FinWork *__restrict__ works)
 {
@@ -1989,43 +1990,58 @@ __global__ __launch_bounds__(NT) void finalize_kernel(const FinWork *__restrict_
     const FinWork *fw = works + blockIdx.y;
     const CWSLG_GLOBAL float *frame = as_global(fw->frame);
     CWSLG_GLOBAL int16_t *out = as_global_rw(fw->out);
-    const unsigned i0 = (blockIdx.x * NT + threadIdx.x) * 8u;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (fw->peak_next) *as_global_rw(fw->peak_next) = 0u;
     }
-    if (!fw->emit || i0 >= fw->frame_len) return;
+    // a workgroup covers kFinChunks x NT x 8 consecutive samples; chunk c of a thread is NT x 8 samples behind chunk c - 1 (every wave-level
+    // access is one contiguous 2 KB / 1 KB run).  Round 3: one chunk per thread was 360 000 workgroups of two loads and a store each
+    // per 4096-slot boundary (0.85 ms for 4.4 GB); four chunks per thread, all loads issued first: see DESIGN.md 4.2.
+    const unsigned base = blockIdx.x * (unsigned)(kFinChunks * NT * 8) + threadIdx.x * 8u;
+    if (!fw->emit || blockIdx.x * (unsigned)(kFinChunks * NT * 8) >= fw->frame_len) return;
+    const unsigned nv = fw->n_valid, flen = fw->frame_len;
+    v4f a[kFinChunks], b[kFinChunks];
+#pragma unroll
+    for (int c = 0; c < kFinChunks; ++c) {
+        const unsigned i0 = base + (unsigned)c * (NT * 8);
+        if (i0 + 8 <= nv) {
+            a[c] = *reinterpret_cast<const CWSLG_GLOBAL v4f *>(frame + i0);
+            b[c] = *reinterpret_cast<const CWSLG_GLOBAL v4f *>(frame + i0 + 4);
+        } else {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = (i0 + k < nv) ? frame[i0 + k] : 0.0f;
+            a[c] = v4f{v[0], v[1], v[2], v[3]};
+            b[c] = v4f{v[4], v[5], v[6], v[7]};
+        }
+    }
     const float peak = __uint_as_float(*as_global(fw->peak));
     float factor = 32767.0f / (peak + 1.0f);
     factor = factor * fw->scale;
-    if (i0 == 0 && fw->factor_out) *as_global_rw(fw->factor_out) = factor;
-    const unsigned nv = fw->n_valid;
-    float v[8];
-    if (i0 + 8 <= nv) {
-        const v4f a = *reinterpret_cast<const CWSLG_GLOBAL v4f *>(frame + i0);
-        const v4f b = *reinterpret_cast<const CWSLG_GLOBAL v4f *>(frame + i0 + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = (i0 + k < nv) ? frame[i0 + k] : 0.0f;
-    }
-    int q[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float scaled = v[k] * factor;                 // buf[k] *= factor
-        const float biased = scaled + 0.5f;                 // + 0.5f
-        q[k] = (int)biased;                                 // C truncation toward zero, then narrowed to int16
-    }
+    if (base == 0 && fw->factor_out) *as_global_rw(fw->factor_out) = factor;
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    v4u pk;
-    pk.x = ((unsigned)q[0] & 0xFFFFu) | ((unsigned)q[1] << 16);
-    pk.y = ((unsigned)q[2] & 0xFFFFu) | ((unsigned)q[3] << 16);
-    pk.z = ((unsigned)q[4] & 0xFFFFu) | ((unsigned)q[5] << 16);
-    pk.w = ((unsigned)q[6] & 0xFFFFu) | ((unsigned)q[7] << 16);
-    const unsigned rem = fw->frame_len - i0;
-    if (rem >= 8) {
-        *reinterpret_cast<CWSLG_GLOBAL v4u *>(out + i0) = pk;
-    } else {
-        for (unsigned k = 0; k < rem; ++k) out[i0 + k] = (int16_t)q[k];
+#pragma unroll
+    for (int c = 0; c < kFinChunks; ++c) {
+        const unsigned i0 = base + (unsigned)c * (NT * 8);
+        if (i0 >= flen) break;
+        const float v[8] = {a[c].x, a[c].y, a[c].z, a[c].w, b[c].x, b[c].y, b[c].z, b[c].w};
+        int q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float scaled = v[k] * factor;                 // buf[k] *= factor
+            const float biased = scaled + 0.5f;                 // + 0.5f
+            q[k] = (int)biased;                                 // C truncation toward zero, then narrowed to int16
+        }
+        v4u pk;
+        pk.x = ((unsigned)q[0] & 0xFFFFu) | ((unsigned)q[1] << 16);
+        pk.y = ((unsigned)q[2] & 0xFFFFu) | ((unsigned)q[3] << 16);
+        pk.z = ((unsigned)q[4] & 0xFFFFu) | ((unsigned)q[5] << 16);
+        pk.w = ((unsigned)q[6] & 0xFFFFu) | ((unsigned)q[7] << 16);
+        const unsigned rem = flen - i0;
+        if (rem >= 8) {
+            *reinterpret_cast<CWSLG_GLOBAL v4u *>(out + i0) = pk;
+        } else {
+            for (unsigned k = 0; k < rem; ++k) out[i0 + k] = (int16_t)q[k];
+        }
     }
 }
 
