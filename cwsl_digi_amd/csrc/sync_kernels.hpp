@@ -662,7 +662,12 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
                 e[k] = s_y[c][16 * k3 + gb];
             }
         }
-        lds_barrier();                     // everyone has gathered: the image may now be rewritten
+        // No workgroup barrier here, nor between pass A and pass B: row c is gathered, rewritten and read again by the SAME sixteen
+        // lanes (tid >> 4 == c), i.e. inside one wave, whose LDS operations execute in program order (round 3: two barriers fewer per
+        // transform, ~0.1 ms each per 4096 slots).  The fences only keep the compiler from moving LDS accesses across these points.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (tid < NGRP) {
             bfly_one(e[0], e[1]); bfly_one(e[2], e[3]); bfly_one(e[4], e[5]); bfly_one(e[6], e[7]);
             bfly_one(e[0], e[2]); bfly_mj(e[1], e[3]); bfly_one(e[4], e[6]); bfly_mj(e[5], e[7]);
@@ -671,7 +676,9 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
             for (int k = 0; k < 8; ++k) s_y[c][sy_col(8 * g + k)] = e[k];
         }
     }
-    lds_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                 // (see above: pass B reads what lanes of this wave wrote)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // pass B: stages len = 16,32,64
     if (tid < NGRP) {
         const int r = tid & 7;
