@@ -957,15 +957,15 @@ __device__ __forceinline__ void wave_first_max(float v, int lag, float &best, in
 // x / 6.0f, correctly rounded, in three operations instead of the ten of the IEEE division sequence: q0 = x * fl(1/6), the residual
 // x - 6 q0 is exact in one fmaf, one more fmaf corrects q0.  Checked against the division for EVERY float (tests/div6_check.c,
 // tests/test_div6_shortcut.py): identical for all x with 2^-125 <= |x| < inf and for +-0; below that range the quotient is denormal
-// (double rounding) and at inf the residual is NaN -- those inputs (and, with margin, everything below 2^-95) take the division itself.
+// (double rounding) and at inf the residual is NaN -- those inputs (with margin: everything below 2^-95, zero included) take the division itself.
 __device__ __forceinline__ float div6_exact(float x)
 {
     const float r = 0x1.555556p-3f;                     // fl(1/6)
     const float q0 = x * r;
     const float e = __builtin_fmaf(-6.0f, q0, x);
     float q = __builtin_fmaf(e, r, q0);
-    const unsigned ex = __float_as_uint(x) & 0x7f800000u;
-    if (__builtin_expect(ex - 0x10000000u > 0x6f000000u && x != 0.0f, 0)) q = x / 6.0f;
+    // |x| outside [2^-95, FLT_MAX] -- zero included: the division gives the same +-0 -- takes the division (one compare on the magnitude bits)
+    if (__builtin_expect((__float_as_uint(x) & 0x7fffffffu) - 0x10000000u >= 0x6f800000u, 0)) q = x / 6.0f;
     return q;
 }
 
@@ -1165,9 +1165,13 @@ __device__ __forceinline__ void sync2d_search_band(const SyncWork *w, unsigned s
                            [vC4] "v"(vC[0]), [vC5] "v"(vC[1]), [vC6] "v"(vC[2]), [vU] "v"(vU), [sS] "s"(sS), [sC] "s"(sC)
                          : SYNC2D_ASM_CLOBBERS);
         if (rr == rr0) SSTAMP(3);
-        const float sa = ok0 ? sync_finish(ta.x, tb.x, tc.x, ua.x, ub.x, uc.x) : ninf;
-        const float sb = ok1 ? sync_finish(ta.y, tb.y, tc.y, ua.y, ub.y, uc.y) : ninf;
-        if (rr == rr0) { asm volatile("" :: "v"(sa), "v"(sb)); SSTAMP(4); }
+        // (computed on every lane and selected afterwards: 62 or 63 of the 64 lanes hold a lag, a branch around the divisions saves nothing)
+        float sa = sync_finish(ta.x, tb.x, tc.x, ua.x, ub.x, uc.x);
+        float sb = sync_finish(ta.y, tb.y, tc.y, ua.y, ub.y, uc.y);
+        asm volatile("" : "+v"(sa), "+v"(sb));
+        sa = ok0 ? sa : ninf;
+        sb = ok1 ? sb : ninf;
+        if (rr == rr0) SSTAMP(4);
         // +-62: the lane's own first maximum (lag j before j + 1), then the wavefront's
         const bool b2 = sb > sa;
         float r2; int l2;

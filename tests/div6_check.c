@@ -1,6 +1,6 @@
 /* Test helper (compiled by tests/test_div6_shortcut.py): compares the three-operation x / 6 of sync_kernels.hpp (div6_exact) with the
  * IEEE division for every float whose bit pattern is start + k * stride.  Prints the number of mismatches inside the range the kernel
- * uses the shortcut for (2^-95 <= |x| <= FLT_MAX, and +-0) and the number outside it. */
+ * uses the shortcut for (2^-95 <= |x| <= FLT_MAX) and the number outside it. */
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -21,7 +21,7 @@ int main(int argc, char **argv)
         memcpy(&c, &q, 4);
         if (a == c || (ref != ref && q != q)) continue;
         const uint32_t ex = b & 0x7f800000u;
-        const int shortcut = !((uint32_t)(ex - 0x10000000u) > 0x6f000000u && x != 0.0f);
+        const int shortcut = !((uint32_t)((b & 0x7fffffffu) - 0x10000000u) >= 0x6f800000u);
         if (shortcut) ++bad_in; else ++bad_out;
     }
     printf("%llu %llu %llu\n", (unsigned long long)n, (unsigned long long)bad_in, (unsigned long long)bad_out);
