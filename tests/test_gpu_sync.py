@@ -97,6 +97,44 @@ def test_sync_many_channels_one_launch(ctx, oracle):
         assert any(abs(c[0] - want_bin) <= 1 for c in got)
 
 
+@pytest.mark.parametrize("maxcand,syncmin,lo,hi", [(600, 1.2, 100, 5800), (200, 1.5, 200, 3000), (50, 2.0, 437, 2313)])
+def test_sync_per_channel_form(ctx, oracle, maxcand, syncmin, lo, hi):
+    """With at least two workgroups' worth of FT8 channels per CU a boundary runs ft8_sync_chan_kernel (one workgroup per channel: sliding
+    LDS window over all bands + fused candidate selection) instead of one workgroup per band: 520 channels share one receiver here; the
+    per-bin peaks and lags and the candidate lists of channels spread over the range must equal the restatement's bit for bit -- for the
+    default search, the widest one (row pitch 1952 bins: the spectra kernel's generic upper half) and a range whose edges fall inside bands."""
+    fs, blk = 48000, 2048
+    n = 720000 // blk * blk
+    rng = np.random.default_rng(5)
+    freqs = [int(f) for f in rng.integers(-fs // 2, fs // 2 - 6500, 520)]
+    iq = oracle.synth_iq(77, n, fs)
+    probe = [0, 1, 257, 519]
+    for k in probe:
+        for j in range(3):
+            iq = iq + ft8_iq(fs, n, freqs[k], 400.0 + 700.0 * j + 13.0 * k % 97, 0.2 + 0.3 * j, 1500.0 + 400.0 * j, rng)
+    iq = iq.astype(np.complex64)
+    ctx.enable_sync(True, syncmin, maxcand, lo, hi)
+    rx = ctx.receiver_open(fs, blk, 0)
+    chans = [ctx.channel_open(rx, f, "FT8") for f in freqs]
+    ctx.slot_boundary("FT8", 1)
+    for k in range(0, n, 64 * blk):
+        ctx.push_iq(rx, iq[k:k + 64 * blk])
+    ctx.slot_boundary("FT8", 16)
+    for k in probe:
+        ch = chans[k]
+        fr = ctx.fetch_frame(ch)["i16"]
+        ref, arr = oracle.ft8_sync(fr, lo, hi, syncmin, maxcand, want_arrays=True)
+        ia, ib = max(1, int(round(lo / 3.125))), min(int(round(hi / 3.125)), 1920 - 12)      # sync8: ia = nint(nfa / df), ib = nint(nfb / df)
+        for name in ("red", "red2"):
+            assert np.array_equal(ctx.sync_debug(ch, name)[ia:ib + 1].view(np.uint32), arr[name][ia:ib + 1].view(np.uint32)), (k, name)
+        for name in ("jpeak", "jpeak2"):
+            assert np.array_equal(ctx.sync_debug(ch, name)[ia:ib + 1], arr[name][ia:ib + 1]), (k, name)
+        got = ctx.fetch_candidates(ch, 600)
+        assert [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in got] == \
+               [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in ref], k
+        assert len(got) <= maxcand
+
+
 # ---------------------------------------------------------------------------------------------- FT4
 from ft8_signal import ft4_iq
 
