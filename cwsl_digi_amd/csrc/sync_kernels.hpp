@@ -8,17 +8,18 @@
 // every float operation is un-fused and in a fixed order, the FFT factorisation and twiddle tables are
 // fixed, so the candidate lists are BIT-IDENTICAL to that restatement (tests/test_gpu_sync.py).
 //
-// Three launches per slot boundary, all channels of the group batched in each:
-//   symbol_spectra_kernel one workgroup per (symbol step, channel): 1920 int16 -> packed 1920-point complex
-//                         FFT (15 x 128: 15-point DFTs + radix-2 DIT butterflies in LDS) -> |X|^2 rows
-//   ft8_sync2d_kernel     one workgroup per (32-bin band, channel): band of the spectra staged in LDS once,
-//                         lane = time lag, Costas correlation for 125 lags, wavefront-shuffle arg-max for the
-//                         +-10 and +-62 lag peak searches
-//   ft8_candidates_kernel one workgroup per channel: 40th-percentile normalisation (bitonic sort in LDS),
-//                         thresholding, near-duplicate suppression, final ordering
-// Why not one fused kernel: one slot's spectra are 372 x ~973 floats = 1.45 MB, nine times the CU's LDS, and
-// every lag touches 21 symbol steps spread over the whole slot; the spectra make one trip through
-// L2/Infinity Cache between the first two launches instead (1.45 MB per slot against 23 MB of IQ).
+// Launches per slot boundary, all FT8 channels of the group batched in each:
+//   symbol_spectra_v2_kernel one workgroup per (12 symbol steps, channel): 1920 int16 -> packed 1920-point complex FFT
+//                         (15 x 128: 15-point DFTs + radix-2 DIT butterflies in LDS) -> |X|^2 rows
+//   ft8_sync_chan_kernel  one workgroup per channel: walks the 32-bin bands of the search range with a sliding LDS window (the next
+//                         band's lines in flight under the search), lane = two adjacent time lags, Costas correlation for 125 lags
+//                         with the LDS traffic of a bin as one hand-scheduled stream (sync2d_asm.inc), wavefront arg-max for the +-10
+//                         and +-62 lag peak searches; then the candidate selection of the channel: 40th-percentile normalisation
+//                         (bitonic sort in LDS), thresholding, near-duplicate suppression, final ordering
+//   (boundaries with fewer channels than two per CU: ft8_sync2d_v3_kernel, one workgroup per (band, channel), + ft8_candidates_kernel)
+// Why not one fused kernel: one slot's spectra are 372 x ~973 floats = 1.45 MB, nine times the CU's LDS, and every lag touches 21
+// symbol steps spread over the whole slot; the spectra make one trip through memory between the two launches instead (1.45 MB per
+// slot, written once and fetched once, against 23 MB of IQ).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
