@@ -1706,6 +1706,7 @@ int cwslg_slot_boundary_begin(cwslg_ctx *c, int group, uint64_t epoch_s)
     if (rc) return rc;
     if (!c->rdv_fn) return CWSLG_OK;
     if (!c->rdv_ready) HIPCHK(c, hipEventCreateWithFlags(&c->rdv_ready, hipEventDisableTiming));
+    if (c->cand_pending) HIPCHK(c, hipStreamWaitEvent(c->stream, c->cand_done, 0));   // (lab variants that run sync work on the side stream: it belongs to this boundary)
     HIPCHK(c, hipEventRecord(c->rdv_ready, c->stream));
     c->rdv_pending = true;
     c->rdv_group = group; c->rdv_epoch = epoch_s; c->rdv_mine = mine;
