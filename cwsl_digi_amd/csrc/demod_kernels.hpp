@@ -151,6 +151,17 @@ __device__ __forceinline__ float2 cmul_exact(float2 a, float2 b)
     const float bc = a.y * b.x;
     return make_float2(ac - bd, ad + bc);
 }
+// The same four products, the same difference and sum (each rounded on its own: un-fused), as THREE packed operations: (ac, ad),
+// (bd, bc), then (ac - bd, ad + bc) with the first component's addend negated (a + (-b) is a - b exactly).  Half the issue slots
+// of the six scalar operations; used where what bounds the code is what one wave can issue (demod_exact3_kernel's mix).
+__device__ __forceinline__ v2f cmul_exact_pk(v2f a, v2f b)
+{
+    v2f p1, p2, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p1) : "v"(a), "v"(b));                 // (a.x b.x, a.x b.y)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(p2) : "v"(a), "v"(b));    // (a.y b.y, a.y b.x)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(p1), "v"(p2));                    // (ac - bd, ad + bc)
+    return r;
+}
 
 // Phasor checkpoint table, built once per distinct tuning at channel-open time.  The recurrence is serial, so
 // pass 1 walks it with one lane per channel, keeping only every kCoarse-th checkpoint; pass 2 fills the checkpoints in
@@ -196,6 +207,19 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_get(float x)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, 0xf, 0xf, false));
+}
+// wavefront maximum of a non-negative float: four DPP steps inside the 16-lane rows, four readlanes across them (a __shfl_xor butterfly
+// is six dependent ds_bpermute round trips)
+__device__ __forceinline__ float wave_max_dpp(float v)
+{
+    v = fmaxf(v, dpp_get<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_get<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_get<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_get<0x140>(v));                            // row_mirror: every lane of a row holds the row maximum
+    const int vi = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(vi, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(vi, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(vi, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(vi, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
 // One halving step over the lane bit BIT (pairing CTRL): lanes with the bit clear keep lo and get the
@@ -1795,10 +1819,10 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
                     if (SLOW) {
                         if (r < fv) x = v4f{0.0f, 0.0f, 0.0f, 0.0f};       // fv is a multiple of D: both samples of the pair
                     }
-                    const float2 a = cmul_exact(make_float2(x.x, x.y), tn0);
-                    const float2 b = cmul_exact(make_float2(x.z, x.w), tn1);
+                    const v2f a = cmul_exact_pk(v2f{x.x, x.y}, v2f{tn0.x, tn0.y});
+                    const v2f b = cmul_exact_pk(v2f{x.z, x.w}, v2f{tn1.x, tn1.y});
                     const int blk = r / D, m = r % D;
-                    float2 *row = &s_t[blk & 1][(blk >> 1) * BP + m];               // rows are 8-byte aligned only: two ds_write_b64
+                    v2f *row = reinterpret_cast<v2f *>(&s_t[blk & 1][(blk >> 1) * BP + m]);   // D = 16: 16-byte aligned (one ds_write_b128); else two ds_write_b64
                     row[0] = a;
                     row[1] = b;
                 }
@@ -1822,6 +1846,7 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
         issue_tile_loads<D, T, NT>(nxt, tid, xs, ck, tn);
     }
     const int o0 = 2 * tid;
+    float mx_lane = 0.0f;                                    // this lane's |output| maximum (0 for lanes without outputs: the reduction below reads every lane)
     if (o0 < T && o0 < cur.n_out) {
         // The FIR loop's memory operations are issued by hand (inline assembly) so that their ORDER is what is written here: at the
         // top of step n one `s_waitcnt lgkmcnt(0)` covers the LDS reads and the scalar tap loads of step n, which were issued a whole
@@ -1898,9 +1923,10 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
         CWSLG_GLOBAL v2f *out2 = reinterpret_cast<CWSLG_GLOBAL v2f *>(as_global_rw(cur.out) + (size_t)cur.tile * T + o0);
         v2f ov; ov.x = v0; ov.y = v1;
         *out2 = ov;
-        float mx = fmaxf(fabsf(v0), fabsf(v1));
-#pragma unroll
-        for (int msk = 32; msk >= 1; msk >>= 1) mx = fmaxf(mx, __shfl_xor(mx, msk, 64));
+        mx_lane = fmaxf(fabsf(v0), fabsf(v1));
+    }
+    {
+        const float mx = wave_max_dpp(mx_lane);              // all 64 lanes take part (DPP and readlane read registers, not exec-masked data)
         if ((tid & 63) == 0) publish_peak(cur.peak, mx);
     }
 #ifndef CWSLG_STAMP_WAVES
