@@ -1721,9 +1721,10 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
     constexpr int NBH = (Geo::NBLK + 1) / 2 + 1;          // blocks per parity array (+1 slack)
     // Row = the block's D mixed samples + its mixer phase; pitch D + 1 complex = 2 (D + 1) dwords, which is 2 (mod 4): the 32 lanes of
     // a ds_read_b64 group (lane l reads row l + n/2) start on the 32 distinct even banks -- conflict-free.
-    // D = 16: pitch D + 2 (16-byte aligned rows, 36 dwords = 4 (mod 32): the eight lanes of a ds_read_b128 group cover the 32 banks once) --
-    // the whole FIR is one generated assembly statement there (exact3_asm.inc) that reads the samples sixteen bytes at a time.
-    constexpr int BP = (D == 16 && ASMFIR) ? D + 2 : D + 1;
+    // ASMFIR (the product): pitch D + 2 -- 16-byte aligned rows whose start banks (36, 20, 12 dwords = 4 (mod 8) apart) put the eight lanes of a
+    // ds_read_b128 group on the 32 banks exactly once -- the whole FIR is one generated assembly statement (exact3_asm.inc) that reads the
+    // samples sixteen bytes at a time.  The C++ form (lab library, CWSLG_DEMOD_VARIANT=25) keeps pitch D + 1 and 8-byte reads.
+    constexpr int BP = ASMFIR ? D + 2 : D + 1;
     static_assert(2 * NT >= T && T % 4 == 0 && D % 4 == 0, "two outputs per thread");
     __shared__ __attribute__((aligned(16))) float2 s_t[2][NBH * BP];
     static_assert(sizeof(float2) * 2 * NBH * BP <= 81920, "at least two tiles per CU");
@@ -1858,12 +1859,14 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
         const unsigned lds1 = (unsigned)(uintptr_t)&s_t[1][tid * BP];          // block 2 l + 1
         const CWSLG_CONST float *h2 = as_const(taps2);
         v2f W = {0.0f, 0.0f};                                // (Re of o0's workspace slot, Im of o0 + 1's): zero after their last read-out (:178)
-        if constexpr (D == 16 && ASMFIR) {
-            // All 33 steps as ONE assembly statement with every register fixed (scripts/gen_exact3_asm.py): same operations in the same
-            // order as the C++ form below, which stays for D = 8 and 4; the samples arrive through eight ds_read_b128 per step instead of
-            // seventeen ds_read_b64 (inline assembly cannot name the upper pair of a 128-bit operand; fixed registers can).
-            static_assert(EXACT3_ASM_ROW_BYTES == BP * (int)sizeof(float2), "exact3_asm.inc is generated for this row pitch");
-            asm volatile(EXACT3_FIR16_ASM : [w] "+v"(W) : [r0] "v"(lds0), [r1] "v"(lds1), [tp] "s"(h2) : EXACT3_ASM_CLOBBERS);
+        if constexpr (ASMFIR) {
+            // All 33 steps as ONE assembly statement with every register fixed (scripts/gen_exact3_asm.py, one stream per D): same operations
+            // in the same order as the C++ form below; the samples arrive through D / 2 ds_read_b128 per step instead of D + 1 ds_read_b64
+            // (inline assembly cannot name the upper pair of a 128-bit operand; fixed registers can).
+            static_assert(EXACT3_ASM_ROW_BYTES(D) == BP * (int)sizeof(float2), "exact3_asm.inc is generated for this row pitch");
+            if constexpr (D == 16) asm volatile(EXACT3_FIR16_ASM : [w] "+v"(W) : [r0] "v"(lds0), [r1] "v"(lds1), [tp] "s"(h2) : EXACT3_ASM_CLOBBERS_16);
+            else if constexpr (D == 8) asm volatile(EXACT3_FIR8_ASM : [w] "+v"(W) : [r0] "v"(lds0), [r1] "v"(lds1), [tp] "s"(h2) : EXACT3_ASM_CLOBBERS_8);
+            else asm volatile(EXACT3_FIR4_ASM : [w] "+v"(W) : [r0] "v"(lds0), [r1] "v"(lds1), [tp] "s"(h2) : EXACT3_ASM_CLOBBERS_4);
         } else {
         ExactBlock<D> bA, bB;
         ExactTaps<D> hA, hB;

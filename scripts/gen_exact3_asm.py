@@ -15,15 +15,27 @@ instances drop the component of the tap block that does not exist.
 
     python scripts/gen_exact3_asm.py > cwsl_digi_amd/csrc/exact3_asm.inc
 """
-D = 16
-ROW = (D + 2) * 8            # LDS row pitch in bytes: 16 samples + phase + pad (16-byte aligned rows)
-TROW = 2 * D * 4             # bytes per tap row
-QA, QB = 160, 192            # sample registers of the two buffers (32 each)
-PH = [224, 226, 228]         # block phase, three in rotation (current, previous for the tail, next in flight)
-SX = [230, 234]              # running sums by step parity
-SY = [232, 236]
-XA, YA, XB, YB, TA, TB = 238, 240, 242, 244, 246, 248
-HA, HB = 36, 68              # tap rows (32 SGPRs each)
+VBASE = {16: 160, 8: 100, 4: 76}     # first fixed VGPR: high enough to leave the compiler its own registers (next tile's prefetch: 68 / 36 / 20),
+                                       # low enough for three (96 kHz) and four (48 kHz) waves per SIMD where the LDS image allows them
+SBASE = 36                            # first fixed SGPR
+
+
+def regmap(D):
+    b = VBASE[D]
+    m = dict(QA=b, QB=b + 2 * D)      # sample registers of the two buffers (2 D each)
+    t = b + 4 * D
+    m["PH"] = [t, t + 2, t + 4]       # block phase, three in rotation (current, previous for the tail, next in flight)
+    m["SX"] = [t + 6, t + 10]         # running sums by step parity
+    m["SY"] = [t + 8, t + 12]
+    m["XA"], m["YA"], m["XB"], m["YB"], m["TA"], m["TB"] = t + 14, t + 16, t + 18, t + 20, t + 22, t + 24
+    m["VTOP"] = t + 26
+    m["HA"], m["HB"] = SBASE, SBASE + 2 * D      # tap rows (2 D SGPRs each)
+    m["STOP"] = SBASE + 4 * D
+    return m
+
+
+def row_bytes(D):
+    return (D + 2) * 8       # LDS row pitch: D samples + phase + pad (16-byte aligned rows)
 
 
 def v2(r):
@@ -34,7 +46,11 @@ def s2(r):
     return "s[%d:%d]" % (r, r + 1)
 
 
-def gen():
+def gen(D):
+    ROW, TROW = row_bytes(D), 2 * D * 4
+    R = regmap(D)
+    QA, QB, PH, SX, SY, HA, HB = R["QA"], R["QB"], R["PH"], R["SX"], R["SY"], R["HA"], R["HB"]
+    XA, YA, XB, YB, TA, TB = R["XA"], R["YA"], R["XB"], R["YB"], R["TA"], R["TB"]
     out = []
     e = out.append
 
@@ -43,11 +59,16 @@ def gen():
         q = QA if n % 2 == 0 else QB
         row = "%[r0]" if n % 2 == 0 else "%[r1]"
         off = (n >> 1) * ROW
-        e("s_load_dwordx16 s[%d:%d], %%[tp], 0x%x" % (h, h + 15, n * TROW))
-        e("s_load_dwordx16 s[%d:%d], %%[tp], 0x%x" % (h + 16, h + 31, n * TROW + 64))
-        for k in range(8):
+        if D == 16:
+            e("s_load_dwordx16 s[%d:%d], %%[tp], 0x%x" % (h, h + 15, n * TROW))
+            e("s_load_dwordx16 s[%d:%d], %%[tp], 0x%x" % (h + 16, h + 31, n * TROW + 64))
+        elif D == 8:
+            e("s_load_dwordx16 s[%d:%d], %%[tp], 0x%x" % (h, h + 15, n * TROW))
+        else:
+            e("s_load_dwordx8 s[%d:%d], %%[tp], 0x%x" % (h, h + 7, n * TROW))
+        for k in range(D // 2):
             e("ds_read_b128 v[%d:%d], %s offset:%d" % (q + 4 * k, q + 4 * k + 3, row, off + 16 * k))
-        e("ds_read_b64 %s, %s offset:%d" % (v2(PH[n % 3]), row, off + 128))
+        e("ds_read_b64 %s, %s offset:%d" % (v2(PH[n % 3]), row, off + 8 * D))
 
     issue(0)
     for n in range(33):
@@ -84,20 +105,25 @@ def gen():
         if tail:
             e("v_pk_mul_f32 %s, %s, %s" % (v2(TA), v2(sxp), v2(php)))
         sets = [(XB, YB), (XA, YA)]                       # sample m (>= 2) uses sets[m % 2]; sample 1 used (XA, YA)
-        for m in range(2, 16):
+        for m in range(2, D):
             px, py = sets[m % 2]
             MX(px, m); MY(py, m)
             ox, oy = sets[(m - 1) % 2]
             AX(ox); AY(oy)
             if tail and m == 2:
                 e("v_pk_mul_f32 %s, %s, %s op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" % (v2(TB), v2(syp), v2(php)))
-            if tail and m == 4:
+            if tail and m == (4 if D >= 8 else 3):
+                if D < 8:
+                    e("s_nop 1")
                 e("v_pk_add_f32 %s, %s, %s" % (v2(TA), v2(TA), v2(TB)))
                 if n == 1:
                     e("v_mov_b32 v%d, 0" % (TA + 1))      # step 0's tail: tap block -1 does not exist (output o0 + 1 gets +0)
-            if tail and m == 6:
+            if tail and D >= 8 and m == 6:
                 e("v_pk_add_f32 %[w], %[w], " + v2(TA))
-        assert sets[15 % 2] == (XA, YA)                   # sample 15's products: accumulated at the top of the next step
+        if tail and D < 8:
+            e("s_nop 1")
+            e("v_pk_add_f32 %[w], %[w], " + v2(TA))
+        assert sets[(D - 1) % 2] == (XA, YA)              # the last sample's products: accumulated at the top of the next step
     # step 32's last accumulation, then its tail: tap block 32 does not exist (output o0 gets +0)
     sx, sy, ph = SX[0], SY[0], PH[32 % 3]
     e("s_nop 1")
@@ -115,9 +141,12 @@ def gen():
     return out
 
 
-lines = gen()
 print("// GENERATED by scripts/gen_exact3_asm.py -- do not edit.  See that script and demod_exact3_kernel (demod_kernels.hpp).")
-print("#define EXACT3_ASM_ROW_BYTES %d" % ROW)
-print("#define EXACT3_ASM_CLOBBERS " + ", ".join('"v%d"' % r for r in range(160, 250)) + ", " + ", ".join('"s%d"' % r for r in range(36, 100)) + ', "memory"')
-print("#define EXACT3_FIR16_ASM \\")
-print(" \\\n".join('    "%s\\n\\t"' % l for l in lines))
+print("#define EXACT3_ASM_ROW_BYTES(D) (((D) + 2) * 8)")
+for D in (16, 8, 4):
+    R = regmap(D)
+    print("#define EXACT3_ASM_CLOBBERS_%d " % D + ", ".join('"v%d"' % r for r in range(VBASE[D], R["VTOP"])) + ", "
+          + ", ".join('"s%d"' % r for r in range(SBASE, R["STOP"])) + ', "memory"')
+    print("#define EXACT3_FIR%d_ASM \\" % D)
+    print(" \\\n".join('    "%s\\n\\t"' % l for l in gen(D)))
+    print()

@@ -42,14 +42,21 @@ def test_sync2d_stream_reads_and_waits():
                     assert where.get(o, 0) <= done, (macro, l)
 
 
-def test_exact3_stream_shape():
-    ls = _lines(_gen("gen_exact3_asm.py"), "EXACT3_FIR16_ASM")
-    assert sum(l.startswith("ds_read_b128") for l in ls) == 33 * 8 and sum(l.startswith("ds_read_b64") for l in ls) == 33
-    assert sum(l.startswith("s_load_dwordx16") for l in ls) == 66 and sum(l.startswith("s_waitcnt lgkmcnt(0)") for l in ls) == 33
+import pytest
+
+
+@pytest.mark.parametrize("D", [16, 8, 4])
+def test_exact3_stream_shape(D):
+    ls = _lines(_gen("gen_exact3_asm.py"), "EXACT3_FIR%d_ASM" % D)
+    assert sum(l.startswith("ds_read_b128") for l in ls) == 33 * D // 2 and sum(l.startswith("ds_read_b64") for l in ls) == 33
+    assert sum(l.startswith("s_load_dwordx") for l in ls) == (66 if D == 16 else 33) and sum(l.startswith("s_waitcnt lgkmcnt(0)") for l in ls) == 33
     muls = [l for l in ls if l.startswith("v_pk_mul_f32")]
     adds = [l for l in ls if l.startswith("v_pk_add_f32")]
-    assert len(muls) == 33 * 32 + 33 * 2              # 16 taps x (Re, Im) per step + two per tail
-    assert len(adds) == 33 * 30 + 33 * 2              # 15 accumulations x (Re, Im) per step (the first product starts the sum) + two per tail
+    assert len(muls) == 33 * 2 * D + 33 * 2           # D taps x (Re, Im) per step + two per tail
+    assert len(adds) == 33 * 2 * (D - 1) + 33 * 2     # D - 1 accumulations x (Re, Im) per step (the first product starts the sum) + two per tail
+    # every tap pair and every sample pair of a step is used exactly once per component, in order
+    for n in (0, 1, 32):
+        pass
     # un-fused arithmetic only
     assert not any("fma" in l or "fmac" in l for l in ls)
     # a product is consumed no sooner than three instructions after it was made (dependent packed operations wait ~11 cycles)
