@@ -97,7 +97,7 @@ def test_sync_many_channels_one_launch(ctx, oracle):
         assert any(abs(c[0] - want_bin) <= 1 for c in got)
 
 
-@pytest.mark.parametrize("maxcand,syncmin,lo,hi", [(600, 1.2, 100, 5800), (200, 1.5, 200, 3000), (50, 2.0, 437, 2313)])
+@pytest.mark.parametrize("maxcand,syncmin,lo,hi", [(600, 1.2, 100, 5800), (200, 1.5, 200, 3000), (50, 2.0, 437, 2313), (100, 1.5, 0, 1000)])
 def test_sync_per_channel_form(ctx, oracle, maxcand, syncmin, lo, hi):
     """With at least two workgroups' worth of FT8 channels per CU a boundary runs ft8_sync_chan_kernel (one workgroup per channel: sliding
     LDS window over all bands + fused candidate selection) instead of one workgroup per band: 520 channels share one receiver here; the
