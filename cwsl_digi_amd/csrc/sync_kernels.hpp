@@ -1576,8 +1576,9 @@ __global__ __launch_bounds__(SYNCC_NT, 4) void ft8_sync_chan_kernel(const SyncWo
         sync2d_search_band<NW>(w, s_base, sC, wvu, lane, i0, ia, ib);
         if (band == 1) SSTAMP1(6);
         if (!more) break;
-        __syncthreads();                                    // every wave has finished reading the image
-        // ---- slide the window: rows 32..43 become rows 0..11 (16 bytes per lane and move), then the prefetched lines fill rows 12..43
+        // ---- slide the window: rows 32..43 become rows 0..11 (16 bytes per lane and move), then the prefetched lines fill rows 12..43.
+        // The rows are only READ while any wave still searches, so this wave fetches its share of rows 32..43 as soon as its own bins are
+        // done; ONE barrier then says both "every wave has finished reading the image" and "rows 32..43 are in registers".
         constexpr int NMV = 12 * S2_PITCH / 4, MVT = (NMV + SYNCC_NT - 1) / SYNCC_NT;       // 1134 float4, 3 per lane
         static_assert((12 * S2_PITCH) % 4 == 0 && (SYNC_BAND * S2_PITCH) % 4 == 0, "16-byte moves");
         v4f mv[MVT];
@@ -1586,7 +1587,7 @@ __global__ __launch_bounds__(SYNCC_NT, 4) void ft8_sync_chan_kernel(const SyncWo
             const int e = tid + SYNCC_NT * q;
             mv[q] = (e < NMV) ? reinterpret_cast<const v4f *>(&s_s[SYNC_BAND][0])[e] : v4f{0.f, 0.f, 0.f, 0.f};
         }
-        __syncthreads();                                    // (rows 32..43 are also among the rows the prefetch overwrites)
+        __syncthreads();
 #pragma unroll
         for (int q = 0; q < MVT; ++q) {
             const int e = tid + SYNCC_NT * q;
