@@ -283,10 +283,11 @@ def main():
                      "verify": ver_x}
         # What actually bounds the exact kernel is not HBM but the un-fused arithmetic on the FP32 pipe: per pair of adjacent
         # outputs 33 steps x (16 taps x (multiply, add) x (Re, Im) + 4 for sum * phase) packed operations, each occupying a SIMD's 32 lanes
-        # for 4 cycles (MI355X_MICROARCH.md: a wave64 FP32 operation takes 2, a packed one is two of them).  Clock: the 2.1 GHz rocm-smi
-        # shows while this kernel runs (profiles/r2_power.txt) -- an assumption of this record, not a measurement of this run.
+        # for 4 cycles (MI355X_MICROARCH.md: a wave64 FP32 operation takes 2, a packed one is two of them).  Clock: the 1.95 GHz rocm-smi
+        # shows while this kernel runs, at 1356 W of the 1400 W package limit (profiles/r3_power.txt) -- an assumption of this record, not a
+        # measurement of this run.
         n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count or 256
-        pk_per_pair, clk_ghz = 33 * (16 * 2 * 2 + 4), 2.1
+        pk_per_pair, clk_ghz = 33 * (16 * 2 * 2 + 4), 1.95
         pipe_cycles = (spl / 16.0 / 2.0 / 64.0) * pk_per_pair * 4.0 / (n_cu * 4.0)
         bound_ms = pipe_cycles / (clk_ghz * 1e6)
         exact_rec["roofline"]["valu_pipe"] = {"bound": "fp32 vector pipe, un-fused packed arithmetic", "packed_ops_per_output_pair": pk_per_pair,
