@@ -4,20 +4,29 @@
 A "step" is one pass of the whole hot path over one batch of synthetic input: every FT8 slot
 (channel) owned by this rank demodulates one complete 15 s slot (2 880 000 complex samples at
 192 kHz, private stream per slot), the slot boundary fires, every frame is peak-normalised and
-rounded to int16 [and, once enabled, the FT8 sync stage runs on every frame].  Inputs are resident
+rounded to int16 and the FT8 sync stage runs on every frame.  Inputs are resident
 in HBM before the timed region (each receiver's ring holds a full slot, filled by the device-side
 synthetic source; the timed region re-commits it lap after lap without copying).
+
+Headline = the PRODUCT DEFAULT: the mode cwslg_create() hands out -- reference-order float32 arithmetic ("exact"), frames and candidate
+lists bit-identical to the reference chain's.  On one GPU the throughput mode (cwslg_set_exact(ctx, 0): fused polyphase form, audio within
+1e-5 of frame peak) is measured right after it on the same slots and reported as the "fast" record of the same JSON line.  --fast swaps
+the two; --primary-only skips the second record.
 
 Workload.  The north-star single-GPU workload -- 4096 FT8 slots resident on ONE MI355X (94 GB of IQ + 20 GB of frames,
 checkpoints and spectra) -- PER GPU at every N: the per-GPU work is fixed as N grows ("weak"; N = 8 carries 32 768 slots).
 --slots overrides it (--slots 512 at N = 8 is BASELINE configs[3], the north star's 4096 slots sharded over eight GPUs).
 
-One process per GPU.  N>1 is launched by torch.distributed.run; slots shard across ranks
-(slot s of rank r is global slot r*S+s) with no data-path collective; the only collective is one
+One process per GPU.  `python bench.py --gpus N` with N > 1 and no RANK in the environment LAUNCHES the N ranks itself: the parent --
+before it imports torch or touches a GPU -- starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+--master-port P bench.py <same arguments>` as a child process and exits with its status (never an exec from a process that has initialised
+the GPU).  Launched by torch.distributed.run directly (RANK / WORLD_SIZE set) it is a rank; WORLD_SIZE != --gpus is an error.
+Slots shard across ranks (slot s of rank r is global slot r*S+s) with no data-path collective; the only collective is one
 32-byte-per-rank all-gather on RCCL at every slot boundary (the north_star's "barrier on the mode's slot
 boundary"), issued from INSIDE cwslg_slot_boundary_end by the library's own communicator (cwslg_rccl_init;
 --rendezvous torch hands torch.distributed in through cwslg_set_boundary_rendezvous instead), one boundary late so that it
-overlaps the next slot's demod launch.  value = all ranks' samples / max-over-ranks time.
+overlaps the next slot's demod launch.  value = all ranks' samples / max-over-ranks time.  --dry-run exercises the launcher and the
+process group on CPU (gloo) without a GPU context.
 
 Prints ONE JSON line on rank 0.
 """
@@ -81,33 +90,100 @@ def slot_freq(gs):
     return -90000 + (gs * 4373) % 176000
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks (one per GPU); N > 1 without RANK in the environment launches them through torch.distributed.run")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--slots", type=int, default=0, help="FT8 slots per GPU (default: 4096 = the north-star workload, at every N; 512 at N = 8 is configs[3])")
     ap.add_argument("--sync", type=int, default=1, help="run the FT8 sync stage (symbol spectra + Costas search) at every boundary")
     ap.add_argument("--channels-per-rx", type=int, default=1,
-                    help="1 = private IQ stream per slot (BASELINE configs); C>1 = the reference's topology, C decoders share one receiver's IQ (<=8)")
-    ap.add_argument("--exact", action="store_true", help="headline record in the product's default mode: reference-order arithmetic (cwslg_set_exact(ctx, 1)), bit-identical")
-    ap.add_argument("--fast-only", action="store_true", help="skip the second (exact-mode) record")
+                    help="1 = private IQ stream per slot (BASELINE configs); C>1 = the reference's topology, C decoders share one receiver's IQ "
+                         "(CWSL: up to 32 receivers, CWSL_Utils.hpp:9; 128 per receiver makes the north star's 4096 channels)")
+    ap.add_argument("--fast", action="store_true", help="headline record in the throughput mode (cwslg_set_exact(ctx, 0)); the product default becomes the second record")
+    ap.add_argument("--exact", action="store_true", help="(the default since round 4) headline record in the product's default mode: reference-order arithmetic, bit-identical")
+    ap.add_argument("--primary-only", action="store_true", help="skip the second record (the other arithmetic mode)")
+    ap.add_argument("--fast-only", action="store_true", help="= --fast --primary-only")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (CPU tensors; for checking the N>1 path on a 1-GPU box)")
     ap.add_argument("--same-device", action="store_true", help="testing only: every rank uses GPU 0")
     ap.add_argument("--rendezvous", default="auto", choices=["auto", "builtin", "torch"],
                     help="N > 1: the slot-boundary rendezvous inside cwslg_slot_boundary_end -- builtin = the library's own RCCL all-gather "
                          "(cwslg_rccl_init; no Python inside the boundary), torch = a torch.distributed all-reduce handed in as a callback; "
                          "auto = builtin on the nccl backend with one GPU per rank, torch otherwise (gloo, --same-device: RCCL refuses two ranks on one GPU)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / process-group check without a GPU: every rank joins a gloo group, rank 0 prints the line's skeleton")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline wall time")
     ap.add_argument("--verify", type=int, default=8, help="slots (spread over the whole range) checked against the oracle after the timed region")
     ap.add_argument("--no-spans", action="store_true", help="diagnostic: no HIP timing events around the kernels (roofline fields are then empty)")
     ap.add_argument("--host-timing", action="store_true", help="print the host time spent inside each asynchronous call of a step (stderr)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.fast_only:
+        args.fast, args.primary_only = True, True
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    return args
 
-    rank = int(os.environ.get("RANK", "0"))
+
+def launch_ranks(args, argv):
+    """The parent of an N > 1 run: nothing GPU- or torch-related has been imported.  Starts torch.distributed.run as a CHILD process (one rank
+    per GPU, rendezvous on 127.0.0.1) and returns its exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                       # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, rank, world):
+    """No GPU: the ranks join a gloo group on 127.0.0.1, agree on the world size and rank 0 prints the line's skeleton."""
+    import torch
+    import torch.distributed as dist
+    from cwsl_digi_amd import shard
+    S = args.slots if args.slots > 0 else 4096
+    seen = world
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.tensor([1], dtype=torch.int64)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        every = [None] * world
+        dist.all_gather_object(every, list(shard.slots_of_rank(S * world, rank, world))[:1])
+        assert [e[0] for e in every] == [r * S for r in range(world)], every
+        dist.barrier()
+    assert seen == world == args.gpus
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "dry_run": True, "ranks_seen": seen, "scaling": "weak", "config": {"workload": f"dry run: {S} FT8 slots/GPU x {world} ranks, no GPU work"}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+METRIC = "IQ Msamples/s demod+sync per GPU; concurrent FT8 slots at real-time; % HBM roofline"
+MODE_TEXT = {True: "exact: the product default (cwslg_create); reference-order un-fused float32, frames and candidate lists bit-identical to the reference chain",
+             False: "fast: fused polyphase arithmetic (cwslg_set_exact(ctx, 0)), float audio within 1e-5 of frame peak"}
+
+
+def main():
+    args = parse_args()
+    env_rank, env_world = os.environ.get("RANK"), os.environ.get("WORLD_SIZE")
+    if env_rank is None and env_world is None:
+        if args.gpus > 1:                               # the parent: launch the ranks, exit with their status -- before torch / HIP is touched
+            sys.exit(launch_ranks(args, sys.argv[1:]))
+    rank = int(env_rank or "0")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
+    if world != args.gpus:
+        print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: launch with --nproc-per-node {args.gpus} (or drop RANK/WORLD_SIZE and let "
+              f"bench.py --gpus {args.gpus} launch the ranks itself)", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_run:
+        return dry_run(args, rank, world)
 
     import torch                          # first: its libamdhip64 must be the process's HIP runtime
     import torch.distributed as dist
@@ -139,17 +215,17 @@ def main():
             ctx.rccl_init(box[0], rank, world)
         else:
             shard.install_rendezvous(ctx, dev)  # cwslg_slot_boundary[_end] ends in torch.distributed's all-reduce (callback form)
+    SYNC_ARGS = (1.5, 200, 200, 3000)                  # jt9 -8 defaults used by the reference: syncmin 1.5, 200..3000 Hz (-H highestdecodefreq)
     if args.sync:
-        ctx.enable_sync(True, 1.5, 200, 200, 3000)    # jt9 -8 defaults used by the reference: syncmin 1.5, 200..3000 Hz (-H highestdecodefreq)
+        ctx.enable_sync(True, *SYNC_ARGS)
     ring_blocks = SLOT_SAMPLES // IQ_LEN + 2 + (SLOT_SAMPLES % IQ_LEN != 0)
     cap = ring_blocks * IQ_LEN
     chans, rxs, freqs = [], [], []
     t_setup = time.time()
     my_slots = list(shard.slots_of_rank(S * world, rank, world))     # contiguous block partition, no data-path collective
     assert len(my_slots) == S and my_slots[0] == rank * S
-    C = max(1, min(8, args.channels_per_rx))
-    assert S % C == 0
-    rx_meta = []
+    C = max(1, args.channels_per_rx)
+    assert S % C == 0, "--slots must be a multiple of --channels-per-rx"
     for r in range(S // C):
         group = my_slots[r * C:(r + 1) * C]
         fl = [slot_freq(gs) for gs in group]
@@ -157,7 +233,7 @@ def main():
         if C == 1:
             tones = [fl[0] + 600.0 + 37.0 * (gs0 % 11), fl[0] + 1500.0, fl[0] + 2450.0 - 13.0 * (gs0 % 7)]
         else:
-            tones = [f + 1500.0 for f in fl]
+            tones = [f + 1500.0 for f in fl[:8]]       # the synthetic source carries up to eight tones: the first eight channels get one each
         rx = ctx.receiver_open(FS, IQ_LEN, 0, ring_blocks=ring_blocks)
         half = cap // 2
         ctx.push_synth(rx, 0xC0FFEE ^ gs0, half, IQ_LEN, tones_hz=tones, amp=2.0e4)   # fill the ring (no channel yet)
@@ -169,7 +245,6 @@ def main():
     ctx.synchronize()
     t_setup = time.time() - t_setup
 
-
     host_t = []                                        # --host-timing: seconds the host spends inside each (asynchronous) call
     def step(k):
         a = time.perf_counter()
@@ -179,7 +254,7 @@ def main():
         c_ = time.perf_counter()
         if world > 1:
             # the rendezvous of the PREVIOUS boundary runs now, while this slot's demod launch (queued just above) keeps the GPU
-            # busy: wait for that boundary's kernels, all-reduce the frame count over RCCL; then queue this boundary's work
+            # busy: wait for that boundary's kernels, all-gather the frame count over RCCL; then queue this boundary's work
             ctx.slot_boundary_end()
             ctx.slot_boundary_begin("FT8", 15 * (k + 2))
         else:
@@ -202,7 +277,7 @@ def main():
             step(laps[0]); laps[0] += 1
         barrier()
         ctx.reset_stats()
-        ctx.set_timing(not args.no_spans)     # HIP events on the context stream around every kernel
+        ctx.set_timing(not args.no_spans)     # HIP events on the context stream around every kernel (+ the in-kernel clock of exact-mode launches)
         del host_t[:]
         t0 = time.perf_counter()
         for k in range(args.steps):
@@ -217,7 +292,7 @@ def main():
         if world > 1:
             assert st_["rendezvous_calls"] == args.steps and st_["rendezvous_frames"] == S * world, st_
             if rendezvous == "builtin":
-                assert st_["rccl_world"] == world, st_
+                assert st_["rccl_world"] == world == args.gpus, st_
             every = [None] * world
             dist.all_gather_object(every, dt_)
             st_["rank_ms_per_step"] = [d / args.steps * 1e3 for d in every]
@@ -257,69 +332,9 @@ def main():
             sys.exit(2)
         return v
 
-    # The headline record is the mode --exact / --fast selects (default: the throughput mode, cwslg_set_exact(ctx, 0)); with neither flag
-    # on one GPU the product's DEFAULT mode -- reference-order arithmetic, bit-identical frames and candidate lists -- is measured
-    # right after it on the same slots, sync stage included, and reported as the "exact" record of the same JSON line.
-    primary_exact = bool(args.exact)
-    dt, st, kernel_name = timed_region(primary_exact)
-    verify = verify_against_oracle(primary_exact)
-    exact_rec = None
-    if not args.exact and not args.fast_only and world == 1:
-        dt_x, st_x, kname_x = timed_region(True)
-        ver_x = verify_against_oracle(True)
-        lx = max(1, st_x["demod_launches"])
-        ax = st_x["demod_ms"] / lx
-        spl = S * SLOT_SAMPLES
-        bps_x = 8.0 / max(1, min(8, args.channels_per_rx)) + 4.0 / 16
-        ach_x = bps_x * spl / (ax * 1e-3) / 1e9 if ax > 0 else 0.0
-        exact_rec = {"mode": "exact: the product default (cwslg_create); reference-order un-fused float32, frames and candidate lists bit-identical to the reference chain",
-                     "value": float(S) * SLOT_SAMPLES * args.steps / dt_x / 1e6, "unit": "Msamples/s", "steps": args.steps, "warmup": args.warmup,
-                     "ms_per_step": dt_x / args.steps * 1e3,
-                     "roofline": {"bound": "hbm", "kernel": kname_x, "avg_launch_ms": ax, "achieved": ach_x, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": ach_x / HBM_PEAK_GBS, "bytes_per_sample": bps_x, "samples_per_launch": spl, "launches": st_x["demod_launches"]},
-                     "whole_path_frac": BYTES_PER_SAMPLE_PATH * spl * args.steps / dt_x / 1e9 / HBM_PEAK_GBS,
-                     "finalize_avg_ms": st_x["finalize_ms"] / max(1, st_x["finalize_launches"]),
-                     "sync_avg_ms": st_x["sync_ms"] / max(1, st_x["sync_launches"]),
-                     "verify": ver_x}
-        # What actually bounds the exact kernel is not HBM but the un-fused arithmetic on the FP32 pipe: per pair of adjacent
-        # outputs 33 steps x (16 taps x (multiply, add) x (Re, Im) + 4 for sum * phase) packed operations, each occupying a SIMD's 32 lanes
-        # for 4 cycles (MI355X_MICROARCH.md: a wave64 FP32 operation takes 2, a packed one is two of them).  Clock: the 1.95 GHz rocm-smi
-        # shows while this kernel runs, at 1356 W of the 1400 W package limit (profiles/r3_power.txt) -- an assumption of this record, not a
-        # measurement of this run.
-        n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count or 256
-        pk_per_pair, clk_ghz = 33 * (16 * 2 * 2 + 4), 1.95
-        pipe_cycles = (spl / 16.0 / 2.0 / 64.0) * pk_per_pair * 4.0 / (n_cu * 4.0)
-        bound_ms = pipe_cycles / (clk_ghz * 1e6)
-        exact_rec["roofline"]["valu_pipe"] = {"bound": "fp32 vector pipe, un-fused packed arithmetic", "packed_ops_per_output_pair": pk_per_pair,
-                                              "cycles_per_packed_op": 4, "assumed_clock_ghz": clk_ghz, "bound_ms": bound_ms,
-                                              "frac": bound_ms / ax if ax > 0 else 0.0}
-
-    total_samples = float(world) * S * SLOT_SAMPLES * args.steps
-    msps = total_samples / dt / 1e6
-
-    def roofline_sync(st_):
-        """The FT8 sync stage (symbol spectra + Costas search + candidate selection) against the FP32 vector peak: it is VALU-bound
-        (AI ~ 1e2 flop/B on its compulsory traffic, SURVEY.md 8d).  Flops are the algorithm's (counted above), time is HIP events
-        around the stage's launches; the bytes the stage moves through the fabric are replayed from the committed PMC summary."""
-        if not args.sync or not st_["sync_launches"]:
-            return None
-        nbins, nsearch = 992, 897                     # jt9 -8 defaults: bins 64..960 searched, rows of 992 bins stored
-        per_slot, per_transform = sync_flops_per_slot(nbins, nsearch)
-        ms = st_["sync_ms"] / st_["sync_launches"]
-        tfl = per_slot * S / (ms * 1e-3) / 1e12
-        fabric, src = None, None
-        tp = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
-        if os.path.isfile(tp):
-            try:
-                for tj in json.load(open(tp)).get("sync_runs", []):
-                    if tj.get("slots") == S:
-                        fabric, src = tj.get("fabric_bytes_per_boundary"), "replayed: " + tj.get("source", "")
-            except Exception:
-                pass
-        return {"bound": "valu", "kernels": "symbol_spectra_v2_kernel + ft8_sync_chan_kernel",
-                "avg_ms": ms, "transforms": 372 * S, "flop_per_transform": per_transform, "flop_per_slot": per_slot,
-                "achieved_tflops": tfl, "peak_tflops": VALU_PEAK_TFLOPS, "frac": tfl / VALU_PEAK_TFLOPS,
-                "algorithmic_bytes": S * (240000 * 2 + 200 * 20), "fabric_bytes": fabric, "fabric_source": src}
+    n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count or 256
+    spl = S * SLOT_SAMPLES                             # complex input samples per demod launch (channel-samples: one per channel and sample)
+    bps = 8.0 / C + 4.0 / 16                           # IQ is fetched once per receiver, audio written per channel
 
     def replay_traffic(kname):
         """HBM bytes per launch of `kname` at this slot count from the committed PMC summary (latest matching entry), or (None, None)."""
@@ -334,7 +349,85 @@ def main():
                 t_, src_ = None, None
         return t_, src_
 
-    # ---- CPU baseline: the oracle in the reference's shape, on this box's host cores (rank 0, N=1 only)
+    def sync_geometry():
+        """Search range and row pitch of the FT8 sync stage as cwslg_enable_sync derives them from the configured range (sync_host.inc), and the
+        kernels the boundary launches at this channel count."""
+        df = 12000.0 / 3840.0
+        ia = max(1, int(round(SYNC_ARGS[2] / df)))
+        ib = min(int(round(SYNC_ARGS[3] / df)), 1920 - 12)
+        nbins = (ib + 13 + 31) // 32 * 32
+        per_channel = S >= 2 * n_cu                   # sync_host.inc: one workgroup per channel once the chip's workgroup slots are filled
+        return nbins, ib - ia + 1, ("symbol_spectra_v2_kernel + ft8_sync_chan_kernel" if per_channel else
+                                    "symbol_spectra_v2_kernel + ft8_sync2d_v3_kernel + ft8_candidates_kernel")
+
+    def roofline_sync(st_):
+        """The FT8 sync stage (symbol spectra + Costas search + candidate selection) against the FP32 vector peak: it is VALU-bound
+        (AI ~ 1e2 flop/B on its compulsory traffic, SURVEY.md 8d).  Flops are the algorithm's (counted above), time is HIP events
+        around the stage's launches; the bytes the stage moves through the fabric are replayed from the committed PMC summary."""
+        if not args.sync or not st_["sync_launches"]:
+            return None
+        nbins, nsearch, kernels = sync_geometry()
+        per_slot, per_transform = sync_flops_per_slot(nbins, nsearch)
+        ms = st_["sync_ms"] / st_["sync_launches"]
+        tfl = per_slot * S / (ms * 1e-3) / 1e12
+        fabric, src = None, None
+        tp = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
+        if os.path.isfile(tp):
+            try:
+                for tj in json.load(open(tp)).get("sync_runs", []):
+                    if tj.get("slots") == S:
+                        fabric, src = tj.get("fabric_bytes_per_boundary"), "replayed: " + tj.get("source", "")
+            except Exception:
+                pass
+        return {"bound": "valu", "kernels": kernels, "nbins_stored": nbins, "bins_searched": nsearch,
+                "avg_ms": ms, "transforms": 372 * S, "flop_per_transform": per_transform, "flop_per_slot": per_slot,
+                "achieved_tflops": tfl, "peak_tflops": VALU_PEAK_TFLOPS, "frac": tfl / VALU_PEAK_TFLOPS,
+                "algorithmic_bytes": S * (240000 * 2 + 200 * 20), "fabric_bytes": fabric, "fabric_source": src}
+
+    def record(exact, dt_, st_, kname, ver):
+        """One arithmetic mode's record: whole-job rate + the roofline object of its demod kernel."""
+        launches = max(1, st_["demod_launches"])
+        avg_ms = st_["demod_ms"] / launches
+        achieved = bps * spl / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic, traffic_source = replay_traffic(kname)
+        roof = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": traffic_source, "bytes_per_sample": bps, "samples_per_launch": spl,
+                "avg_launch_ms": avg_ms, "launches": st_["demod_launches"],
+                "finalize_avg_ms": st_["finalize_ms"] / max(1, st_["finalize_launches"]),
+                "sync_avg_ms": st_["sync_ms"] / max(1, st_["sync_launches"]),
+                "whole_path_frac": BYTES_PER_SAMPLE_PATH * spl * args.steps / dt_ / 1e9 / HBM_PEAK_GBS}
+        if exact:
+            # What bounds the exact kernel is not HBM but its un-fused arithmetic on the FP32 pipe (DESIGN.md 4.1b): per pair of adjacent outputs
+            # 33 steps x (16 taps x (multiply, add) x (Re, Im) + 4 for sum * phase) packed operations, each occupying its SIMD's vector pipe for 4
+            # cycles (MI355X_MICROARCH.md: one wave's VALU instruction issues every 4 cycles; SQ_ACTIVE_INST_VALU = 1 quad-cycle per instruction in
+            # profiles/r3_pmc_summary_bench4096.txt).  Clock: MEASURED inside the timed launches -- delta s_memtime / delta s_memrealtime x 100 MHz
+            # read by one workgroup at the start and the end of its life (cwslg_stats.demod_clock_mhz; MI355X_MICROARCH.md, DVFS item 6).
+            pk_per_pair = 33 * (16 * 2 * 2 + 4)
+            clk_mhz = float(st_.get("demod_clock_mhz", 0.0))
+            pipe_cycles = (spl / 16.0 / 2.0 / 64.0) * pk_per_pair * 4.0 / (n_cu * 4.0)
+            vp = {"bound": "fp32 vector pipe, un-fused packed arithmetic", "packed_ops_per_output_pair": pk_per_pair, "cycles_per_packed_op": 4,
+                  "clock_mhz": clk_mhz or None, "clock_source": f"in-kernel s_memtime / s_memrealtime over {int(st_.get('demod_clock_launches', 0))} timed launches",
+                  "bound_ms": None, "frac": None}
+            if clk_mhz > 0 and avg_ms > 0:
+                vp["bound_ms"] = pipe_cycles / (clk_mhz * 1e3)
+                vp["frac"] = vp["bound_ms"] / avg_ms
+            roof["valu_pipe"] = vp
+        else:
+            roof["valu_tflops"] = 80.0 * spl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        return {"mode": MODE_TEXT[exact], "value": float(world) * spl * args.steps / dt_ / 1e6, "unit": "Msamples/s", "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": dt_ / args.steps * 1e3, "roofline": roof, "roofline_sync": roofline_sync(st_), "verify": ver}
+
+    # The headline record is the product default (exact) unless --fast; on one GPU the other mode is measured right after it on the same slots.
+    primary_exact = not args.fast
+    dt, st, kernel_name = timed_region(primary_exact)
+    verify = verify_against_oracle(primary_exact)
+    second = None
+    if not args.primary_only and world == 1:
+        dt2, st2, kname2 = timed_region(not primary_exact)
+        ver2 = verify_against_oracle(not primary_exact)
+        second = (not primary_exact, dt2, st2, kname2, ver2)
+
+    # ---- CPU baseline: the reference's own code in the reference's shape, on this box's host cores (rank 0, N=1 only)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
@@ -343,8 +436,7 @@ def main():
         if O.have_ref():
             # kind "reference": the reference's own SSBD<float>/LowPass code (oracle/_ref, compiled from its headers)
             fn, kind = O.bench_cpu_reference, "reference"
-            what = "reference SSBD.hpp/LowPass.hpp compiled -O2 -ffp-contract=off (Iterate loop + per-slot SSBD construction; " \
-                   "prepareAudio/int16, <2% of the path, not included)"
+            what = "reference SSBD.hpp/LowPass.hpp compiled -O2 -ffp-contract=off (Iterate loop + per-slot SSBD construction)"
         else:
             fn, kind = O.bench_cpu, "port"
             what = "oracle/cwsl_oracle.c -O2 -ffp-contract=off (whole path incl. prepareAudio + int16)"
@@ -356,52 +448,56 @@ def main():
                "sample": f"{cores} channels x {slots_each} FT8 slots (2.88 M IQ samples each) on {cores} threads, {what}; "
                          f"single thread: {2 * n_eff / t1 / 1e6:.1f} Msamples/s; host CPU: {cpu_model()}, "
                          f"{len(os.sched_getaffinity(0))} logical CPUs visible, {cores} usable under the cgroup quota"}
+        if kind == "reference" and hasattr(O, "bench_cpu_finalize"):
+            # the rest of the path -- prepareAudio + int16 (Instance.cpp:294-338, 238-241), which needs <windows.h> to compile as the reference's
+            # own code -- as the oracle's restatement, timed on the same threads and folded into a whole-path figure
+            tf = O.bench_cpu_finalize(cores, max(4, slots_each))
+            per_slot_demod = tN / slots_each
+            per_slot_fin = tf / max(4, slots_each)
+            cpu["whole_path_value"] = cores * n_eff / (per_slot_demod + per_slot_fin) / 1e6
+            cpu["finalize_share"] = per_slot_fin / (per_slot_demod + per_slot_fin)
+            cpu["sample"] += f"; whole_path_value adds prepareAudio + int16 (oracle restatement of Instance.cpp:294-338,238-241; {100 * cpu['finalize_share']:.1f}% of the path)"
 
     if rank == 0:
-        launches = max(1, st["demod_launches"])
-        avg_ms = st["demod_ms"] / launches
-        samples_per_launch = S * SLOT_SAMPLES
-        bps = 8.0 / C + 4.0 / 16                      # IQ is fetched once per receiver, audio written per channel
-        achieved = bps * samples_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # HBM traffic cannot be counted from inside the process (PMC counters need rocprofv3): the figure is REPLAYED
-        # from the committed PMC summary of this same command and slot count, and labelled so
-        traffic, traffic_source = replay_traffic(kernel_name)
-        if exact_rec is not None:
-            exact_rec["roofline"]["traffic"], exact_rec["roofline"]["traffic_source"] = replay_traffic(exact_rec["roofline"]["kernel"])
+        rec = record(primary_exact, dt, st, kernel_name, verify)
+        if world > 1:
+            assert rec["value"] > 0 and world == args.gpus
+        topo = ("private IQ stream per slot " if C == 1 else f"{C} slots share each receiver's IQ (reference topology, {S // C} receivers) ")
         out = {
-            "metric": "IQ Msamples/s demod+sync per GPU; concurrent FT8 slots at real-time; % HBM roofline",
-            "value": msps, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "metric": METRIC,
+            "value": rec["value"], "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": rec["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{S} FT8 slots/GPU x 15 s (2.88 M IQ samples) at 192 kHz, " + ("private IQ stream per slot " if C == 1 else f"{C} slots share each receiver's IQ (reference topology) ") +
+            "config": {"workload": f"{S} FT8 slots/GPU x 15 s (2.88 M IQ samples) at 192 kHz, " + topo +
                                    ("(north_star: 4096 concurrent FT8 slots on ONE MI355X, all inputs resident in HBM)" if S == 4096 and world == 1 else
                                     f"(the north-star workload per GPU, x{world} GPUs: weak scaling)" if S == 4096 else
                                     "(BASELINE configs[3]: 4096 slots sharded 512 per GPU)" if S == 512 else "(--slots override)"),
                        "slots_per_gpu": S, "channels_per_receiver": C, "fs_hz": FS, "iq_block": IQ_LEN, "stages": "nco-mix+polyphase-decimate, peak-normalise+int16" + (", ft8 symbol-spectra+costas-sync+candidates" if args.sync else ""),
-                       "sharding": (f"slots x{world}, no data-path collective; per slot boundary one 24-byte-per-rank RCCL all-gather inside cwslg_slot_boundary_end "
+                       "sharding": (f"slots x{world}, no data-path collective; per slot boundary one 32-byte-per-rank RCCL all-gather inside cwslg_slot_boundary_end "
                                     f"(built-in rendezvous, cwslg_rccl_init)" if rendezvous == "builtin" else
                                     f"slots x{world}, no data-path collective; per slot boundary one 8-byte {args.dist_backend} all-reduce called back from "
                                     f"cwslg_slot_boundary_end (torch.distributed)") if world > 1 else "single GPU"},
-            "realtime_ft8_slots": msps / 0.192,
+            "mode": rec["mode"],
+            "realtime_ft8_slots": rec["value"] / 0.192,
             "multi_gpu": None if world == 1 else {"rendezvous": rendezvous, "rccl_world": int(st.get("rccl_world", 0)),
                                                   "rendezvous_calls": int(st["rendezvous_calls"]), "rendezvous_frames": int(st["rendezvous_frames"]),
                                                   "rank_ms_per_step_min": min(st["rank_ms_per_step"]), "rank_ms_per_step_max": max(st["rank_ms_per_step"])},
-            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "bytes_per_sample": bps, "samples_per_launch": samples_per_launch,
-                         "valu_tflops": 80.0 * samples_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0,
-                         "avg_launch_ms": avg_ms, "launches": st["demod_launches"],
-                         "finalize_avg_ms": st["finalize_ms"] / max(1, st["finalize_launches"]),
-                         "sync_avg_ms": st["sync_ms"] / max(1, st["sync_launches"]),
-                         "whole_path_frac": BYTES_PER_SAMPLE_PATH * samples_per_launch * args.steps / dt / 1e9 / HBM_PEAK_GBS},
-            "roofline_sync": roofline_sync(st),
-            "mode": ("exact: reference-order arithmetic, bit-identical (the product default)" if args.exact else
-                     "fast: fused polyphase arithmetic (cwslg_set_exact(ctx, 0)), float audio within 1e-5 of frame peak"),
-            "exact": exact_rec,
-            "cpu_baseline": cpu,
-            "verify": verify,
-            "setup_s": t_setup,
+            "roofline": rec["roofline"],
+            "roofline_sync": rec["roofline_sync"],
+            "verify": rec["verify"],
         }
+        if C > 1:
+            # with shared receivers the compulsory bytes collapse and the kernel is FP32-bound -- report it as achieved TFLOP/s of
+            # useful work (80 flop per channel-sample: 6 for the mix amortised + 32 real MACs + Weaver sign; the reference spends ~340)
+            avg_ms = rec["roofline"]["avg_launch_ms"]
+            out["shared_topology"] = {"receivers": S // C, "channels_per_receiver": C, "channel_samples_per_launch": spl,
+                                      "useful_flop_per_channel_sample": 80, "achieved_tflops": 80.0 * spl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else None,
+                                      "peak_tflops": VALU_PEAK_TFLOPS, "channel_msamples_per_s": rec["value"]}
+        if second is not None:
+            r2 = record(*second)
+            out["exact" if second[0] else "fast"] = r2
+        out["cpu_baseline"] = cpu
+        out["setup_s"] = t_setup
         print(json.dumps(out))
     ctx.close()
     if world > 1:

@@ -104,7 +104,9 @@ class Stats(C.Structure):
                 ("frames_discarded", C.c_uint64), ("blocks_dropped", C.c_uint64),
                 ("h2d_bytes", C.c_uint64), ("demod_ms", C.c_double), ("finalize_ms", C.c_double),
                 ("sync_ms", C.c_double), ("phasor_regrows", C.c_uint64), ("rendezvous_calls", C.c_uint64),
-                ("rendezvous_frames", C.c_uint64), ("rccl_world", C.c_uint64), ("rendezvous_flags_and", C.c_uint64)]
+                ("rendezvous_frames", C.c_uint64), ("rccl_world", C.c_uint64), ("rendezvous_flags_and", C.c_uint64),
+                ("demod_clock_mhz", C.c_double), ("demod_clock_launches", C.c_uint64), ("push_calls", C.c_uint64),
+                ("push_batches", C.c_uint64), ("push_host_ms", C.c_double)]
 
 
 # int (*)(void *user, int group, uint64_t epoch_s, uint64_t frames_local, uint64_t *frames_total)
@@ -115,7 +117,7 @@ _lib = None
 # every symbol include/cwsl_gpu.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = [
     "cwslg_abi_version", "cwslg_create", "cwslg_destroy", "cwslg_strerror", "cwslg_last_error",
-    "cwslg_set_scale_factors", "cwslg_set_exact", "cwslg_receiver_open", "cwslg_receiver_close", "cwslg_push_iq",
+    "cwslg_set_scale_factors", "cwslg_set_exact", "cwslg_receiver_open", "cwslg_receiver_close", "cwslg_push_iq", "cwslg_push_iq_many",
     "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_parse_decoder_line", "cwslg_channel_open_line", "cwslg_channel_open", "cwslg_channel_close", "cwslg_channel_tune", "cwslg_channel_tune_ex",
     "cwslg_channel_info", "cwslg_process", "cwslg_slot_boundary", "cwslg_slot_boundary_begin", "cwslg_slot_boundary_end", "cwslg_slot_boundary_channel",
     "cwslg_set_boundary_rendezvous", "cwslg_set_rendezvous_flag", "cwslg_rccl_unique_id", "cwslg_rccl_init",
@@ -174,6 +176,7 @@ def load_library(build_if_missing=True):
     L.cwslg_receiver_open.argtypes = [vp, u32, u32, C.c_int32, u32, C.POINTER(i32)]
     L.cwslg_receiver_close.argtypes = [vp, i32]
     L.cwslg_push_iq.argtypes = [vp, i32, vp, u32]
+    L.cwslg_push_iq_many.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(vp), u32]
     L.cwslg_push_iq_device.argtypes = [vp, i32, vp, u32]
     L.cwslg_push_synth.argtypes = [vp, i32, u64, u32, u32, vp, i32, f32]
     L.cwslg_ring_commit.argtypes = [vp, i32, u32, u32]
@@ -340,6 +343,16 @@ class Context:
         """iq: complex64[n] host array (one or more Receiver blocks)."""
         iq = np.ascontiguousarray(iq, dtype=np.complex64)
         self._chk(self.L.cwslg_push_iq(self.h, rx, iq.ctypes.data, iq.shape[0]))
+
+    def push_iq_many(self, rxs, blocks):
+        """One block per receiver in ONE call (cwslg_push_iq_many): rxs = receiver ids, blocks = complex64 arrays of one common length
+        (or one 2-D array, row k for rxs[k])."""
+        arrs = [np.ascontiguousarray(b, dtype=np.complex64) for b in blocks]
+        n = arrs[0].shape[0]
+        assert len(arrs) == len(rxs) and all(a.shape == (n,) for a in arrs)
+        ids = (C.c_int * len(rxs))(*[int(r) for r in rxs])
+        ptrs = (C.c_void_p * len(rxs))(*[a.ctypes.data for a in arrs])
+        self._chk(self.L.cwslg_push_iq_many(self.h, len(rxs), ids, ptrs, n))
 
     def push_iq_device(self, rx, dptr, n_complex):
         self._chk(self.L.cwslg_push_iq_device(self.h, rx, C.c_void_p(dptr), n_complex))

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cctype>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -53,19 +54,24 @@ constexpr int kTileExact2 = 248;       // ... of demod_exact2_kernel, lab build 
 constexpr int kDemodThreads = 256;
 constexpr int kFinThreads = 256;
 constexpr int kCkptStride = cwslg::kCk;   // blocks between phasor checkpoints
-constexpr size_t kStageHalf = 4u << 20;    // pinned staging PER RECEIVER: two halves of 4 MiB, allocated at the receiver's first host push
+// Pinned staging PER RECEIVER: two halves, allocated at the receiver's first host push and sized by it -- four of that push, between 64 KiB and
+// 4 MiB per half (round 3 gave every receiver 2 x 4 MiB: 32 GiB of pinned memory for 4096 private streams; a real-time receiver pushes one
+// 16 KiB block at a time and gets 2 x 64 KiB) -- and grown when a larger push arrives.
+constexpr size_t kStageHalfMin = 64u << 10, kStageHalfMax = 4u << 20;
 constexpr int kWorkBufs = 8;
 // Events that only order device work or tell the host that a descriptor buffer is free again: no system-scope fence (a fenced event
 // behind the last sync kernel of a slot cost a 0.3 ms L2 write-back before the next launch could start).  Host-visible RESULTS are
 // always fetched behind hipStreamSynchronize, which fences.
 constexpr unsigned kOrderEvent = hipEventDisableTiming | hipEventDisableSystemFence;
 constexpr int kCopyStreams = 4;
+constexpr unsigned kClkSlots = 1024;      // timed exact-mode demod launches between two drains of the spans
 
 // Host-push staging of one receiver.  The reference has one thread per Receiver (Receiver.hpp:167); each of them gets its own
 // pinned double buffer here, filled OUTSIDE the context mutex, so that pushes of different receivers copy in parallel.
 struct RxStage {
     std::mutex mu;                     // one push at a time per receiver
-    char *h = nullptr;                 // 2 * kStageHalf, pinned
+    char *h = nullptr;                 // 2 * half, pinned
+    size_t half = 0;                   // bytes per half
     size_t pos = 0;
     hipEvent_t ev[2] = {nullptr, nullptr};
     bool busy[2] = {false, false};
@@ -75,6 +81,18 @@ struct RxStage {
         for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
     }
 };
+
+// cwslg_push_iq_many: one pinned buffer per concurrent batch pusher -- [n descriptors][n blocks] -- read by ONE scatter kernel.
+constexpr int kBatchStages = 4;
+struct BatchStage {
+    std::mutex mu;
+    char *h = nullptr;                 // pinned, host-mapped
+    void *h_dev = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ev = nullptr;           // behind the scatter kernel that reads the buffer
+    bool busy = false;
+};
+struct ScatterDesc { float2 *ring; unsigned pos, cap; };     // 16 bytes: where receiver k's block goes
 
 struct Receiver {
     bool open = false;
@@ -216,6 +234,14 @@ struct cwslg_ctx {
     bool copies_pending[kCopyStreams] = {};
     bool copy_on_main = true;          // H2D copies on the compute stream: measured 30 GB/s from one pusher thread against 21-28 GB/s on
                                        // the dedicated copy streams (CWSLG_COPY_ON_MAIN=0 selects those: copies then overlap the kernels)
+    BatchStage batch[kBatchStages];
+    std::atomic<unsigned> batch_next{0};
+    // in-kernel clock of timed exact-mode demod launches: a host-mapped ring of (s_memtime, s_memrealtime) pairs at the start and the end of
+    // one workgroup's life (demod_exact3_kernel's `clk`), read back by drain_spans
+    unsigned long long *clk_h = nullptr, *clk_dev = nullptr;
+    unsigned clk_head = 0, clk_tail = 0;
+    double clk_sum_mhz = 0.0;
+    int occ_cache[3][4] = {};          // launch_demod: resident demod_exact3 workgroups per CU by (D, tile form); per context = per device
     // launch descriptors
     WorkBuf wb[kWorkBufs];
     int wb_next = 0;
@@ -242,7 +268,7 @@ struct cwslg_ctx {
     cwslg_rendezvous_fn rdv_fn = nullptr;
     void *rdv_user = nullptr;
     ncclComm_t rccl_comm = nullptr;
-    uint64_t *d_rdv = nullptr, *h_rdv = nullptr;   // [3]: this rank's (frames, group, epoch), then [world][3]: every rank's
+    uint64_t *d_rdv = nullptr, *h_rdv = nullptr;   // [4]: this rank's (frames, group, epoch, flag) = 32 bytes, then [world][4]: every rank's
     int rccl_world = 0;
     std::atomic<uint64_t> rdv_flag{0}, rdv_flags_and{0};   // cwslg_set_rendezvous_flag; AND over the ranks at the last built-in rendezvous
     // cwslg_slot_boundary_begin / _end: the rendezvous of a boundary whose device work is queued but not yet waited for
@@ -315,6 +341,19 @@ __global__ void upload_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n16) dst[i] = src[i];
 }
+// cwslg_push_iq_many: block k of a batch (n_pairs x 16 bytes, read straight from the host-mapped staging buffer over the host link) goes
+// to ring k at its write position, wrapping at the ring's end.  grid (ceil(n_pairs / 256), receivers): every wave-level access is one
+// contiguous 1 KiB run on both sides (positions and capacities are multiples of 4 D samples, so a 16-byte pair never straddles the wrap).
+__global__ __launch_bounds__(256) void scatter_blocks_kernel(const ScatterDesc *__restrict__ desc, const uint4 *__restrict__ src, unsigned n_pairs)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_pairs) return;
+    const ScatterDesc d = desc[blockIdx.y];
+    const uint4 v = src[(size_t)blockIdx.y * n_pairs + i];
+    unsigned idx = d.pos + 2u * i;
+    if (idx >= d.cap) idx -= d.cap;
+    reinterpret_cast<uint4 *>(d.ring)[idx >> 1] = v;
+}
 hipError_t upload_workbuf(cwslg_ctx *c, WorkBuf *w, size_t bytes)
 {
     if (!w->h_dev || c->upload_by_dma) return hipMemcpyAsync(w->d, w->h, bytes, hipMemcpyHostToDevice, c->stream);
@@ -375,6 +414,14 @@ void drain_spans(cwslg_ctx *c)
         c->ev_pool.push_back({s.a, s.b});
     }
     c->spans.clear();
+    for (; c->clk_tail != c->clk_head; ++c->clk_tail) {
+        const unsigned long long *q = c->clk_h + 4 * (c->clk_tail % kClkSlots);
+        if (q[0] && q[1] && q[2] > q[0] && q[3] > q[1] + 1000) {       // >= 10 us of the 100 MHz counter: a quotient worth having
+            c->clk_sum_mhz += 100.0 * (double)(q[2] - q[0]) / (double)(q[3] - q[1]);
+            c->stats.demod_clock_launches++;
+            c->stats.demod_clock_mhz = c->clk_sum_mhz / (double)c->stats.demod_clock_launches;
+        }
+    }
 }
 
 int ensure_taps(cwslg_ctx *c, uint32_t fs)
@@ -590,17 +637,22 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
             const long long slots = std::max<long long>(1, (long long)c->cu_count * occ / 8);     // resident workgroups per XCD
             const int run_len = (int)std::min<long long>(8, std::max<long long>(1, per_xcd / slots));  // items per draw
             const long long wgs = 8 * std::min(slots, (per_xcd + run_len - 1) / run_len);
+            unsigned long long *clk = nullptr;
+            if (c->timing && c->clk_dev && c->clk_head - c->clk_tail < kClkSlots) {
+                const unsigned slot = c->clk_head++ % kClkSlots;
+                std::memset(c->clk_h + 4 * slot, 0, 4 * sizeof(unsigned long long));
+                clk = c->clk_dev + 4 * slot;
+            }
             hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(nt), 0, c->stream, (const ChanWork *)w->d, (const float *)c->d_taps2[fs],
-                               tiles_x, (int)works.size(), (unsigned *)((char *)w->d + ctr_off), run_len);
+                               tiles_x, (int)works.size(), (unsigned *)((char *)w->d + ctr_off), run_len, clk);
         };
-        static int occ_cache[3][3] = {};                    // resident workgroups per CU, by D and tile form (asked once)
+        int (&occ_cache)[3][4] = c->occ_cache;              // resident workgroups per CU on THIS device, by D and tile form (asked once; guarded by c->mu)
         const int di = D == 16 ? 0 : D == 8 ? 1 : 2;
 #if CWSLG_LAB
         if (tile == 256) go(demod_exact3_kernel<D, 256, 128>, 128, occ_cache[di][1]);
         else if (tile == 128) go(demod_exact3_kernel<D, 128, 64>, 64, occ_cache[di][2]);
         else if (c->demod_variant == 25) {                   // the FIR as C++ with hand-issued 8-byte loads (round 3's first form; same bits)
-            static int occ25[3] = {};
-            go(demod_exact3_kernel<D, kTileExact, kExactThreads, false>, kExactThreads, occ25[di]);
+            go(demod_exact3_kernel<D, kTileExact, kExactThreads, false>, kExactThreads, occ_cache[di][3]);
         } else
 #endif
         go(demod_exact3_kernel<D, kTileExact, kExactThreads>, kExactThreads, occ_cache[di][0]);
@@ -931,6 +983,19 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s,
     return CWSLG_OK;
 }
 
+// A failed rendezvous: the built-in form has already recorded WHAT failed (which rank was at which group / epoch) -- keep that text and
+// put the generic line in front of it; a callback's failure has no text of its own.
+int rendezvous_failed(cwslg_ctx *c, int rc)
+{
+    std::string inner;
+    {
+        std::lock_guard<std::mutex> g(c->err_mu);
+        if (c->last_error.rfind("slot-boundary rendezvous:", 0) == 0) inner = c->last_error;
+    }
+    if (!inner.empty()) return fail(c, rc, "slot-boundary rendezvous failed (%d): %s", rc, inner.c_str() + sizeof("slot-boundary rendezvous:"));
+    return fail(c, rc, "slot-boundary rendezvous failed (%d)", rc);
+}
+
 } // namespace
 
 // sync stage glue (kept in its own file so this one stays readable)
@@ -1054,6 +1119,11 @@ void cwslg_destroy(cwslg_ctx *c)
     sync_free_shared(c->sync_shared);
     long_free_shared(c->long_shared);
     if (c->d_sincos) hipFree(c->d_sincos);
+    if (c->clk_h) (void)hipHostFree(c->clk_h);
+    for (BatchStage &b : c->batch) {
+        if (b.h) (void)hipHostFree(b.h);
+        if (b.ev) (void)hipEventDestroy(b.ev);
+    }
     for (int k = 0; k < kCopyStreams; ++k) {
         if (c->copy_stream[k]) { hipStreamSynchronize(c->copy_stream[k]); hipStreamDestroy(c->copy_stream[k]); }
         if (c->copy_done[k]) hipEventDestroy(c->copy_done[k]);
@@ -1102,7 +1172,7 @@ int cwslg_receiver_open(cwslg_ctx *c, uint32_t fs, uint32_t iq_len, int32_t lo_h
     rx.fs = fs; rx.iq_len = iq_len; rx.lo_hz = lo_hz; rx.D = D;
     const uint64_t blocks = ring_blocks ? ring_blocks : (uint64_t)(fs / iq_len + 1) * 3;   // Receiver.hpp:132
     uint64_t cap = blocks * iq_len;
-    const uint64_t min_cap = 2ull * (D * (kTile + 31)) + 64;       // the tile loader wraps at most once
+    const uint64_t min_cap = 2ull * (D * (kTileMax + 31)) + 64;    // the tile loader wraps at most once (whatever tile the mode's kernel walks: kTileMax)
     if (cap < min_cap) cap = (min_cap + iq_len - 1) / iq_len * iq_len;
     if (cap > 0xFFFFFFF0ull) return fail(c, CWSLG_ERR_ARG, "ring too large");
     rx.cap = (uint32_t)cap;
@@ -1169,12 +1239,18 @@ int cwslg_push_iq(cwslg_ctx *c, int rx_id, const float *iq, uint32_t n)
         stage = r.stage;
     }
     std::lock_guard<std::mutex> gp(stage->mu);            // the reference has ONE thread per Receiver; a second pusher waits here
+    const auto t_in = std::chrono::steady_clock::now();
     uint32_t done = 0;
     while (done < n) {
         const uint32_t m = std::min(piece, n - done);
         int rc = push_iq_piece(c, rx_id, iq + 2 * (size_t)done, m);
         if (rc) return rc;
         done += m;
+    }
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        c->stats.push_calls++;
+        c->stats.push_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count();
     }
     return CWSLG_OK;
 }
@@ -1199,11 +1275,25 @@ static int push_iq_piece(cwslg_ctx *c, int rx_id, const float *iq, uint32_t n)
     }
     RxStage &st = *stage;
     hipSetDevice(c->device);
-    if (!st.h) {
-        if (hipHostMalloc((void **)&st.h, 2 * kStageHalf, hipHostMallocDefault) != hipSuccess) return fail(c, CWSLG_ERR_NOMEM, "staging allocation failed");
-        hipEventCreateWithFlags(&st.ev[0], hipEventDisableTiming);
-        hipEventCreateWithFlags(&st.ev[1], hipEventDisableTiming);
+    {
+        size_t want = kStageHalfMin;
+        while (want < kStageHalfMax && want < 4 * (size_t)n * sizeof(float2)) want <<= 1;
+        if (want > st.half) {              // first push, or a larger one than any before: (re)allocate once the copies in flight have drained
+            for (int k = 0; k < 2; ++k)
+                if (st.busy[k]) { HIPCHK(c, hipEventSynchronize(st.ev[k])); st.busy[k] = false; }
+            if (st.h) {                    // copies of segments that never left a half carry no event: drain the stream they were queued on
+                HIPCHK(c, hipStreamSynchronize(c->copy_on_main ? c->stream : c->copy_stream[rx_id % kCopyStreams]));
+                (void)hipHostFree(st.h);
+                st.h = nullptr;
+            }
+            if (hipHostMalloc((void **)&st.h, 2 * want, hipHostMallocDefault) != hipSuccess) { st.half = 0; return fail(c, CWSLG_ERR_NOMEM, "staging allocation failed"); }
+            st.half = want;
+            st.pos = 0;
+            if (!st.ev[0]) hipEventCreateWithFlags(&st.ev[0], hipEventDisableTiming);
+            if (!st.ev[1]) hipEventCreateWithFlags(&st.ev[1], hipEventDisableTiming);
+        }
     }
+    const size_t kStageHalf = st.half;
     struct Seg { size_t stage_off; uint32_t ring_pos, count; int leaves_half; };
     std::vector<Seg> segs;
     uint32_t done = 0;
@@ -1270,6 +1360,83 @@ int cwslg_push_iq_device(cwslg_ctx *c, int rx_id, const void *d_iq, uint32_t n)
         done += m;
     }
     account_push(c, *rx, n, rx->iq_len);
+    return CWSLG_OK;
+}
+
+// One block for each of n_rx receivers in ONE call: the batched form of Receiver::readIQ's per-block memcpy + inc_write_index
+// (Receiver.hpp:242-249) for a host that serves thousands of streams.  Three steps like cwslg_push_iq -- (1) under the context mutex make room
+// in every ring and read the write positions; (2) with no context lock, copy the callers' blocks into one pinned, host-mapped staging
+// buffer; (3) under the mutex again, ONE kernel scatters the batch into the rings and the samples are accounted to the channels -- so a
+// batch costs two mutex acquisitions and one launch whatever n_rx is (4096 private streams through cwslg_push_iq: 8192 and 4096 copies).
+int cwslg_push_iq_many(cwslg_ctx *c, int n_rx, const int *rx_ids, const float *const *iq, uint32_t n)
+{
+    if (!c || n_rx <= 0 || !rx_ids || !iq) return CWSLG_ERR_ARG;
+    const auto t_in = std::chrono::steady_clock::now();
+    std::vector<ScatterDesc> desc((size_t)n_rx);
+    std::vector<uint64_t> total0((size_t)n_rx);
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        hipSetDevice(c->device);
+        std::vector<char> seen(c->rxs.size(), 0);
+        for (int k = 0; k < n_rx; ++k) {
+            const int id = rx_ids[k];
+            if (id < 0 || id >= (int)c->rxs.size() || !c->rxs[id].open) return fail(c, CWSLG_ERR_ARG, "cwslg_push_iq_many: bad receiver id %d", id);
+            if (seen[id]) return fail(c, CWSLG_ERR_ARG, "cwslg_push_iq_many: receiver %d appears twice in one batch", id);
+            seen[id] = 1;
+            if (!iq[k]) return fail(c, CWSLG_ERR_ARG, "cwslg_push_iq_many: null block for receiver %d", id);
+            Receiver *rx = nullptr;
+            int rc = push_prologue(c, id, n, &rx);          // block-length check + room in the ring (may launch pending demodulation)
+            if (rc) return rc;
+            desc[k] = ScatterDesc{rx->d_ring, (unsigned)(rx->total % rx->cap), rx->cap};
+            total0[k] = rx->total;
+        }
+    }
+    // a staging buffer nobody else is filling (several threads may push disjoint batches side by side)
+    BatchStage *bs = nullptr;
+    std::unique_lock<std::mutex> hold;
+    for (int tries = 0; tries < kBatchStages && !bs; ++tries) {
+        BatchStage &cand = c->batch[(c->batch_next.fetch_add(1) + 0u) % kBatchStages];
+        std::unique_lock<std::mutex> l(cand.mu, std::try_to_lock);
+        if (l.owns_lock()) { bs = &cand; hold = std::move(l); }
+    }
+    if (!bs) { bs = &c->batch[c->batch_next.fetch_add(1) % kBatchStages]; hold = std::unique_lock<std::mutex>(bs->mu); }
+    hipSetDevice(c->device);
+    const size_t desc_bytes = ((size_t)n_rx * sizeof(ScatterDesc) + 255) & ~size_t(255);
+    const size_t block_bytes = (size_t)n * sizeof(float2);
+    const size_t need = desc_bytes + (size_t)n_rx * block_bytes;
+    if (bs->busy) { HIPCHK(c, hipEventSynchronize(bs->ev)); bs->busy = false; }
+    if (bs->bytes < need) {
+        if (bs->h) { (void)hipHostFree(bs->h); bs->h = nullptr; bs->bytes = 0; }
+        const size_t nb = (need + (1u << 20) - 1) & ~size_t((1u << 20) - 1);
+        if (hipHostMalloc((void **)&bs->h, nb, hipHostMallocDefault) != hipSuccess) return fail(c, CWSLG_ERR_NOMEM, "batch staging allocation failed (%zu bytes)", nb);
+        if (hipHostGetDevicePointer(&bs->h_dev, bs->h, 0) != hipSuccess) return fail(c, CWSLG_ERR_HIP, "batch staging is not device-mapped");
+        bs->bytes = nb;
+        if (!bs->ev) hipEventCreateWithFlags(&bs->ev, hipEventDisableTiming);
+    }
+    std::memcpy(bs->h, desc.data(), (size_t)n_rx * sizeof(ScatterDesc));
+    for (int k = 0; k < n_rx; ++k) std::memcpy(bs->h + desc_bytes + (size_t)k * block_bytes, iq[k], block_bytes);
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        for (int k = 0; k < n_rx; ++k) {
+            const int id = rx_ids[k];
+            if (id >= (int)c->rxs.size() || !c->rxs[id].open || c->rxs[id].d_ring != desc[k].ring || c->rxs[id].total != total0[k])
+                return fail(c, CWSLG_ERR_ARG, "cwslg_push_iq_many: receiver %d was closed or pushed by another thread during the batch", id);
+        }
+        const unsigned n_pairs = n / 2;
+        hipLaunchKernelGGL(scatter_blocks_kernel, dim3((n_pairs + 255) / 256, (unsigned)n_rx), dim3(256), 0, c->stream,
+                           (const ScatterDesc *)bs->h_dev, (const uint4 *)((const char *)bs->h_dev + desc_bytes), n_pairs);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(bs->ev, c->stream));
+        bs->busy = true;
+        for (int k = 0; k < n_rx; ++k) {
+            Receiver &rx = c->rxs[rx_ids[k]];
+            account_push(c, rx, n, rx.iq_len);
+        }
+        c->stats.h2d_bytes += (uint64_t)n_rx * block_bytes;
+        c->stats.push_calls += (uint64_t)n_rx;
+        c->stats.push_batches++;
+        c->stats.push_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count();
+    }
     return CWSLG_OK;
 }
 
@@ -1680,7 +1847,7 @@ int cwslg_slot_boundary(cwslg_ctx *c, int group, uint64_t epoch_s)
     uint64_t total = mine;                                  // ... and after the rendezvous so are every other GPU's
     const int rc = fn(user, group, epoch_s, mine, &total);
     std::lock_guard<std::mutex> g(c->mu);
-    if (rc < 0) return fail(c, rc, "slot-boundary rendezvous failed (%d)", rc);
+    if (rc < 0) return rendezvous_failed(c, rc);
     c->stats.rendezvous_calls++;
     c->stats.rendezvous_frames = total;
     c->stats.rendezvous_flags_and = c->rccl_comm ? c->rdv_flags_and.load() : c->rdv_flag.load();
@@ -1733,7 +1900,7 @@ int cwslg_slot_boundary_end(cwslg_ctx *c)
     uint64_t total = mine;                                      // ... and after the rendezvous so are every other GPU's
     const int rc = fn(user, group, epoch, mine, &total);
     std::lock_guard<std::mutex> g(c->mu);
-    if (rc < 0) return fail(c, rc, "slot-boundary rendezvous failed (%d)", rc);
+    if (rc < 0) return rendezvous_failed(c, rc);
     c->stats.rendezvous_calls++;
     c->stats.rendezvous_frames = total;
     c->stats.rendezvous_flags_and = c->rccl_comm ? c->rdv_flags_and.load() : c->rdv_flag.load();
@@ -1944,6 +2111,7 @@ int cwslg_reset_stats(cwslg_ctx *c)
     std::lock_guard<std::mutex> g(c->mu);
     c->stats = cwslg_stats{};
     c->stats.rccl_world = (uint64_t)c->rccl_world;
+    c->clk_sum_mhz = 0.0;
     return CWSLG_OK;
 }
 
@@ -1959,6 +2127,17 @@ int cwslg_set_timing(cwslg_ctx *c, int enable)
     if (!c) return CWSLG_ERR_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     c->timing = enable != 0;
+    if (c->timing && !c->clk_h) {          // the host-mapped ring the timed exact-mode launches write their clock counters to
+        hipSetDevice(c->device);
+        void *h = nullptr, *d = nullptr;
+        if (hipHostMalloc(&h, kClkSlots * 4 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess &&
+            hipHostGetDevicePointer(&d, h, 0) == hipSuccess) {
+            c->clk_h = (unsigned long long *)h;
+            c->clk_dev = (unsigned long long *)d;
+        } else if (h) {
+            (void)hipHostFree(h);
+        }
+    }
     return CWSLG_OK;
 }
 

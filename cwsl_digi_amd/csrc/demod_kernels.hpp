@@ -407,6 +407,11 @@ __device__ __forceinline__ void decode_item(const ChanWork *sd, int tile, TileCt
     const long long c0 = (qlo >= 0) ? (qlo / kCk) : -((kCk - 1 - qlo) / kCk);     // floor(qlo/kCk)
     c.ck_first = (int)c0;
     c.pb0 = (int)(c0 * kCk - qlo);                                              // in (-kCk, 0]
+    // A tile past the channel's own pending blocks (the launch's tile count comes from the channel with the MOST pending blocks): nothing
+    // is computed for it, but the persistent kernels issue an item's loads before they look at n_out.  Its positions above are
+    // meaningless -- `b` may lie beyond one wrap of a SMALLER ring, the checkpoint index beyond this channel's table -- so point the
+    // loads at the start of the ring and of the table, which always exist (cap >= 2 NSAMP, cwslg_receiver_open; tables hold >= NCK + 4).
+    if (c.n_out == 0) { c.base = 0; c.ck_first = 0; c.pb0 = 0; c.first_valid = 0; }
 }
 
 template <int D, int T, int NT>
@@ -1714,7 +1719,8 @@ __device__ __forceinline__ void exact3_steps(std::integer_sequence<int, Ps...>, 
 template <int D, int T, int NT, bool ASMFIR = true>
 __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__restrict__ works,
                                                               const float *__restrict__ taps2,
-                                                              int tiles_x, int n_ch, unsigned *__restrict__ xcd_next, int run_len)
+                                                              int tiles_x, int n_ch, unsigned *__restrict__ xcd_next, int run_len,
+                                                              unsigned long long *__restrict__ clk)
 {
     using Geo = DemodGeom<D, T>;
     constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
@@ -1761,17 +1767,29 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
     // one draw = a run of run_len consecutive items, chosen by the launch (same-address atomics retire at about one per 100 ns: a
     // draw per tile would bound large launches; small ones use shorter runs so that every CU gets work)
     const int kRun = run_len;
-    __shared__ int s_draw;
+    __shared__ int s_draw[2];          // by draw parity: the draw made during iteration k is read after that iteration's first barrier, while a
+                                       // slow wave may still be reading the previous one (run_len == 1: a draw per iteration)
     // (A start offset of half a tile for the CU's second workgroup -- the one in the odd wave slots -- was tried, to put one
     // workgroup's mix and barriers into the other's FIR: no change at 1, 2 or 3 x 8 k cycles.  The tile period is the same 19.8 k ticks
     // from the tenth tile of a run to the last: the workgroups de-phase by themselves, and the FIR is bound by what ONE wave can issue,
     // ~5 cycles per instruction, not by the pipe the two waves of a SIMD share -- scripts/micro/pk_latency.hip.)
     CWSLG_GLOBAL unsigned *ctr = as_global_rw(xcd_next) + xcd;
-    if (tid == 0) s_draw = (int)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) s_draw[0] = (int)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    int item = lo_item + kRun * (int)uni((unsigned)s_draw);
+    int item = lo_item + kRun * (int)uni((unsigned)s_draw[0]);
+    int draw_par = 1;                                        // the slot the next draw is written to
     if (item >= hi_item) return;
     int run_left = kRun - 1;                                 // items of the current run after `item`
+    // The shader clock this launch actually ran at (bench.py's roofline.valu_pipe; MI355X_MICROARCH.md, DVFS item 6: in-kernel clock =
+    // delta s_memtime / delta s_memrealtime x 100 MHz).  ONE workgroup of a timed launch (clk != nullptr: cwslg_set_timing) reads the two
+    // counters when it has drawn its first run and again when it leaves -- a persistent workgroup lives as long as the launch --
+    // and writes them to a host-mapped slot nothing on the device reads.  Untimed launches (clk == nullptr) execute none of it.
+    if (clk != nullptr && blockIdx.x == 0 && tid == 0) {
+        unsigned long long t_, r_;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");
+        as_global_rw(clk)[0] = t_;
+        as_global_rw(clk)[1] = r_;
+    }
     TileCtx<D, T> cur;
     int ich, itile;
     item_to_ch_tile(item, tiles_x, n_ch, ich, itile);
@@ -1833,11 +1851,12 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
         else mix(std::false_type{});
     }
     }   // cur.n_out > 0
-    if (run_left == 0 && tid == 0) s_draw = (int)draw;
+    if (run_left == 0 && tid == 0) s_draw[draw_par] = (int)draw;
     lds_barrier();                                           // the tile's LDS image is complete (every load it came from has been consumed)
     STAMP(3);
     // the next item of this workgroup: its IQ, checkpoint and tone loads fly while the FIR below runs (xs, ck, tn are free now)
-    const int nitem = run_left ? item + 1 : lo_item + kRun * (int)uni((unsigned)s_draw);
+    const int nitem = run_left ? item + 1 : lo_item + kRun * (int)uni((unsigned)s_draw[draw_par]);
+    if (run_left == 0) draw_par ^= 1;
     run_left = run_left ? run_left - 1 : kRun - 1;
     const bool has_next = nitem < hi_item;                   // workgroup-uniform
     TileCtx<D, T> nxt = cur;
@@ -1956,6 +1975,12 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
     STAMP(0); STAMP(1);
 #endif
 #endif
+    }
+    if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long t_, r_;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");
+        as_global_rw(clk)[2] = t_;
+        as_global_rw(clk)[3] = r_;
     }
 }
 

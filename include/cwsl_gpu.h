@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CWSLG_ABI_VERSION 3
+#define CWSLG_ABI_VERSION 4
 
 /* ---- status codes ---- */
 #define CWSLG_OK                  0
@@ -100,6 +100,16 @@ int cwslg_receiver_close(cwslg_ctx *ctx, int rx_id);
  * pop_no_wait()/Iterate() loops (Instance.cpp:265-276): called ONCE per block per receiver.  The host block
  * is only read during the call.  n_complex must be a multiple of 2*fs/6000 (SSBD::GetInSize). */
 int cwslg_push_iq(cwslg_ctx *ctx, int rx_id, const float *iq_interleaved, uint32_t n_complex);
+/* One block of n_complex samples for EACH of n_rx receivers in one call -- the batched form of the per-block memcpy + inc_write_index of
+ * Receiver::readIQ (Receiver.hpp:242-249) for a host that serves thousands of streams (the north star's 4096 private 192 kHz streams are
+ * 384 000 blocks a second: through cwslg_push_iq that is as many H2D copies and twice as many context-mutex acquisitions; through this
+ * call, with one batch per block period, 94 launches and 188 acquisitions).  iq[k] is receiver rx_ids[k]'s block (interleaved re, im; read
+ * only during the call); every receiver of a batch gets the same n_complex (a multiple of SSBD::GetInSize for each of them) and may appear
+ * once.  The blocks are copied into one pinned, host-mapped staging buffer (sized on demand) and ONE kernel scatters them into the rings;
+ * frame-overflow accounting is per receiver with its own iq_len, exactly as n_rx calls of cwslg_push_iq would do it.  Thread safety: several
+ * threads may push disjoint batches concurrently; a receiver must not be pushed from two threads at once (the reference has one thread per
+ * Receiver, Receiver.hpp:167) -- detected and refused with CWSLG_ERR_ARG, nothing accounted. */
+int cwslg_push_iq_many(cwslg_ctx *ctx, int n_rx, const int *rx_ids, const float *const *iq_interleaved, uint32_t n_complex);
 /* Same, source already in device memory (tests, device-side producers). */
 int cwslg_push_iq_device(cwslg_ctx *ctx, int rx_id, const void *d_iq_interleaved, uint32_t n_complex);
 /* Synthetic IQ source standing in for CW Skimmer's shared memory (SharedMemory.cpp is Win32-only):
@@ -191,8 +201,8 @@ int cwslg_synchronize(cwslg_ctx *ctx);
  * not call back into the same context.  Return 0 or a negative CWSLG_ERR_*; the total is kept in the stats. */
 typedef int (*cwslg_rendezvous_fn)(void *user, int group, uint64_t epoch_s, uint64_t frames_local, uint64_t *frames_total);
 int cwslg_set_boundary_rendezvous(cwslg_ctx *ctx, cwslg_rendezvous_fn fn, void *user);
-/* Built-in rendezvous (C/C++ hosts; bench.py's default for N > 1): ONE all-gather of 24 bytes per rank on RCCL over xGMI -- (frames,
- * group, epoch) -- enqueued on the context's SIDE stream (the context stream may already hold the next slot's demodulation): every
+/* Built-in rendezvous (C/C++ hosts; bench.py's default for N > 1): ONE all-gather of 32 bytes per rank on RCCL over xGMI -- (frames,
+ * group, epoch, flag) -- enqueued on the context's SIDE stream (the context stream may already hold the next slot's demodulation): every
  * rank sums the frames and checks that all ranks are at the same group and epoch; a mismatch fails the boundary on every rank with
  * CWSLG_ERR_ARG.  librccl is opened on first use (a process that already carries one, e.g. torch's, shares it).
  * cwslg_rccl_unique_id fills the 128-byte ncclUniqueId on rank 0; the host program hands it to the other ranks by any
@@ -360,6 +370,14 @@ typedef struct {
     uint64_t rendezvous_frames;    /* frames over ALL processes at the last rendezvous                    */
     uint64_t rccl_world;           /* ranks of the built-in RCCL communicator (cwslg_rccl_init), 0 without one */
     uint64_t rendezvous_flags_and; /* AND over all ranks of cwslg_set_rendezvous_flag's value at the last built-in rendezvous */
+    /* ABI 4 */
+    double   demod_clock_mhz;      /* shader clock INSIDE the timed exact-mode demod launches since the last reset: mean over launches of
+                                    * delta s_memtime / delta s_memrealtime x 100 MHz, read by one workgroup at the start and the end of its
+                                    * life (0 until a timed launch has been drained).  What bench.py prices roofline.valu_pipe at.        */
+    uint64_t demod_clock_launches; /* launches that contributed to it                                                                 */
+    uint64_t push_calls;           /* host pushes accepted (cwslg_push_iq: one per call; cwslg_push_iq_many: one per receiver)         */
+    uint64_t push_batches;         /* cwslg_push_iq_many calls                                                                        */
+    double   push_host_ms;         /* wall time spent inside host pushes (staging copy + enqueue), summed over the calling threads      */
 } cwslg_stats;
 int cwslg_get_stats(cwslg_ctx *ctx, cwslg_stats *out);
 int cwslg_reset_stats(cwslg_ctx *ctx);

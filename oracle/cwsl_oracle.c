@@ -471,3 +471,40 @@ double orc_bench_cpu(int threads, int slots, uint64_t fs, uint32_t iq_len, uint6
     if (bad) return -1.0;
     return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
 }
+
+/* The rest of the path for bench.py's whole-path CPU figure: prepareAudio + int16 (Instance.cpp:294-338, 238-241) plus the frame memset of
+ * the slot swap (:213) on `threads` threads, `reps` FT8 frames each; returns wall seconds.  (These lines sit inside Instance.cpp, which needs
+ * <windows.h>: they cannot be timed as the reference's own object code, so this is the restatement above.) */
+typedef struct { int reps; double checksum; } fin_job_t;
+static void *fin_worker(void *arg)
+{
+    fin_job_t *j = (fin_job_t *)arg;
+    const size_t n = orc_frame_len("FT8");
+    float *src = (float *)malloc(sizeof(float) * n), *buf = (float *)malloc(sizeof(float) * n);
+    int16_t *pcm = (int16_t *)malloc(sizeof(int16_t) * n);
+    for (size_t k = 0; k < n; ++k) src[k] = (k < 180000) ? (float)((int)((k * 2654435761u) >> 20 & 0xFFF) - 2048) * 7.5f : 0.0f;
+    double acc = 0.0;
+    for (int r = 0; r < j->reps; ++r) {
+        memcpy(buf, src, sizeof(float) * n);                    /* stands in for the frame the demodulator has just filled */
+        float f = orc_prepare_audio(buf, n, "FT8", 0.90f, 0.20f, NULL);
+        orc_to_int16(buf, n, pcm);
+        memset(buf, 0, sizeof(float) * n);                      /* :213 */
+        acc += f + pcm[1000 + (r & 255)];
+    }
+    j->checksum = acc;
+    free(src); free(buf); free(pcm);
+    return NULL;
+}
+double orc_bench_finalize(int threads, int reps)
+{
+    if (threads < 1 || threads > 1024 || reps < 1) return -1.0;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+    fin_job_t *jobs = (fin_job_t *)calloc((size_t)threads, sizeof(fin_job_t));
+    struct timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    for (int t = 0; t < threads; ++t) { jobs[t].reps = reps; pthread_create(&th[t], NULL, fin_worker, &jobs[t]); }
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    free(th); free(jobs);
+    return (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+}

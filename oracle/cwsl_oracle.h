@@ -126,6 +126,7 @@ void orc_synth_add_tones(uint64_t fs, uint64_t first_sample, uint64_t n_complex,
 /* CPU baseline ("port"): `threads` channels in parallel (one pthread each, the reference's
  * thread-per-Instance shape), `slots` FT8 slots of n_per_slot samples each; returns wall seconds. */
 double orc_bench_cpu(int threads, int slots, uint64_t fs, uint32_t iq_len, uint64_t n_per_slot);
+double orc_bench_finalize(int threads, int reps);
 
 /* position-weighted checksum used by fixtures: sum_k (1+(k%251)) * x[k] in double */
 double orc_checksum_f32(const float *x, size_t n);

@@ -537,6 +537,14 @@ def bench_cpu(threads, slots, fs=192000, iq_len=2048, n_per_slot=2880000):
     return float(lib().orc_bench_cpu(threads, slots, fs, iq_len, n_per_slot))
 
 
+def bench_cpu_finalize(threads, reps):
+    """Wall seconds of prepareAudio + int16 + the frame memset (Instance.cpp:294-338, 238-241, 213) for `threads` threads x `reps` FT8 frames."""
+    L = lib()
+    L.orc_bench_finalize.restype = C.c_double
+    L.orc_bench_finalize.argtypes = [C.c_int, C.c_int]
+    return float(L.orc_bench_finalize(int(threads), int(reps)))
+
+
 class _Cand(C.Structure):
     _fields_ = [("freq_bin", C.c_int32), ("time_step", C.c_int32), ("sync", C.c_float),
                 ("freq_hz", C.c_float), ("dt_s", C.c_float)]

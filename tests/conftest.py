@@ -51,8 +51,8 @@ def assert_frames_match(gpu_f32, ref_f32, tol=1e-5):
     reference's bits."""
     if _STATE["exact"]:
         a, b = np.asarray(gpu_f32, np.float32), np.asarray(ref_f32, np.float32)
-        n = min(len(a), len(b))
-        assert np.array_equal(a[:n].view(np.uint32), b[:n].view(np.uint32)), "exact mode: float frame differs from the reference's bits"
+        assert len(a) == len(b), f"exact mode: frame lengths differ ({len(a)} vs {len(b)})"
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "exact mode: float frame differs from the reference's bits"
         return 0.0
     peak = float(np.abs(ref_f32).max())
     err = float(np.abs(gpu_f32.astype(np.float64) - ref_f32.astype(np.float64)).max())

@@ -54,3 +54,33 @@ def test_single_process_rendezvous_is_identity():
     from cwsl_digi_amd import shard
     assert shard.slot_boundary_rendezvous(7) == 7
     assert list(shard.slots_of_rank(10, 0, 1)) == list(range(10))
+
+
+def _bench(*argv, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` from a plain shell: the parent starts two ranks through torch.distributed.run (before it imports
+    torch), they form a process group on 127.0.0.1, and rank 0's line says n_gpus = 2 (--dry-run: gloo, no GPU context)."""
+    import json
+    p = _bench("--gpus", "2", "--dry-run", "--slots", "64")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "torch.distributed.run" in p.stderr and "--nproc-per-node=2" in p.stderr
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["dry_run"] is True
+    p1 = _bench("--dry-run")                                         # N = 1: no launcher, same process
+    assert p1.returncode == 0 and "torch.distributed.run" not in p1.stderr
+    assert json.loads(p1.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    p = _bench("--gpus", "2", "--dry-run", env_extra={"RANK": "0", "WORLD_SIZE": "4", "LOCAL_RANK": "0"})
+    assert p.returncode == 2 and "WORLD_SIZE=4 but --gpus 2" in p.stderr
+    p = _bench("--gpus", "1", "--dry-run", env_extra={"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
+    assert p.returncode == 2

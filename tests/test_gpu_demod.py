@@ -294,3 +294,40 @@ def test_measured_alternative_kernels_live_in_the_lab_library(variant, mode):
     r = subprocess.run([sys.executable, os.path.join(here, "lab_variant_check.py"), mode], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "lab check OK" in r.stdout
+
+
+def test_ragged_launch_small_ring_beside_full_slot(ctx, oracle):
+    """Two receivers of one sample rate in ONE launch: A has the smallest ring the library hands out and one block pending, B a ring of
+    a whole slot with a whole slot pending.  The launch's tile count comes from B, so A's descriptor is drawn with tile indices far
+    beyond its own range (n_out == 0): those items must touch neither A's small ring beyond its end nor A's checkpoint table beyond
+    its length (round 3: the persistent kernels issued such an item's loads from the meaningless positions).  Both frames are
+    checked against the oracle; the process must survive."""
+    fa, fb = -26000, 40000
+    nb = 1400 * IQ_LEN                                         # ~15 s: 5600 tiles of 512 outputs on B
+    iq_a = oracle.synth_iq(5, 2 * IQ_LEN, FS, tones_hz=_tones(fa), amp=2.0e4)
+    iq_b = oracle.synth_iq(6, IQ_LEN + nb, FS, tones_hz=_tones(fb), amp=2.0e4)
+    rx_a = ctx.receiver_open(FS, IQ_LEN, 0, ring_blocks=1)     # clamped up to the minimum ring (two tiles + slack)
+    rx_b = ctx.receiver_open(FS, IQ_LEN, 0, ring_blocks=nb // IQ_LEN + 8)
+    cap_a = ctx.ring_info(rx_a)[1]
+    assert cap_a < 40000, cap_a
+    ch_a = ctx.channel_open(rx_a, fa, "FT8")
+    ch_b = ctx.channel_open(rx_b, fb, "FT8")
+    oa, ob = oracle.Channel("FT8", FS, IQ_LEN, fa), oracle.Channel("FT8", FS, IQ_LEN, fb)
+    ctx.push_iq(rx_a, iq_a[:IQ_LEN]); oa.push_many(iq_a[:IQ_LEN])
+    ctx.push_iq(rx_b, iq_b[:IQ_LEN]); ob.push_many(iq_b[:IQ_LEN])
+    ctx.slot_boundary("FT8", 15); assert oa.boundary(15) is None and ob.boundary(15) is None
+    ctx.push_iq(rx_a, iq_a[IQ_LEN:]); oa.push_many(iq_a[IQ_LEN:])          # one block pending on A ...
+    for k in range(IQ_LEN, len(iq_b), 256 * IQ_LEN):                       # ... a whole slot on B (no process() in between)
+        ctx.push_iq(rx_b, iq_b[k:k + 256 * IQ_LEN])
+    ob.push_many(iq_b[IQ_LEN:])
+    before = ctx.stats()["demod_launches"]
+    ctx.process()                                                          # ONE launch for both
+    assert ctx.stats()["demod_launches"] == before + 1
+    ctx.slot_boundary("FT8", 30)
+    ra, rb = oa.boundary(30, want_f32=True), ob.boundary(30, want_f32=True)
+    for ch, r in ((ch_a, ra), (ch_b, rb)):
+        a, nv = ctx.fetch_audio_f32(ch)
+        g = ctx.fetch_frame(ch)
+        assert nv == (IQ_LEN // 16 if ch == ch_a else nb // 16)
+        assert_frames_match(a, r["f32"])
+        assert_int16_match(g["i16"], r["i16"], r["f32"] * r["factor"])

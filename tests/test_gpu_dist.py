@@ -123,3 +123,22 @@ def test_builtin_rccl_rendezvous_world_1():
         ctx.rccl_init(P.rccl_unique_id(), 0, 1)
         first2, st2, crcs2 = _run_slots(ctx, range(3), split=True)
         assert first2 == 0 and st2["rendezvous_calls"] == 2 and st2["rendezvous_frames"] == 3 and crcs2 == crcs
+
+
+def test_bench_py_gpus_2_launches_two_ranks_on_this_gpu():
+    """The driver's N > 1 entry, end to end through bench.py itself: `python bench.py --gpus 2 ...` from a plain shell launches two ranks
+    (torch.distributed.run, 127.0.0.1), each owns a real Context on the one GPU of the box (--same-device; gloo carries the rendezvous
+    because RCCL refuses two ranks on one device), and rank 0's line reports n_gpus = 2 with one rendezvous per step."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--same-device", "--dist-backend", "gloo", "--slots", "64",
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--verify", "2"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3
+    assert line["multi_gpu"]["rendezvous_calls"] == 3 and line["multi_gpu"]["rendezvous_frames"] == 128
+    assert line["mode"].startswith("exact") and line["verify"]["max_rel_err"] == 0.0 and line["verify"]["int16_mismatches"] == 0
+    assert line["value"] > 0 and line["config"]["slots_per_gpu"] == 64

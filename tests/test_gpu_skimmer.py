@@ -136,21 +136,28 @@ def test_skimmer_udp_source(tmp_path, oracle):
     iq = oracle.synth_iq(9, n, fs, tones_hz=[13000 + 1500.0], amp=1.0e4).astype(np.complex64)
     cfg = tmp_path / "config.ini"
     cfg.write_text("[decoders]\ndecoder=3573000 FT8\n")
-    out_dir = tmp_path / "out"; out_dir.mkdir()
-    port = 47000 + os.getpid() % 1000
     start_ms = 1_790_000_000_000 // 15000 * 15000 + 13_000
-    proc = subprocess.Popen([B.build_skimmer(), "--config", str(cfg), "--out", str(out_dir), "--start-ms", str(start_ms), "--exact",
-                             "--wav", "always", "--rx", f"udp={port},fs={fs},block={block},lo={lo},idle=2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    first = proc.stderr.readline()                                            # "ready: ..." once the context exists and the port is bound
-    assert first.startswith("ready"), first + proc.stderr.read()
-    s = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
-    for k in range(n // block):
-        s.sendto(iq[k * block:(k + 1) * block].tobytes(), ("127.0.0.1", port))
-        if k % 4 == 3:
-            time.sleep(0.001)                                                 # keep the loopback socket buffer from overflowing
-    out, err = proc.communicate(timeout=120)                                  # the 2 s receive timeout ends the run
-    assert proc.returncode == 0, (out, err)
-    summary = json.loads(out.strip().splitlines()[-1])
+    summary = None
+    for attempt in range(4):                                                  # loopback may drop datagrams under load: retry with slower pacing, then FAIL
+        out_dir = tmp_path / f"out{attempt}"; out_dir.mkdir()
+        port = 47000 + (os.getpid() + 17 * attempt) % 1000
+        proc = subprocess.Popen([B.build_skimmer(), "--config", str(cfg), "--out", str(out_dir), "--start-ms", str(start_ms), "--exact",
+                                 "--wav", "always", "--rx", f"udp={port},fs={fs},block={block},lo={lo},idle=2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        first = proc.stderr.readline()                                        # "ready: ..." once the context exists and the port is bound
+        assert first.startswith("ready"), first + proc.stderr.read()
+        s = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        every = max(1, 4 >> attempt)
+        for k in range(n // block):
+            s.sendto(iq[k * block:(k + 1) * block].tobytes(), ("127.0.0.1", port))
+            if k % every == every - 1:
+                time.sleep(0.001 * (1 + attempt))                             # keep the loopback socket buffer from overflowing
+        s.close()
+        out, err = proc.communicate(timeout=120)                              # the 2 s receive timeout ends the run
+        assert proc.returncode == 0, (out, err)
+        summary = json.loads(out.strip().splitlines()[-1])
+        if summary["pushed_samples"] == n:
+            break
+    assert summary["pushed_samples"] == n, f"loopback dropped datagrams in four attempts: {summary}"
     c = oracle.Channel("FT8", fs, block, 3_573_000 - lo)
     nxt = P.slot_clock_next("FT8", start_ms)
     expect = []
@@ -162,8 +169,6 @@ def test_skimmer_udp_source(tmp_path, oracle):
             if fr is not None:
                 expect.append(fr)
             nxt = P.slot_clock_next("FT8", nxt)
-    if summary["pushed_samples"] != n:
-        pytest.skip("loopback dropped datagrams on this box")
     assert summary["frames"] == len(expect) == 1
     _, pcm = _read_wav(out_dir / f"{expect[0]['t_start']}_3573000_FT8.wav")
     assert np.array_equal(pcm, expect[0]["i16"])
