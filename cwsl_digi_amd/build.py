@@ -16,6 +16,7 @@ LIB = os.path.join(LIBDIR, "libcwslgpu.so")
 LAB_LIB = os.path.join(LIBDIR, "libcwslgpu_lab.so")
 BINDIR = os.path.join(HERE, "bin")
 SKIMMER = os.path.join(BINDIR, "cwsl_gpu_skimmer")
+REALTIME = os.path.join(BINDIR, "cwsl_gpu_realtime")
 
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit __builtin_fmaf and every
 # bit-exact sequence (the float32 phasor recurrence, prepareAudio, the synthetic source) is plain * and +.
@@ -48,7 +49,7 @@ def _source_hash():
 
 
 def _stale():
-    if not os.path.isfile(LIB) or not os.path.isfile(LAB_LIB) or not os.path.isfile(SKIMMER) or not os.path.isfile(HASHFILE):
+    if not os.path.isfile(LIB) or not os.path.isfile(LAB_LIB) or not os.path.isfile(SKIMMER) or not os.path.isfile(REALTIME) or not os.path.isfile(HASHFILE):
         return True
     return open(HASHFILE).read().strip() != _source_hash()
 
@@ -95,17 +96,18 @@ def build(force=False, verbose=False):
 
 
 def build_skimmer(force=False, verbose=False):
-    """Compile the Linux host program (csrc/host/skimmer_main.cpp, plain C++17 over the C ABI) -> bin/cwsl_gpu_skimmer."""
-    src = os.path.join(CSRC, "host", "skimmer_main.cpp")
-    if not force and os.path.isfile(SKIMMER) and os.path.getmtime(SKIMMER) >= max(
-            os.path.getmtime(os.path.join(CSRC, "host", f)) for f in os.listdir(os.path.join(CSRC, "host"))):
+    """Compile the Linux host programs (plain C++17 over the C ABI): csrc/host/skimmer_main.cpp -> bin/cwsl_gpu_skimmer and
+    csrc/host/realtime_main.cpp -> bin/cwsl_gpu_realtime (the wall-clock-paced ingest harness)."""
+    newest = max(os.path.getmtime(os.path.join(CSRC, "host", f)) for f in os.listdir(os.path.join(CSRC, "host")))
+    if not force and all(os.path.isfile(b) and os.path.getmtime(b) >= newest for b in (SKIMMER, REALTIME)):
         return SKIMMER
     os.makedirs(BINDIR, exist_ok=True)
-    cmd = ["g++", "-std=c++17", "-O2", "-Wall", src, "-o", SKIMMER, "-L" + LIBDIR, "-lcwslgpu",
-           "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    for name, out in (("skimmer_main.cpp", SKIMMER), ("realtime_main.cpp", REALTIME)):
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", os.path.join(CSRC, "host", name), "-o", out, "-L" + LIBDIR, "-lcwslgpu",
+               "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath,/opt/rocm/lib", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return SKIMMER
 
 

@@ -21,6 +21,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -64,6 +65,7 @@ constexpr int kWorkBufs = 8;
 // always fetched behind hipStreamSynchronize, which fences.
 constexpr unsigned kOrderEvent = hipEventDisableTiming | hipEventDisableSystemFence;
 constexpr int kCopyStreams = 4;
+constexpr int kFetchStreams = 4;
 constexpr unsigned kClkSlots = 1024;      // timed exact-mode demod launches between two drains of the spans
 
 // Host-push staging of one receiver.  The reference has one thread per Receiver (Receiver.hpp:167); each of them gets its own
@@ -234,6 +236,13 @@ struct cwslg_ctx {
     bool copies_pending[kCopyStreams] = {};
     bool copy_on_main = true;          // H2D copies on the compute stream: measured 30 GB/s from one pusher thread against 21-28 GB/s on
                                        // the dedicated copy streams (CWSLG_COPY_ON_MAIN=0 selects those: copies then overlap the kernels)
+    // frames out: D2H copies of finalised frames run on their own streams behind ONE event recorded after the boundary's kernels (at the
+    // first fetch of a frame generation), with the context mutex released -- 4096 fetches do not serialise pushes, launches or each other
+    hipStream_t fetch_stream[kFetchStreams] = {};
+    hipEvent_t fetch_ev = nullptr;
+    bool fetch_ev_valid = false;
+    unsigned fetch_rr = 0;
+    std::shared_mutex life_mu;         // shared: a fetch's copy is in flight; exclusive: a close frees device buffers (order: mu, then life_mu)
     BatchStage batch[kBatchStages];
     std::atomic<unsigned> batch_next{0};
     // in-kernel clock of timed exact-mode demod launches: a host-mapped ring of (s_memtime, s_memrealtime) pairs at the start and the end of
@@ -401,10 +410,19 @@ hipError_t sync_streams(cwslg_ctx *c)
     if (c->side) { hipError_t e = hipStreamSynchronize(c->side); if (e != hipSuccess) return e; }
     return hipStreamSynchronize(c->stream);
 }
+// before device buffers are freed: no fetch may still be copying out of them (caller holds the context mutex)
+void wait_fetches(cwslg_ctx *c)
+{
+    std::unique_lock<std::shared_mutex> l(c->life_mu);
+    for (hipStream_t fs : c->fetch_stream) if (fs) (void)hipStreamSynchronize(fs);
+}
 // Only call with the stream idle (after hipStreamSynchronize).
 void drain_spans(cwslg_ctx *c)
 {
+    // spans whose end event has not completed (another thread queued work since the caller's wait) stay for the next drain
+    std::vector<TimedSpan> later;
     for (const TimedSpan &s : c->spans) {
+        if (hipEventQuery(s.b) != hipSuccess) { later.push_back(s); continue; }
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
             if (s.kind == 0) c->stats.demod_ms += ms;
@@ -413,7 +431,8 @@ void drain_spans(cwslg_ctx *c)
         }
         c->ev_pool.push_back({s.a, s.b});
     }
-    c->spans.clear();
+    c->spans.swap(later);
+    if (!c->spans.empty()) return;         // (the clock slots below belong to launches that may still run)
     for (; c->clk_tail != c->clk_head; ++c->clk_tail) {
         const unsigned long long *q = c->clk_h + 4 * (c->clk_tail % kClkSlots);
         if (q[0] && q[1] && q[2] > q[0] && q[3] > q[1] + 1000) {       // >= 10 us of the 100 MHz counter: a quotient worth having
@@ -971,6 +990,7 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s,
     w->in_flight = true;
     c->stats.finalize_launches++;
     if (n_emitted) *n_emitted = emitted.size();
+    c->fetch_ev_valid = false;             // a new generation of frames: the next fetch records its event behind this boundary's kernels
     // optional sync stage on the freshly finalised int16 frames
     if (c->sync_cfg.enabled && !emitted.empty()) {
         rc = sync_launch(c, emitted);
@@ -1074,6 +1094,9 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
         hipEventCreateWithFlags(&c->copy_done[k], hipEventDisableTiming);
     }
     hipEventCreateWithFlags(&c->demod_done, kOrderEvent);
+    for (int k = 0; k < kFetchStreams; ++k)
+        if (hipStreamCreateWithFlags(&c->fetch_stream[k], hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
+    hipEventCreateWithFlags(&c->fetch_ev, hipEventDisableTiming);      // WITH a system-scope fence: the copy engines read what the kernels wrote
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
     hipEventCreateWithFlags(&c->sync2d_done, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->cand_done, hipEventDisableTiming);
@@ -1098,6 +1121,7 @@ void cwslg_destroy(cwslg_ctx *c)
     for (hipStream_t cs : c->copy_stream) if (cs) hipStreamSynchronize(cs);
     if (c->side) hipStreamSynchronize(c->side);
     if (c->stream) hipStreamSynchronize(c->stream);
+    for (hipStream_t fs : c->fetch_stream) if (fs) (void)hipStreamSynchronize(fs);
     for (Channel &ch : c->chans) {
         if (ch.d_block) hipFree(ch.d_block);
         sync_free_channel(ch.syncbuf);
@@ -1120,6 +1144,8 @@ void cwslg_destroy(cwslg_ctx *c)
     long_free_shared(c->long_shared);
     if (c->d_sincos) hipFree(c->d_sincos);
     if (c->clk_h) (void)hipHostFree(c->clk_h);
+    for (hipStream_t fs : c->fetch_stream) if (fs) { (void)hipStreamSynchronize(fs); (void)hipStreamDestroy(fs); }
+    if (c->fetch_ev) (void)hipEventDestroy(c->fetch_ev);
     for (BatchStage &b : c->batch) {
         if (b.h) (void)hipHostFree(b.h);
         if (b.ev) (void)hipEventDestroy(b.ev);
@@ -1193,6 +1219,7 @@ int cwslg_receiver_close(cwslg_ctx *c, int rx_id)
     hipSetDevice(c->device);
     for (hipStream_t cs : c->copy_stream) HIPCHK(c, hipStreamSynchronize(cs));
     HIPCHK(c, sync_streams(c));
+    wait_fetches(c);
     Receiver &rx = c->rxs[rx_id];
     for (int id : rx.channels) {        // Receiver::finish terminates its instances (Receiver.hpp:194-199)
         Channel &ch = c->chans[id];
@@ -1680,6 +1707,7 @@ int cwslg_channel_close(cwslg_ctx *c, int ch_id)
     if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
     hipSetDevice(c->device);
     HIPCHK(c, sync_streams(c));
+    wait_fetches(c);
     Channel &ch = c->chans[ch_id];
     Receiver &rx = c->rxs[ch.rx];
     rx.channels.erase(std::remove(rx.channels.begin(), rx.channels.end(), ch_id), rx.channels.end());
@@ -1919,10 +1947,12 @@ int cwslg_slot_boundary_channel(cwslg_ctx *c, int ch_id, uint64_t epoch_s)
 int cwslg_synchronize(cwslg_ctx *c)
 {
     if (!c) return CWSLG_ERR_ARG;
-    std::lock_guard<std::mutex> g(c->mu);
+    // the wait itself runs WITHOUT the context mutex: receiver threads keep pushing while a clock thread waits for its boundary's kernels
     hipSetDevice(c->device);
     for (hipStream_t cs : c->copy_stream) HIPCHK(c, hipStreamSynchronize(cs));
     HIPCHK(c, sync_streams(c));
+    for (hipStream_t fs : c->fetch_stream) HIPCHK(c, hipStreamSynchronize(fs));
+    std::lock_guard<std::mutex> g(c->mu);
     drain_spans(c);
     return CWSLG_OK;
 }
@@ -1930,20 +1960,36 @@ int cwslg_synchronize(cwslg_ctx *c)
 int cwslg_fetch_frame(cwslg_ctx *c, int ch_id, int16_t *dst, size_t cap, uint64_t *start_epoch, size_t *n_valid, float *factor)
 {
     if (!c) return CWSLG_ERR_ARG;
-    std::lock_guard<std::mutex> g(c->mu);
-    if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
-    Channel &ch = c->chans[ch_id];
-    if (!ch.have_frame) return CWSLG_ERR_NO_FRAME;
-    hipSetDevice(c->device);
-    if (dst) {
-        if (cap < ch.frame_len) return fail(c, CWSLG_ERR_ARG, "destination holds %zu samples, frame has %zu", cap, ch.frame_len);
-        HIPCHK(c, hipMemcpyAsync(dst, ch.d_i16, ch.frame_len * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+    hipStream_t fs = nullptr;
+    const int16_t *src = nullptr;
+    const float *fac_src = nullptr;
+    size_t flen = 0;
+    std::shared_lock<std::shared_mutex> life;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
+        Channel &ch = c->chans[ch_id];
+        if (!ch.have_frame) return CWSLG_ERR_NO_FRAME;
+        hipSetDevice(c->device);
+        if (dst && cap < ch.frame_len) return fail(c, CWSLG_ERR_ARG, "destination holds %zu samples, frame has %zu", cap, ch.frame_len);
+        if (start_epoch) *start_epoch = ch.frame_t0;
+        if (n_valid) *n_valid = ch.frame_valid;
+        if (!dst && !factor) return CWSLG_OK;
+        // ONE event per generation of frames, recorded behind everything queued so far (the boundary's finalise and sync kernels); every
+        // fetch of the generation waits for it on a fetch stream of its own, not for the compute stream
+        if (!c->fetch_ev_valid) {
+            HIPCHK(c, hipEventRecord(c->fetch_ev, c->stream));
+            c->fetch_ev_valid = true;
+        }
+        fs = c->fetch_stream[c->fetch_rr++ % kFetchStreams];
+        src = ch.d_i16; fac_src = ch.d_factor; flen = ch.frame_len;
+        life = std::shared_lock<std::shared_mutex>(c->life_mu);      // the buffers stay allocated until the copy below is done
     }
-    if (factor) HIPCHK(c, hipMemcpyAsync(factor, ch.d_factor, sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, sync_streams(c));
-    drain_spans(c);
-    if (start_epoch) *start_epoch = ch.frame_t0;
-    if (n_valid) *n_valid = ch.frame_valid;
+    // no context lock from here on: pushes, launches and other fetches proceed
+    HIPCHK(c, hipStreamWaitEvent(fs, c->fetch_ev, 0));
+    if (dst) HIPCHK(c, hipMemcpyAsync(dst, src, flen * sizeof(int16_t), hipMemcpyDeviceToHost, fs));
+    if (factor) HIPCHK(c, hipMemcpyAsync(factor, fac_src, sizeof(float), hipMemcpyDeviceToHost, fs));
+    HIPCHK(c, hipStreamSynchronize(fs));
     return CWSLG_OK;
 }
 

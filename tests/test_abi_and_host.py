@@ -126,4 +126,4 @@ def test_product_library_has_one_kernel_per_job_and_no_lab_switches():
     assert len(exact) == 3 and all("demod_exact3_kernel" in k and "ELi512ELi256E" in k for k in exact), exact
     # FT8: Costas search + candidate selection in one launch per boundary, or (few channels) one workgroup per band + the selection
     assert any("ft8_sync_chan_kernel" in k for k in kp) and any("ft8_sync2d_v3_kernel" in k for k in kp)
-    assert len(kp) <= 36, sorted(kp)
+    assert len(kp) <= 37, sorted(kp)                   # round 4: + scatter_blocks_kernel (cwslg_push_iq_many)
