@@ -353,15 +353,15 @@ __global__ void upload_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__
 // cwslg_push_iq_many: block k of a batch (n_pairs x 16 bytes, read straight from the host-mapped staging buffer over the host link) goes
 // to ring k at its write position, wrapping at the ring's end.  grid (ceil(n_pairs / 256), receivers): every wave-level access is one
 // contiguous 1 KiB run on both sides (positions and capacities are multiples of 4 D samples, so a 16-byte pair never straddles the wrap).
-__global__ __launch_bounds__(256) void scatter_blocks_kernel(const ScatterDesc *__restrict__ desc, const uint4 *__restrict__ src, unsigned n_pairs)
+__global__ __launch_bounds__(256) void scatter_blocks_kernel(const ScatterDesc *__restrict__ desc, const v4f *__restrict__ src, unsigned n_pairs)
 {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n_pairs) return;
     const ScatterDesc d = desc[blockIdx.y];
-    const uint4 v = src[(size_t)blockIdx.y * n_pairs + i];
+    const v4f v = src[(size_t)blockIdx.y * n_pairs + i];
     unsigned idx = d.pos + 2u * i;
     if (idx >= d.cap) idx -= d.cap;
-    reinterpret_cast<uint4 *>(d.ring)[idx >> 1] = v;
+    reinterpret_cast<CWSLG_GLOBAL v4f *>((uintptr_t)d.ring)[idx >> 1] = v;     // (a ring is HBM: global_store, not flat_store)
 }
 hipError_t upload_workbuf(cwslg_ctx *c, WorkBuf *w, size_t bytes)
 {
@@ -1451,7 +1451,7 @@ int cwslg_push_iq_many(cwslg_ctx *c, int n_rx, const int *rx_ids, const float *c
         }
         const unsigned n_pairs = n / 2;
         hipLaunchKernelGGL(scatter_blocks_kernel, dim3((n_pairs + 255) / 256, (unsigned)n_rx), dim3(256), 0, c->stream,
-                           (const ScatterDesc *)bs->h_dev, (const uint4 *)((const char *)bs->h_dev + desc_bytes), n_pairs);
+                           (const ScatterDesc *)bs->h_dev, (const v4f *)((const char *)bs->h_dev + desc_bytes), n_pairs);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipEventRecord(bs->ev, c->stream));
         bs->busy = true;

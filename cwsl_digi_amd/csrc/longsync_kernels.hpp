@@ -210,7 +210,7 @@ __device__ __forceinline__ float2 fftb_at(const float2 *y, int t, int k)
 // ---------------------------------------------------------------------------------------------
 // WSPR.  What wsprd reads as sample n of the file the reference writes: a 46-byte header of which wsprd skips 44, so sample 0
 // is the upper half of the data-length field and sample n is frame[n - 1] (longsync_oracle.c:wspr_sample).
-__device__ __forceinline__ float wspr_sample(const int16_t *frame, int frame_len, int n)
+__device__ __forceinline__ float wspr_sample(const CWSLG_GLOBAL int16_t *frame, int frame_len, int n)
 {
     if (n >= WSPR_NPTS) return 0.0f;
     int v;
@@ -219,22 +219,56 @@ __device__ __forceinline__ float wspr_sample(const int16_t *frame, int frame_len
     return (float)v * (1.0f / 32768.0f);
 }
 
-// grid (M / 256, channels): 256 consecutive b = 8192 consecutive samples, read once (coalesced), dealt out to the 16 packed
-// sequences through LDS (index n + n/32: the stride-32 reads of the deal fall on 32 different banks).
+// Eight consecutive int16 samples of a frame as floats: one 16-byte global load where the chunk lies inside the frame (frames are 256-byte
+// aligned and their lengths multiples of 8), element by element at its end, zeros beyond it.
+__device__ __forceinline__ void load_i16x8(const CWSLG_GLOBAL int16_t *frame, int frame_len, int i0, float (&v)[8])
+{
+    if (i0 + 8 <= frame_len) {
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        const v4u q = *reinterpret_cast<const CWSLG_GLOBAL v4u *>(frame + i0);
+        const unsigned wds[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] = (float)(int)(short)(wds[e] & 0xFFFFu);
+            v[2 * e + 1] = (float)((int)wds[e] >> 16);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (i0 + e < frame_len) ? (float)frame[i0 + e] : 0.0f;
+    }
+}
+
+// grid (M / 256, channels): 256 consecutive b = 8192 consecutive samples, read once -- 16 bytes per lane (round 3 read two: 0.51 ms per
+// 128 frames) -- and dealt out to the 16 packed sequences through LDS (index n + n/32: the stride-32 reads of the deal fall on 32
+// different banks).  wsprd's sample n is frame[n - 1] (wspr_sample above), so the aligned chunk frame[N0 + 8 c ...] lands on local samples
+// 8 c + 1 ... 8 c + 8; local sample 0 is the last element of the previous workgroup's range (the header word for the first).
 __global__ __launch_bounds__(256) void wspr_pack_kernel(const LongWork *__restrict__ works)
 {
     __shared__ float s_x[WSPR_R * 256 + 256];
     const LongWork *w = works + blockIdx.y;
+    const CWSLG_GLOBAL int16_t *frame = as_global(w->frame);
+    const int frame_len = w->frame_len;
     const int b0 = blockIdx.x * 256, tid = threadIdx.x;
-    for (int k = 0; k < WSPR_R; ++k) {
-        const int n = 256 * k + tid;
-        s_x[n + (n >> 5)] = wspr_sample(w->frame, w->frame_len, WSPR_R * b0 + n);
+    const int N0 = WSPR_R * b0;
+    constexpr int NLOC = WSPR_R * 256;
+#pragma unroll
+    for (int k = 0; k < NLOC / 8 / 256; ++k) {
+        const int c = tid + 256 * k;
+        float v[8];
+        load_i16x8(frame, frame_len, N0 + 8 * c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = 8 * c + e + 1;                      // local sample; global sample N0 + n
+            if (n < NLOC) s_x[n + (n >> 5)] = (N0 + n < WSPR_NPTS) ? v[e] * (1.0f / 32768.0f) : 0.0f;
+        }
     }
+    if (tid == 0) s_x[0] = wspr_sample(frame, frame_len, N0);
     __syncthreads();
+    CWSLG_GLOBAL v2f *z = reinterpret_cast<CWSLG_GLOBAL v2f *>(as_global_rw(w->z));
 #pragma unroll 4
     for (int p = 0; p < WSPR_R / 2; ++p) {
         const int n1 = WSPR_R * tid + p, n2 = n1 + WSPR_R / 2;
-        w->z[(size_t)p * WSPR_M + b0 + tid] = make_float2(s_x[n1 + (n1 >> 5)], s_x[n2 + (n2 >> 5)]);
+        z[(size_t)p * WSPR_M + b0 + tid] = v2f{s_x[n1 + (n1 >> 5)], s_x[n2 + (n2 >> 5)]};
     }
 }
 
@@ -486,16 +520,23 @@ __global__ __launch_bounds__(256) void fst4w_pack_kernel(const LongWork *__restr
 {
     __shared__ float s_x[F4W_R * 256];
     const LongWork *w = works + blockIdx.y;
+    const CWSLG_GLOBAL int16_t *frame = as_global(w->frame);
+    const int lim = min(w->frame_len, F4W_NMAX);              // samples at and beyond either bound read as zero
     const int b0 = blockIdx.x * 256, tid = threadIdx.x;
-    for (int k = 0; k < F4W_R; ++k) {
-        const int n = F4W_R * b0 + 256 * k + tid;
-        s_x[256 * k + tid] = (n < w->frame_len && n < F4W_NMAX) ? (float)w->frame[n] : 0.0f;
+    const int N0 = F4W_R * b0;                                // a multiple of 8: 16-byte loads (round 3 read two bytes per lane: 0.59 ms)
+    static_assert((F4W_R * 256) % 8 == 0, "whole 16-byte chunks");
+    for (int c = tid; c < F4W_R * 256 / 8; c += 256) {
+        float v[8];
+        load_i16x8(frame, lim, N0 + 8 * c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s_x[8 * c + e] = v[e];
     }
     __syncthreads();
+    CWSLG_GLOBAL v2f *z = reinterpret_cast<CWSLG_GLOBAL v2f *>(as_global_rw(w->z));
     for (int p = 0; p < 23; ++p) {
         const float x1 = s_x[F4W_R * tid + (p < 22 ? p : 44)];
         const float x2 = (p < 22) ? s_x[F4W_R * tid + p + 22] : 0.0f;
-        w->z[(size_t)p * F4W_M + b0 + tid] = make_float2(x1, x2);
+        z[(size_t)p * F4W_M + b0 + tid] = v2f{x1, x2};
     }
 }
 

@@ -1652,6 +1652,7 @@ __global__ __launch_bounds__(256) void ft4_candidates_kernel(const SyncWork *__r
     __shared__ float s_savg[NB1], s_savsm[NB1], s_sdb[NB1], s_sbase[NB1];
     __shared__ float s_segbase[10];
     __shared__ double s_a[5];
+    __shared__ double s_A[5][6];       // the 5 x 5 system + right-hand side: pivoting indexes its rows dynamically (in registers that is 256 bytes of scratch)
     __shared__ int s_scan[256];
     __shared__ int s_ok;
     __shared__ int s_cbin[SYNC_MAXCAND_CAP];
@@ -1659,7 +1660,9 @@ __global__ __launch_bounds__(256) void ft4_candidates_kernel(const SyncWork *__r
     __shared__ unsigned s_hi[1024], s_lo[1024];
     const SyncWork *w = works + blockIdx.x;
     const int tid = threadIdx.x;
-    const float *sp = w->spectra;
+    // the descriptor's pointers are HBM addresses: say so (global_load / global_store instead of flat_*)
+    const CWSLG_GLOBAL float *sp = as_global(w->spectra);
+    CWSLG_GLOBAL int *ncand_out = as_global_rw(w->ncand);
     const float df = 12000.0f / (float)FT4_NFFT1;
     // averaged spectrum: sum over the 122 symbol steps in order, then /NHSYM
     for (int i = tid; i < NB1; i += 256) {
@@ -1686,7 +1689,7 @@ __global__ __launch_bounds__(256) void ft4_candidates_kernel(const SyncWork *__r
     const int nlen = (ib - ia + 1) / nseg, i0 = (ib - ia + 1) / 2;
     const double half = (double)(ib - ia + 1) / 2.0;
     const bool range_ok = (nfb - nfa) >= 20;
-    if (!range_ok) { if (tid == 0) *w->ncand = 0; return; }
+    if (!range_ok) { if (tid == 0) *ncand_out = 0; return; }
     for (int i = ia + tid; i <= ib; i += 256) s_sdb[i] = (float)(10.0 * log10_fixed((double)s_savg[i]));
     __syncthreads();
     // 10th percentile of each of the 10 segments (rank of every element inside its segment)
@@ -1727,7 +1730,7 @@ __global__ __launch_bounds__(256) void ft4_candidates_kernel(const SyncWork *__r
             }
         }
         int ok = kz >= 5;
-        double A[5][6];
+        double (&A)[5][6] = s_A;
         for (int r = 0; r < 5; ++r) { for (int cc = 0; cc < 5; ++cc) A[r][cc] = S[r + cc]; A[r][5] = Tm[r]; }
         for (int col = 0; col < 5 && ok; ++col) {
             int piv = col;
@@ -1751,7 +1754,7 @@ __global__ __launch_bounds__(256) void ft4_candidates_kernel(const SyncWork *__r
         s_ok = ok;
     }
     __syncthreads();
-    if (!s_ok) { if (tid == 0) *w->ncand = 0; return; }
+    if (!s_ok) { if (tid == 0) *ncand_out = 0; return; }
     int bad = 0;
     for (int i = ia + tid; i <= ib; i += 256) {
         const double u = (double)(i - i0) / half;
@@ -1760,10 +1763,13 @@ __global__ __launch_bounds__(256) void ft4_candidates_kernel(const SyncWork *__r
         s_sbase[i] = b;
         if (!(b > 0.0f)) bad = 1;
     }
-    if (__syncthreads_or(bad)) { if (tid == 0) *w->ncand = 0; return; }
+    if (__syncthreads_or(bad)) { if (tid == 0) *ncand_out = 0; return; }
     for (int i = nfa + tid; i <= nfb; i += 256) s_savsm[i] = s_savsm[i] / s_sbase[i];
     __syncthreads();
-    for (int i = tid; i < NB1; i += 256) { w->red[i] = s_savsm[i]; w->red2[i] = s_sbase[i]; }   // for parity tests
+    {
+        CWSLG_GLOBAL float *red = as_global_rw(w->red), *red2 = as_global_rw(w->red2);
+        for (int i = tid; i < NB1; i += 256) { red[i] = s_savsm[i]; red2[i] = s_sbase[i]; }   // for parity tests
+    }
     // local maxima, ascending bin, first maxcand kept
     constexpr int PER = 5;
     const float f_offset = -1.5f * 12000.0f / 576.0f;
@@ -1837,11 +1843,10 @@ __global__ __launch_bounds__(256) void ft4_candidates_kernel(const SyncWork *__r
     }
     for (int r = tid; r < ncand; r += 256) {
         const int i = (int)(s_lo[r] & 0xFFFu);
-        SyncChannelBuffers::Cand c;
-        c.freq_bin = s_cbin[i]; c.time_step = 0; c.sync = s_cs[i]; c.freq_hz = s_cf[i]; c.dt_s = 0.0f;
-        w->cand[r] = c;
+        CWSLG_GLOBAL SyncChannelBuffers::Cand *c = as_global_rw(w->cand) + r;
+        c->freq_bin = s_cbin[i]; c->time_step = 0; c->sync = s_cs[i]; c->freq_hz = s_cf[i]; c->dt_s = 0.0f;
     }
-    if (tid == 0) *w->ncand = ncand;
+    if (tid == 0) *ncand_out = ncand;
 }
 
 } // namespace cwslg

@@ -1,0 +1,112 @@
+"""CPU: the committed measurement records are consistent with the evidence they cite, and the product kernels stay clean.
+
+1. profiles/traffic_per_launch.json is what bench.py REPLAYS as roofline.traffic (PMC counters cannot be read from inside the process).
+   Every entry names the PMC summary it came from; this test recomputes the bytes from that summary -- FETCH_SIZE (KiB) x 2 + WRITE_SIZE
+   (KiB), as MI355X_MICROARCH.md's HBM section prescribes for gfx950 -- and fails on any mismatch.
+2. The product library's kernels, compiled here for gfx950: no scratch (private segment) in any kernel, no flat_ memory instruction in
+   any kernel of the hot path (demodulation, finalise, FT8 spectra / search) nor in the 120 s / FT4 kernels cleaned in round 4."""
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _summary(path):
+    """{kernel base name + first template argument: {counter: value}} of a profiles/*pmc_summary*.txt file."""
+    out, cur = {}, None
+    for line in open(path):
+        if not line.startswith(" "):
+            name = line.strip().replace("void ", "").replace("cwslg::", "").replace(" ", "")
+            cur = out.setdefault(name, {})
+        elif cur is not None and line.strip():
+            k, v = line.split()
+            cur[k] = float(v)
+    return out
+
+
+def _find(summary, kernel):
+    want = kernel.replace(" ", "")
+    base, args = want.split("<")[0], want.split("<")[1].rstrip(">").split(",") if "<" in want else []
+    hits = [k for k in summary if k.split("<")[0] == base and ("<" not in k or k.split("<")[1].split(",")[:len(args[:2])] == args[:2])]
+    assert len(hits) == 1, (kernel, sorted(summary))
+    return summary[hits[0]]
+
+
+def test_replayed_traffic_matches_the_pmc_summaries_it_cites():
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_per_launch.json")))
+    checked = 0
+    for run in tj["runs"]:
+        src = run["source"].split()[0]
+        path = os.path.join(ROOT, src)
+        assert os.path.isfile(path), f"{src} cited by traffic_per_launch.json is not in the tree"
+        c = _find(_summary(path), run["kernel"])
+        assert c["FETCH_SIZE"] == pytest.approx(run["fetch_size_kb_raw"], rel=2e-4), run
+        assert c["WRITE_SIZE"] == pytest.approx(run["write_size_kb_raw"], rel=2e-4), run
+        assert (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 == pytest.approx(run["hbm_bytes_per_launch"], rel=2e-4), run
+        # and the traffic is not implausible: between the algorithmic bytes and 1.2x of them
+        assert run["algorithmic_bytes_per_launch"] <= run["hbm_bytes_per_launch"] <= 1.2 * run["algorithmic_bytes_per_launch"], run
+        checked += 1
+    for run in tj.get("sync_runs", []):
+        path = os.path.join(ROOT, run["source"].split()[0])
+        s = _summary(path)
+        total = 0.0
+        for kname in run["fetch_size_kb_raw"]:
+            c = _find(s, kname)
+            assert c["FETCH_SIZE"] == pytest.approx(run["fetch_size_kb_raw"][kname], rel=2e-4), (kname, run)
+            assert c["WRITE_SIZE"] == pytest.approx(run["write_size_kb_raw"][kname], rel=2e-4), (kname, run)
+            total += (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        assert total == pytest.approx(run["fabric_bytes_per_boundary"], rel=2e-4), run
+        checked += 1
+    assert checked >= 4
+
+
+@pytest.fixture(scope="module")
+def product_isa(tmp_path_factory):
+    from cwsl_digi_amd import build as B
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.fail("hipcc is needed to inspect the product kernels")
+    out = tmp_path_factory.mktemp("isa") / "prod.s"
+    flags = [f for f in B.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.check_call([hipcc] + flags + ["-S", "--cuda-device-only", "-o", str(out)] + B.sources(), stderr=subprocess.DEVNULL)
+    s = open(out).read()
+    kernels = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", s, re.S):
+        name, blk = m.group(1), m.group(2)
+        i = s.find("\n" + name + ":")
+        body = s[i:s.find("s_endpgm", i)]
+        kernels[name] = dict(scratch=int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", blk).group(1)),
+                             scratch_ops=len(re.findall(r"\bscratch_", body)), flat=len(re.findall(r"\bflat_(?:load|store|atomic)", body)),
+                             vgpr=int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", blk).group(1)))
+    return kernels
+
+
+def test_no_product_kernel_uses_scratch(product_isa):
+    bad = {k: v for k, v in product_isa.items() if v["scratch"] or v["scratch_ops"]}
+    assert not bad, bad
+
+
+# kernels whose every global access goes through the global address space (no flat_ instruction: a flat access also counts in lgkmcnt
+# and stalls the next LDS wait); grown as kernels are cleaned
+NO_FLAT = ("demod_kernel", "demod_exact3_kernel", "demod_transition_kernel", "finalize_kernel", "symbol_spectra_v2_kernel", "synth_kernel",
+           "scatter_blocks_kernel", "upload_kernel", "wspr_pack_kernel", "fst4w_pack_kernel", "ft4_candidates_kernel")
+
+
+def test_hot_path_kernels_have_no_flat_memory_instructions(product_isa):
+    seen = set()
+    for name, v in product_isa.items():
+        for want in NO_FLAT:
+            if want in name:
+                seen.add(want)
+                assert v["flat"] == 0, (name, v)
+    assert seen == set(NO_FLAT), set(NO_FLAT) - seen
+
+
+def test_exact_kernel_register_budget(product_isa):
+    """Two workgroups per CU -- one wave of each on every SIMD -- need at most 256 VGPRs per lane (192 kHz form)."""
+    k = [v for n, v in product_isa.items() if "demod_exact3_kernelILi16E" in n]
+    assert len(k) == 1 and k[0]["vgpr"] <= 256, k
