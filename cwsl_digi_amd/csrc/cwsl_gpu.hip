@@ -250,7 +250,7 @@ struct cwslg_ctx {
     unsigned long long *clk_h = nullptr, *clk_dev = nullptr;
     unsigned clk_head = 0, clk_tail = 0;
     double clk_sum_mhz = 0.0;
-    int occ_cache[3][4] = {};          // launch_demod: resident demod_exact3 workgroups per CU by (D, tile form); per context = per device
+    int occ_cache[3][5] = {};          // launch_demod: resident demod_exact3 workgroups per CU by (D, tile form); per context = per device
     // launch descriptors
     WorkBuf wb[kWorkBufs];
     int wb_next = 0;
@@ -646,8 +646,13 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
         launched = false;
     }
 #endif
+    bool use_exact4 = D == 16;             // 192 kHz: the two-stream form, eight waves per tile image (demod_exact4_kernel); 96 / 48 kHz: exact3
+#if CWSLG_LAB
+    if (c->demod_variant == 26 || tile != kTileExact) use_exact4 = false;       // CWSLG_DEMOD_VARIANT=26: round 3's exact3 at 192 kHz (same bits; A/B)
+#endif
     if (!launched && c->exact) {
-        c->demod_kernel_name = D == 16 ? "demod_exact3_kernel<16,512,256>" : D == 8 ? "demod_exact3_kernel<8,512,256>" : "demod_exact3_kernel<4,512,256>";
+        c->demod_kernel_name = D == 16 ? (use_exact4 ? "demod_exact4_kernel<512,512>" : "demod_exact3_kernel<16,512,256>")
+                             : D == 8 ? "demod_exact3_kernel<8,512,256>" : "demod_exact3_kernel<4,512,256>";
         // Large launches: as many workgroups as are resident at once (two per CU, LDS-bound: one wave of each on every SIMD), each
         // drawing runs of tiles with the next tile's loads in flight under its FIR; small launches (real-time pushes): one
         // workgroup per run of tiles.
@@ -665,16 +670,24 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
             hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(nt), 0, c->stream, (const ChanWork *)w->d, (const float *)c->d_taps2[fs],
                                tiles_x, (int)works.size(), (unsigned *)((char *)w->d + ctr_off), run_len, clk);
         };
-        int (&occ_cache)[3][4] = c->occ_cache;              // resident workgroups per CU on THIS device, by D and tile form (asked once; guarded by c->mu)
+        int (&occ_cache)[3][5] = c->occ_cache;              // resident workgroups per CU on THIS device, by D and tile form (asked once; guarded by c->mu)
         const int di = D == 16 ? 0 : D == 8 ? 1 : 2;
 #if CWSLG_LAB
         if (tile == 256) go(demod_exact3_kernel<D, 256, 128>, 128, occ_cache[di][1]);
         else if (tile == 128) go(demod_exact3_kernel<D, 128, 64>, 64, occ_cache[di][2]);
         else if (c->demod_variant == 25) {                   // the FIR as C++ with hand-issued 8-byte loads (round 3's first form; same bits)
-            go(demod_exact3_kernel<D, kTileExact, kExactThreads, false>, kExactThreads, occ_cache[di][3]);
+            go(demod_exact3_kernel<D, kTileExact, kExactThreads, false>, kExactThreads, occ_cache[di][4]);
         } else
 #endif
-        go(demod_exact3_kernel<D, kTileExact, kExactThreads>, kExactThreads, occ_cache[di][0]);
+        if (use_exact4) {
+            if constexpr (D == 16) go(demod_exact4_kernel<kTileExact, kTileExact>, kTileExact, occ_cache[di][0]);
+        } else {
+#if CWSLG_LAB
+            go(demod_exact3_kernel<D, kTileExact, kExactThreads>, kExactThreads, occ_cache[di][3]);
+#else
+            if constexpr (D != 16) go(demod_exact3_kernel<D, kTileExact, kExactThreads>, kExactThreads, occ_cache[di][0]);
+#endif
+        }
     } else if (!launched) {
         c->demod_kernel_name = D == 16 ? "demod_kernel<16,256,256,0>" : D == 8 ? "demod_kernel<8,256,256,0>" : "demod_kernel<4,256,256,0>";
         hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, 0>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,

@@ -1482,6 +1482,7 @@ __global__ __launch_bounds__(NT, 2) void demod_exact2_kernel(const ChanWork *__r
 }
 
 #include "exact3_asm.inc"
+#include "exact4_asm.inc"
 // ---------------------------------------------------------------------------------------------
 // Registers of demod_exact3_kernel's software pipeline, filled by hand-issued loads (see the kernel).
 typedef float v8f __attribute__((ext_vector_type(8)));
@@ -1975,6 +1976,168 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
     STAMP(0); STAMP(1);
 #endif
 #endif
+    }
+    if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long t_, r_;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");
+        as_global_rw(clk)[2] = t_;
+        as_global_rw(clk)[3] = r_;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// demod_exact4_kernel (192 kHz; round 4): demod_exact3_kernel's arithmetic with the 33 steps of an output pair split between TWO waves,
+// so that one tile image serves eight waves and a SIMD holds four.
+//
+//   Why.  exact3 keeps a pair of outputs on one lane for all 33 steps: 250 registers per lane, four waves per 78 KB image, two waves per
+//   SIMD.  scripts/micro/pk_issue.hip (profiles/r4_pk_issue.txt): a SIMD retires one packed FP32 operation per 5.2 cycles from one wave,
+//   4.46 from two, 4.34 from three, 4.25 from four; exact3 averaged 4.95 (SQ_INSTS_VALU x 4 / GRBM cycles: 81 % pipe-busy) because for
+//   a third of a tile's life one of a SIMD's two waves is loading, mixing, waiting at a barrier or storing.  More waves need a smaller
+//   footprint PER WAVE, and the image cannot shrink: its rows are the outputs in flight.
+//   How.  The only dependence between the steps of an output is the accumulation W = ((0 + R_0) + R_1) + ... + R_32 of the block terms
+//   R_n = sum_n * phase_n (SSBD.hpp:170); the R_n are independent.  Waves 0-3 of the workgroup ("A", lane = output pair) run steps 0..16
+//   and publish W_A = R_0 + ... + R_16 in LDS; waves 4-7 ("B", the same pairs) run steps 17..32 KEEPING their sixteen R_n in registers,
+//   meet the A waves at one barrier, read W_A and finish W = (W_A + R_17) + ... + R_32 -- the reference's additions in the reference's
+//   order: bit-identical.  Both streams are generated assembly with every register fixed (exact4_asm.inc, scripts/gen_exact4_asm.py;
+//   checked instruction by instruction on the CPU: tests/test_exact4_stream.py) inside 128 registers per lane: the samples of a step
+//   live in one 32-register buffer refilled half a step ahead.
+//   The workgroup (512 threads) loads, rebuilds the phasor and mixes a tile together (nine 16-byte loads per lane), then FIR, then the
+//   next tile: no register prefetch across tiles -- the CU's other workgroup (its four waves per SIMD are two of each) computes meanwhile.
+template <int T, int NT>
+__global__ __launch_bounds__(NT, 4) void demod_exact4_kernel(const ChanWork *__restrict__ works,
+                                                              const float *__restrict__ taps2,
+                                                              int tiles_x, int n_ch, unsigned *__restrict__ xcd_next, int run_len,
+                                                              unsigned long long *__restrict__ clk)
+{
+    constexpr int D = 16;
+    using Geo = DemodGeom<D, T>;
+    constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
+    constexpr int NBH = (Geo::NBLK + 1) / 2 + 1;
+    constexpr int BP = D + 2;                              // row pitch in complex samples: exact3's 16-byte-read image
+    constexpr int NP = NT / 2;                             // output pairs per tile = lanes per stream
+    static_assert(2 * NP == T && NT % 128 == 0 && Geo::NCK <= NT, "one lane per output pair and stream");
+    static_assert(EXACT4_ASM_ROW_BYTES == BP * (int)sizeof(float2), "exact4_asm.inc is generated for this row pitch");
+    __shared__ __attribute__((aligned(16))) float2 s_t[2][NBH * BP];
+    __shared__ __attribute__((aligned(8))) v2f s_w[NP];    // W_A of every pair: stream A -> stream B
+    __shared__ int s_draw[2];
+    static_assert(2 * (sizeof(float2) * 2 * NBH * BP + sizeof(v2f) * NP + 64) <= 163840, "two workgroups per CU");
+
+    const int total = (tiles_x < 0 ? -tiles_x : tiles_x) * n_ch;
+    const int per_xcd = (total + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int lo_item = xcd * per_xcd, hi_item = min((xcd + 1) * per_xcd, total);
+    const int kRun = run_len;
+    CWSLG_GLOBAL unsigned *ctr = as_global_rw(xcd_next) + xcd;
+    if (threadIdx.x == 0) s_draw[0] = (int)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    int item = lo_item + kRun * (int)uni((unsigned)s_draw[0]);
+    if (item >= hi_item) return;
+    int draw_par = 1;
+    int run_left = kRun - 1;
+    if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {     // the launch's shader clock (see demod_exact3_kernel)
+        unsigned long long t_, r_;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");
+        as_global_rw(clk)[0] = t_;
+        as_global_rw(clk)[1] = r_;
+    }
+    const bool is_b = uni((unsigned)(threadIdx.x >= NP)) != 0;   // wave-uniform: NP is a multiple of 64
+    const CWSLG_CONST float *h2 = as_const(taps2);
+    for (;;) {
+        // An opaque copy of the thread index per tile: hipcc would otherwise hoist every per-lane address of the loads and of the mix's LDS
+        // writes out of the loop, and values that live across the FIR statements (which own v40-v127) are spilled to scratch.
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int pair = tid & (NP - 1);
+        const unsigned lds0 = (unsigned)(uintptr_t)&s_t[0][pair * BP];          // block 2 l of this pair's window
+        const unsigned lds1 = (unsigned)(uintptr_t)&s_t[1][pair * BP];          // block 2 l + 1
+        const unsigned xaddr = (unsigned)(uintptr_t)&s_w[pair];
+        TileCtx<D, T> cur;
+        {
+            int ich, itile;
+            item_to_ch_tile(item, tiles_x, n_ch, ich, itile);
+            decode_item<D, T>(works + ich, itile, cur);
+        }
+        // the run after this one is drawn while its last item is loaded and mixed
+        unsigned draw = 0;
+        if (run_left == 0 && tid == 0) draw = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur.n_out > 0) {
+            v4f xs[NIT];
+            float2 ck;
+            v4f tn;
+            issue_tile_loads<D, T, NT>(cur, tid, xs, ck, tn);
+            {
+                const int cidx = cur.ck_first + tid;
+                if (tid < Geo::NCK) {
+                    float2 p = (cidx >= 0) ? ck : make_float2(0.0f, 0.0f);   // blocks before the origin: a FINITE phase (their samples are zero)
+                    const int pbase = cur.pb0 + kCk * tid;
+#pragma unroll
+                    for (int s = 0; s < kCk; ++s) {
+                        const int pb = pbase + s;
+                        if (pb >= 0 && pb < Geo::NBLK) s_t[pb & 1][(pb >> 1) * BP + D] = p;
+                        p = cmul_exact(p, cur.inc);
+                    }
+                }
+            }
+            // t = in[m] * tone[m]  (SSBD.hpp:167), un-fused, into the parity arrays; x[i < 0] = 0 on the (wave-uniform) slow path
+            {
+                const float2 tn0 = make_float2(tn.x, tn.y), tn1 = make_float2(tn.z, tn.w);
+                const int fv = cur.first_valid;
+                auto mix = [&](auto slow_tag) {
+                    constexpr bool SLOW = decltype(slow_tag)::value;
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int r = 2 * tid + it * 2 * NT;
+                        if (r < Geo::NSAMP) {
+                            v4f x = xs[it];
+                            if (SLOW) {
+                                if (r < fv) x = v4f{0.0f, 0.0f, 0.0f, 0.0f};
+                            }
+                            const v2f a = cmul_exact_pk(v2f{x.x, x.y}, v2f{tn0.x, tn0.y});
+                            const v2f b = cmul_exact_pk(v2f{x.z, x.w}, v2f{tn1.x, tn1.y});
+                            const int blk = r / D, m = r % D;
+                            v2f *row = reinterpret_cast<v2f *>(&s_t[blk & 1][(blk >> 1) * BP + m]);
+                            row[0] = a;
+                            row[1] = b;
+                        }
+                    }
+                };
+                if (fv != 0) mix(std::true_type{});
+                else mix(std::false_type{});
+            }
+        }
+        if (run_left == 0 && tid == 0) s_draw[draw_par] = (int)draw;
+        lds_barrier();                                       // the tile's image is complete
+        const int nitem = run_left ? item + 1 : lo_item + kRun * (int)uni((unsigned)s_draw[draw_par]);
+        if (run_left == 0) draw_par ^= 1;
+        run_left = run_left ? run_left - 1 : kRun - 1;
+        if (cur.n_out > 0) {
+            // Every wave runs its stream whether or not its lanes hold outputs of a ragged last tile (their rows hold the ring's next samples:
+            // finite or not, nothing of them is stored): stream B contains the workgroup barrier, which every wave must reach exactly once.
+            if (!is_b) {
+                v2f W = {0.0f, 0.0f};
+                asm volatile(EXACT4_FIRA_ASM : [w] "+v"(W) : [r0] "v"(lds0), [r1] "v"(lds1), [tp] "s"(h2) : EXACT4_ASM_CLOBBERS_A);
+                s_w[pair] = W;
+                lds_barrier();                               // W_A is published; every FIR read of the image is done (stream B: inside its statement)
+            } else {
+                v2f W;
+                asm volatile(EXACT4_FIRB_ASM : [w] "=&v"(W) : [r0] "v"(lds0), [r1] "v"(lds1), [tp] "s"(h2), [xa] "v"(xaddr) : EXACT4_ASM_CLOBBERS_B);
+                const int o0 = 2 * pair;
+                float mx_lane = 0.0f;
+                if (o0 < cur.n_out) {
+                    // Iterate(): out[k] for block index mod 4 (qs and T are multiples of 4; o0 is even)
+                    const float v0 = (o0 & 2) ? -W.x : W.x;
+                    const float v1 = (o0 & 2) ? W.y * cur.sign : -W.y * cur.sign;
+                    CWSLG_GLOBAL v2f *out2 = reinterpret_cast<CWSLG_GLOBAL v2f *>(as_global_rw(cur.out) + (size_t)cur.tile * T + o0);
+                    v2f ov; ov.x = v0; ov.y = v1;
+                    *out2 = ov;
+                    mx_lane = fmaxf(fabsf(v0), fabsf(v1));
+                }
+                const float mx = wave_max_dpp(mx_lane);
+                if ((tid & 63) == 0) publish_peak(cur.peak, mx);
+            }
+        }
+        if (nitem >= hi_item) break;
+        item = nitem;
     }
     if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
         unsigned long long t_, r_;

@@ -123,7 +123,9 @@ def test_product_library_has_one_kernel_per_job_and_no_lab_switches():
     demod = sorted(k for k in kp if "demod_kernel" in k)
     assert len(demod) == 3 and all("ELi256ELi256ELi0E" in k for k in demod), demod
     exact = sorted(k for k in kp if "demod_exact" in k)
-    assert len(exact) == 3 and all("demod_exact3_kernel" in k and "ELi512ELi256E" in k for k in exact), exact
+    # exact mode: the two-stream form at 192 kHz (eight waves per tile image), round 3's one-stream form at 96 / 48 kHz
+    assert len(exact) == 3 and sum("demod_exact4_kernelILi512ELi512E" in k for k in exact) == 1, exact
+    assert sum("demod_exact3_kernelILi8ELi512ELi256E" in k or "demod_exact3_kernelILi4ELi512ELi256E" in k for k in exact) == 2, exact
     # FT8: Costas search + candidate selection in one launch per boundary, or (few channels) one workgroup per band + the selection
     assert any("ft8_sync_chan_kernel" in k for k in kp) and any("ft8_sync2d_v3_kernel" in k for k in kp)
     assert len(kp) <= 37, sorted(kp)                   # round 4: + scatter_blocks_kernel (cwslg_push_iq_many)

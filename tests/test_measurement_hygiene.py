@@ -92,7 +92,7 @@ def test_no_product_kernel_uses_scratch(product_isa):
 
 # kernels whose every global access goes through the global address space (no flat_ instruction: a flat access also counts in lgkmcnt
 # and stalls the next LDS wait); grown as kernels are cleaned
-NO_FLAT = ("demod_kernel", "demod_exact3_kernel", "demod_transition_kernel", "finalize_kernel", "symbol_spectra_v2_kernel", "synth_kernel",
+NO_FLAT = ("demod_kernel", "demod_exact3_kernel", "demod_exact4_kernel", "demod_transition_kernel", "finalize_kernel", "symbol_spectra_v2_kernel", "synth_kernel",
            "scatter_blocks_kernel", "upload_kernel", "wspr_pack_kernel", "fst4w_pack_kernel", "ft4_candidates_kernel")
 
 
@@ -107,6 +107,6 @@ def test_hot_path_kernels_have_no_flat_memory_instructions(product_isa):
 
 
 def test_exact_kernel_register_budget(product_isa):
-    """Two workgroups per CU -- one wave of each on every SIMD -- need at most 256 VGPRs per lane (192 kHz form)."""
-    k = [v for n, v in product_isa.items() if "demod_exact3_kernelILi16E" in n]
-    assert len(k) == 1 and k[0]["vgpr"] <= 256, k
+    """192 kHz exact mode: eight waves per tile image, two images per CU = four waves per SIMD, i.e. at most 128 VGPRs per lane."""
+    k = [v for n, v in product_isa.items() if "demod_exact4_kernel" in n]
+    assert len(k) == 1 and k[0]["vgpr"] <= 128, k
