@@ -2003,24 +2003,29 @@ __global__ __launch_bounds__(NT, 2) void demod_exact3_kernel(const ChanWork *__r
 //   live in one 32-register buffer refilled half a step ahead.
 //   The workgroup (512 threads) loads, rebuilds the phasor and mixes a tile together (nine 16-byte loads per lane), then FIR, then the
 //   next tile: no register prefetch across tiles -- the CU's other workgroup (its four waves per SIMD are two of each) computes meanwhile.
-template <int T, int NT>
-__global__ __launch_bounds__(NT, 4) void demod_exact4_kernel(const ChanWork *__restrict__ works,
-                                                              const float *__restrict__ taps2,
-                                                              int tiles_x, int n_ch, unsigned *__restrict__ xcd_next, int run_len,
-                                                              unsigned long long *__restrict__ clk)
+// One stream's whole life (IS_B is a compile-time constant: the two streams keep different registers across their FIR statements, and only
+// a per-stream copy of the loop lets the register allocator see that -- with one loop and a run-time test, stream A's prefetch registers
+// count as live across stream B's statement and are spilled).  Both copies execute the same barriers in the same order.
+template <int T, int NT, bool IS_B>
+__device__ __forceinline__ void exact4_stream(const ChanWork *__restrict__ works, const float *__restrict__ taps2, int tiles_x, int n_ch,
+                                              unsigned *__restrict__ xcd_next, int run_len, unsigned long long *__restrict__ clk,
+                                              float2 *s_tp, v2f *s_w, int *s_draw)
 {
     constexpr int D = 16;
     using Geo = DemodGeom<D, T>;
-    constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
     constexpr int NBH = (Geo::NBLK + 1) / 2 + 1;
     constexpr int BP = D + 2;                              // row pitch in complex samples: exact3's 16-byte-read image
     constexpr int NP = NT / 2;                             // output pairs per tile = lanes per stream
-    static_assert(2 * NP == T && NT % 128 == 0 && Geo::NCK <= NT, "one lane per output pair and stream");
+    // The next tile's IQ is prefetched into registers under the FIR, as in exact3 -- but the two streams have different room beside their
+    // fixed registers (A: v0-v71, B: v0-v39), so an A lane carries ITA 16-byte loads and a B lane ITB: A covers samples [0, 2 NP ITA),
+    // B the rest.
+    constexpr int ITA = 13, ITB = 4;
+    constexpr int RB0 = 2 * NP * ITA;                      // first sample the B lanes load
+    static_assert(2 * NP == T && NT % 128 == 0 && Geo::NCK <= NP, "one lane per output pair and stream; the phasor rebuild runs on stream A's lanes");
+    static_assert(RB0 + 2 * NP * ITB >= Geo::NSAMP && RB0 < Geo::NSAMP && RB0 % D == 0, "the two streams' loads cover the tile");
     static_assert(EXACT4_ASM_ROW_BYTES == BP * (int)sizeof(float2), "exact4_asm.inc is generated for this row pitch");
-    __shared__ __attribute__((aligned(16))) float2 s_t[2][NBH * BP];
-    __shared__ __attribute__((aligned(8))) v2f s_w[NP];    // W_A of every pair: stream A -> stream B
-    __shared__ int s_draw[2];
-    static_assert(2 * (sizeof(float2) * 2 * NBH * BP + sizeof(v2f) * NP + 64) <= 163840, "two workgroups per CU");
+    float2 (*s_t)[NBH * BP] = reinterpret_cast<float2 (*)[NBH * BP]>(s_tp);
+    constexpr bool is_b = IS_B;
 
     const int total = (tiles_x < 0 ? -tiles_x : tiles_x) * n_ch;
     const int per_xcd = (total + 7) >> 3;
@@ -2040,36 +2045,55 @@ __global__ __launch_bounds__(NT, 4) void demod_exact4_kernel(const ChanWork *__r
         as_global_rw(clk)[0] = t_;
         as_global_rw(clk)[1] = r_;
     }
-    const bool is_b = uni((unsigned)(threadIdx.x >= NP)) != 0;   // wave-uniform: NP is a multiple of 64
     const CWSLG_CONST float *h2 = as_const(taps2);
+    v4f xs[IS_B ? ITB : ITA];
+    float2 ck = make_float2(0.0f, 0.0f);
+    v4f tn;
+    // this lane's loads of a tile: samples r0 + 2 NP it, it < ITA (stream A) / ITB (stream B); unconditional and clamped like issue_tile_loads
+    auto issue = [&](const TileCtx<D, T> &c, int pair) {
+        const CWSLG_GLOBAL v4f *ring4 = as_global(reinterpret_cast<const v4f *>(c.ring));
+        const bool flat_run = c.base + (unsigned)Geo::NSAMP <= c.cap;        // the tile does not cross the end of the ring
+        auto load = [&](int r) -> v4f {
+            if (r > Geo::NSAMP - 2) r = Geo::NSAMP - 2;
+            unsigned idx = c.base + (unsigned)r;
+            if (!flat_run && idx >= c.cap) idx -= c.cap;
+            return ring4[idx >> 1];
+        };
+        if constexpr (!IS_B) {
+#pragma unroll
+            for (int it = 0; it < ITA; ++it) xs[it] = load(2 * pair + it * 2 * NP);
+            int cidx = c.ck_first + ((pair < Geo::NCK) ? pair : 0);
+            if (cidx < 0) cidx = 0;
+            const v2f t = as_global(reinterpret_cast<const v2f *>(c.ckpt))[cidx];
+            ck = make_float2(t.x, t.y);
+        } else {
+#pragma unroll
+            for (int it = 0; it < ITB; ++it) xs[it] = load(RB0 + 2 * pair + it * 2 * NP);
+        }
+        tn = as_global(reinterpret_cast<const v4f *>(c.tone))[((2 * pair) % D) >> 1];   // tone[m0], tone[m0+1]
+    };
+    TileCtx<D, T> cur;
+    {
+        int ich, itile;
+        item_to_ch_tile(item, tiles_x, n_ch, ich, itile);
+        decode_item<D, T>(works + ich, itile, cur);
+        issue(cur, (int)(threadIdx.x & (NP - 1)));
+    }
     for (;;) {
         // An opaque copy of the thread index per tile: hipcc would otherwise hoist every per-lane address of the loads and of the mix's LDS
         // writes out of the loop, and values that live across the FIR statements (which own v40-v127) are spilled to scratch.
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
         const int pair = tid & (NP - 1);
-        const unsigned lds0 = (unsigned)(uintptr_t)&s_t[0][pair * BP];          // block 2 l of this pair's window
-        const unsigned lds1 = (unsigned)(uintptr_t)&s_t[1][pair * BP];          // block 2 l + 1
-        const unsigned xaddr = (unsigned)(uintptr_t)&s_w[pair];
-        TileCtx<D, T> cur;
-        {
-            int ich, itile;
-            item_to_ch_tile(item, tiles_x, n_ch, ich, itile);
-            decode_item<D, T>(works + ich, itile, cur);
-        }
-        // the run after this one is drawn while its last item is loaded and mixed
+        // the run after this one is drawn while its last item is mixed
         unsigned draw = 0;
         if (run_left == 0 && tid == 0) draw = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur.n_out > 0) {
-            v4f xs[NIT];
-            float2 ck;
-            v4f tn;
-            issue_tile_loads<D, T, NT>(cur, tid, xs, ck, tn);
-            {
-                const int cidx = cur.ck_first + tid;
-                if (tid < Geo::NCK) {
+            if constexpr (!IS_B) {
+                const int cidx = cur.ck_first + pair;
+                if (pair < Geo::NCK) {
                     float2 p = (cidx >= 0) ? ck : make_float2(0.0f, 0.0f);   // blocks before the origin: a FINITE phase (their samples are zero)
-                    const int pbase = cur.pb0 + kCk * tid;
+                    const int pbase = cur.pb0 + kCk * pair;
 #pragma unroll
                     for (int s = 0; s < kCk; ++s) {
                         const int pb = pbase + s;
@@ -2082,23 +2106,25 @@ __global__ __launch_bounds__(NT, 4) void demod_exact4_kernel(const ChanWork *__r
             {
                 const float2 tn0 = make_float2(tn.x, tn.y), tn1 = make_float2(tn.z, tn.w);
                 const int fv = cur.first_valid;
+                auto mix_one = [&](int r, v4f x, bool slow) {
+                    if (r < Geo::NSAMP) {
+                        if (slow && r < fv) x = v4f{0.0f, 0.0f, 0.0f, 0.0f};   // fv is a multiple of D: both samples of the pair
+                        const v2f a = cmul_exact_pk(v2f{x.x, x.y}, v2f{tn0.x, tn0.y});
+                        const v2f b = cmul_exact_pk(v2f{x.z, x.w}, v2f{tn1.x, tn1.y});
+                        const int blk = r / D, m = r % D;
+                        v2f *row = reinterpret_cast<v2f *>(&s_t[blk & 1][(blk >> 1) * BP + m]);   // 16-byte aligned: one ds_write_b128
+                        row[0] = a;
+                        row[1] = b;
+                    }
+                };
                 auto mix = [&](auto slow_tag) {
                     constexpr bool SLOW = decltype(slow_tag)::value;
+                    if constexpr (!IS_B) {
 #pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
-                        const int r = 2 * tid + it * 2 * NT;
-                        if (r < Geo::NSAMP) {
-                            v4f x = xs[it];
-                            if (SLOW) {
-                                if (r < fv) x = v4f{0.0f, 0.0f, 0.0f, 0.0f};
-                            }
-                            const v2f a = cmul_exact_pk(v2f{x.x, x.y}, v2f{tn0.x, tn0.y});
-                            const v2f b = cmul_exact_pk(v2f{x.z, x.w}, v2f{tn1.x, tn1.y});
-                            const int blk = r / D, m = r % D;
-                            v2f *row = reinterpret_cast<v2f *>(&s_t[blk & 1][(blk >> 1) * BP + m]);
-                            row[0] = a;
-                            row[1] = b;
-                        }
+                        for (int it = 0; it < ITA; ++it) mix_one(2 * pair + it * 2 * NP, xs[it], SLOW);
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < ITB; ++it) mix_one(RB0 + 2 * pair + it * 2 * NP, xs[it], SLOW);
                     }
                 };
                 if (fv != 0) mix(std::true_type{});
@@ -2106,19 +2132,31 @@ __global__ __launch_bounds__(NT, 4) void demod_exact4_kernel(const ChanWork *__r
             }
         }
         if (run_left == 0 && tid == 0) s_draw[draw_par] = (int)draw;
-        lds_barrier();                                       // the tile's image is complete
+        lds_barrier();                                       // the tile's image is complete (every load it came from has been consumed)
+        // the next item of this workgroup: its loads fly while the FIR below runs (xs, ck, tn are free now)
         const int nitem = run_left ? item + 1 : lo_item + kRun * (int)uni((unsigned)s_draw[draw_par]);
         if (run_left == 0) draw_par ^= 1;
         run_left = run_left ? run_left - 1 : kRun - 1;
+        const bool has_next = nitem < hi_item;               // workgroup-uniform
+        TileCtx<D, T> nxt = cur;
+        if (has_next) {
+            int ich, itile;
+            item_to_ch_tile(nitem, tiles_x, n_ch, ich, itile);
+            decode_item<D, T>(works + ich, itile, nxt);
+            issue(nxt, pair);
+        }
         if (cur.n_out > 0) {
             // Every wave runs its stream whether or not its lanes hold outputs of a ragged last tile (their rows hold the ring's next samples:
             // finite or not, nothing of them is stored): stream B contains the workgroup barrier, which every wave must reach exactly once.
-            if (!is_b) {
+            const unsigned lds0 = (unsigned)(uintptr_t)&s_t[0][pair * BP];          // block 2 l of this pair's window
+            const unsigned lds1 = (unsigned)(uintptr_t)&s_t[1][pair * BP];          // block 2 l + 1
+            if constexpr (!IS_B) {
                 v2f W = {0.0f, 0.0f};
                 asm volatile(EXACT4_FIRA_ASM : [w] "+v"(W) : [r0] "v"(lds0), [r1] "v"(lds1), [tp] "s"(h2) : EXACT4_ASM_CLOBBERS_A);
                 s_w[pair] = W;
                 lds_barrier();                               // W_A is published; every FIR read of the image is done (stream B: inside its statement)
             } else {
+                const unsigned xaddr = (unsigned)(uintptr_t)&s_w[pair];
                 v2f W;
                 asm volatile(EXACT4_FIRB_ASM : [w] "=&v"(W) : [r0] "v"(lds0), [r1] "v"(lds1), [tp] "s"(h2), [xa] "v"(xaddr) : EXACT4_ASM_CLOBBERS_B);
                 const int o0 = 2 * pair;
@@ -2136,7 +2174,8 @@ __global__ __launch_bounds__(NT, 4) void demod_exact4_kernel(const ChanWork *__r
                 if ((tid & 63) == 0) publish_peak(cur.peak, mx);
             }
         }
-        if (nitem >= hi_item) break;
+        if (!has_next) break;
+        cur = nxt;
         item = nitem;
     }
     if (clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -2145,6 +2184,23 @@ __global__ __launch_bounds__(NT, 4) void demod_exact4_kernel(const ChanWork *__r
         as_global_rw(clk)[2] = t_;
         as_global_rw(clk)[3] = r_;
     }
+}
+
+template <int T, int NT>
+__global__ __launch_bounds__(NT, 4) void demod_exact4_kernel(const ChanWork *__restrict__ works,
+                                                              const float *__restrict__ taps2,
+                                                              int tiles_x, int n_ch, unsigned *__restrict__ xcd_next, int run_len,
+                                                              unsigned long long *__restrict__ clk)
+{
+    using Geo = DemodGeom<16, T>;
+    constexpr int NBH = (Geo::NBLK + 1) / 2 + 1, BP = 16 + 2, NP = NT / 2;
+    __shared__ __attribute__((aligned(16))) float2 s_t[2][NBH * BP];
+    __shared__ __attribute__((aligned(8))) v2f s_w[NP];    // W_A of every pair: stream A -> stream B
+    __shared__ int s_draw[2];
+    static_assert(2 * (sizeof(float2) * 2 * NBH * BP + sizeof(v2f) * NP + 64) <= 163840, "two workgroups per CU");
+    // waves 0 .. NP/64 - 1 run stream A, the others stream B (wave-uniform: NP is a multiple of 64)
+    if (uni((unsigned)(threadIdx.x >= NP)) == 0) exact4_stream<T, NT, false>(works, taps2, tiles_x, n_ch, xcd_next, run_len, clk, &s_t[0][0], s_w, s_draw);
+    else exact4_stream<T, NT, true>(works, taps2, tiles_x, n_ch, xcd_next, run_len, clk, &s_t[0][0], s_w, s_draw);
 }
 
 // ---------------------------------------------------------------------------------------------
