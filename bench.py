@@ -411,6 +411,13 @@ def main():
             if clk_mhz > 0 and avg_ms > 0:
                 vp["bound_ms"] = pipe_cycles / (clk_mhz * 1e3)
                 vp["frac"] = vp["bound_ms"] / avg_ms
+                # What a SIMD actually retires (scripts/micro/pk_issue.hip, profiles/r4_pk_issue.txt: bare streams of independent v_pk_mul / v_pk_add):
+                # one packed operation per 5.20 cycles from one resident wave, 4.46 from two, 4.34 from three, 4.25 from four -- never 4.0.
+                vp["measured_issue_floor"] = {"cycles_per_packed_op_by_waves_per_simd": {"1": 5.20, "2": 4.46, "3": 4.34, "4": 4.25},
+                                              "source": "profiles/r4_pk_issue.txt", "waves_per_simd": 4 if "exact4" in kname else 2}
+                cyc = 4.25 if "exact4" in kname else 4.46
+                vp["measured_issue_floor"]["bound_ms"] = vp["bound_ms"] * cyc / 4.0
+                vp["measured_issue_floor"]["frac"] = vp["measured_issue_floor"]["bound_ms"] / avg_ms
             roof["valu_pipe"] = vp
         else:
             roof["valu_tflops"] = 80.0 * spl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0

@@ -57,6 +57,9 @@ namespace cwslg {
 #ifndef CWSLG_DIAG_NOHALO
 #define CWSLG_DIAG_NOHALO 0
 #endif
+#ifndef CWSLG_MIX_SWIZZLE
+#define CWSLG_MIX_SWIZZLE 1        // demod_kernel<16>: conflict-free scatter of the mix (0: round 3's lane order, for A/B builds)
+#endif
 #define CWSLG_GLOBAL __attribute__((address_space(1)))
 template <typename T>
 __device__ __forceinline__ const CWSLG_GLOBAL T *as_global(const T *p)
@@ -484,6 +487,15 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, n_slots = gridDim.x >> 3;
     const int hi_item = min((xcd + 1) * per_xcd, total);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // Which pair of samples a lane loads, mixes and scatters: "mix lane" mt handles samples 2 mt + 2 NT it.  D = 16 (round 4): mt is tid
+    // with bit 4 flipped where bit 3 is set, so that the sixteen lanes of one ds_write_b64 cycle hold rows 0-7 of one column and rows 8-15
+    // of the NEXT one -- sixteen distinct bank pairs (row pitch = 4 mod 32 dwords; rows k and k + 8 of the same column share a pair:
+    // the 2-way conflict behind the 20 % of LDS cycles round 3's counters showed).  Global loads stay whole 128-byte runs per eight lanes.
+#if CWSLG_MIX_SWIZZLE
+    const int mt = (D == 16) ? (tid ^ ((tid & 8) << 1)) : tid;
+#else
+    const int mt = tid;
+#endif
     const int k = lane % GL;                    // this lane's branch pair (2k, 2k+1)
     int item = xcd * per_xcd + slot;
     if (item >= hi_item) return;
@@ -503,11 +515,11 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
     float2 ck;
     v4f tn;
     STAMP(7);
-    issue_tile_loads<D, T, NT>(cur, tid, xs, ck, tn);
+    issue_tile_loads<D, T, NT>(cur, mt, xs, ck, tn);
     STAMP(1);
 
     // per-thread LDS addresses of the scatter: r = 2*tid + 2*NT*it  ->  pair-row (r % G)/2 (constant), column w0 + WSTEP*it
-    const int r0 = 2 * tid;
+    const int r0 = 2 * mt;
     float *p0 = s_plane + ((r0 % G) >> 1) * PR + 2 * (r0 / G);                      // plane 0: rel = r
     const int rel1 = r0 - D + 2 * NT;                                               // plane 1: rel = r - D, taken at it = 1
     float *p1 = s_plane + Geo::PLANE_FLOATS + ((rel1 % G) >> 1) * PR + 2 * (rel1 / G - (2 * NT) / G);
@@ -529,10 +541,10 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
         const bool has_next = PERSIST && nitem < hi_item;                           // wave-uniform
         // ---- phase 0: bit-exact phasor for the tile's T+31 blocks (lanes 0..NCK-1, <=kCk un-fused steps each)
         {
-            const int cidx = cur.ck_first + tid;
-            if (tid < Geo::NCK && cidx >= 0) {
+            const int cidx = cur.ck_first + mt;
+            if (mt < Geo::NCK && cidx >= 0) {
                 float2 p = ck;
-                const int pbase = cur.pb0 + kCk * tid;
+                const int pbase = cur.pb0 + kCk * mt;
 #pragma unroll
                 for (int s = 0; s < kCk; ++s) {
                     const int pb = pbase + s;
@@ -564,7 +576,7 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
             item_to_ch_tile(nitem, tiles_x, n_ch, nch, ntile);
             decode_item<D, T>(reinterpret_cast<const ChanWork *>(s_desc[cb ^ 1]), ntile, nxt);
             nring4 = as_global(reinterpret_cast<const v4f *>(nxt.ring));
-            int cidx = nxt.ck_first + ((tid < Geo::NCK) ? tid : 0);
+            int cidx = nxt.ck_first + ((mt < Geo::NCK) ? mt : 0);
             if (cidx < 0) cidx = 0;
             const v2f t = as_global(reinterpret_cast<const v2f *>(nxt.ckpt))[cidx];       // ck was consumed by phase 0
             ck = make_float2(t.x, t.y);
@@ -576,12 +588,12 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
             float2 ph[NIT];
 #pragma unroll
             for (int it = CWSLG_DIAG_NOHALO; it < NIT; ++it) {
-                int blk = (2 * tid) / D + it * (2 * NT / D);
+                int blk = (2 * mt) / D + it * (2 * NT / D);
                 if (blk > Geo::NBLK - 1) blk = Geo::NBLK - 1;
                 ph[it] = s_phase[blk];
             }
             const float2 tn0 = make_float2(tn.x, tn.y), tn1 = make_float2(tn.z, tn.w);
-            if (has_next) tn = as_global(reinterpret_cast<const v4f *>(nxt.tone))[((2 * tid) % D) >> 1];
+            if (has_next) tn = as_global(reinterpret_cast<const v4f *>(nxt.tone))[((2 * mt) % D) >> 1];
             const int fv = cur.first_valid;
             // two copies of the loop behind ONE scalar branch: with the origin test inside a single loop hipcc if-converts it, and
             // its four moves and the compare are then issued (under an empty exec mask) for every load of every tile
@@ -589,7 +601,7 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
                 constexpr bool SLOW = decltype(slow_tag)::value;
 #pragma unroll
                 for (int it = CWSLG_DIAG_NOHALO; it < NIT; ++it) {
-                    const int r = 2 * tid + it * 2 * NT;
+                    const int r = 2 * mt + it * 2 * NT;
                     const v4f x = xs[it];
                     if (has_next) {                                  // in-place prefetch: xs[it] is free from here on
                         int rn = (r > Geo::NSAMP - 2) ? Geo::NSAMP - 2 : r;
@@ -714,7 +726,7 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
             lds_barrier();                                       // s_aux (= s_phase) is rewritten by the next phase 0
             item_to_ch_tile(item, tiles_x, n_ch, ich, itile);
             decode_item<D, T>(works + ich, itile, cur);
-            issue_tile_loads<D, T, NT>(cur, tid, xs, ck, tn);
+            issue_tile_loads<D, T, NT>(cur, mt, xs, ck, tn);
             continue;
         }
         if (!has_next) break;
