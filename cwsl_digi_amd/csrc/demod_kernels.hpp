@@ -57,8 +57,8 @@ namespace cwslg {
 #ifndef CWSLG_DIAG_NOHALO
 #define CWSLG_DIAG_NOHALO 0
 #endif
-#ifndef CWSLG_MIX_SWIZZLE
-#define CWSLG_MIX_SWIZZLE 1        // demod_kernel<16>: conflict-free scatter of the mix (0: round 3's lane order, for A/B builds)
+#ifndef CWSLG_DIAG_LDS
+#define CWSLG_DIAG_LDS 0           // 1..3: timing-only diagnostic builds of demod_kernel without one of its LDS phases (scripts/gpu_r4_ldsdiag.sh)
 #endif
 #define CWSLG_GLOBAL __attribute__((address_space(1)))
 template <typename T>
@@ -487,15 +487,13 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, n_slots = gridDim.x >> 3;
     const int hi_item = min((xcd + 1) * per_xcd, total);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    // Which pair of samples a lane loads, mixes and scatters: "mix lane" mt handles samples 2 mt + 2 NT it.  D = 16 (round 4): mt is tid
-    // with bit 4 flipped where bit 3 is set, so that the sixteen lanes of one ds_write_b64 cycle hold rows 0-7 of one column and rows 8-15
-    // of the NEXT one -- sixteen distinct bank pairs (row pitch = 4 mod 32 dwords; rows k and k + 8 of the same column share a pair:
-    // the 2-way conflict behind the 20 % of LDS cycles round 3's counters showed).  Global loads stay whole 128-byte runs per eight lanes.
-#if CWSLG_MIX_SWIZZLE
-    const int mt = (D == 16) ? (tid ^ ((tid & 8) << 1)) : tid;
-#else
+    // Which pair of samples a lane loads, mixes and scatters: "mix lane" mt handles samples 2 mt + 2 NT it.  Round 4 measured where this
+    // kernel's LDS bank-conflict cycles (20 % of its LDS-active cycles) come from with builds that drop one LDS phase each
+    // (-DCWSLG_DIAG_LDS=1..3, scripts/gpu_r4_ldsdiag.sh): 70 % are the mix's ds_write_b64 scatter, 4 % the FIR's ds_read_b128 -- and the
+    // launch takes the same 2.67 ms with the scatter's writes removed ALTOGETHER (2.671 against 2.676 ms), so they are not on the critical
+    // path.  (A lane order meant to spread the sixteen lanes of a write over sixteen bank pairs, mt = tid ^ ((tid & 8) << 1), changed
+    // neither the counter nor the time: the scatter's conflicts are not the 2-way pattern a 32-bank model predicts.)
     const int mt = tid;
-#endif
     const int k = lane % GL;                    // this lane's branch pair (2k, 2k+1)
     int item = xcd * per_xcd + slot;
     if (item >= hi_item) return;
@@ -622,8 +620,12 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
                     }
                     const bool in0 = (it < NIT - 1) || (r < G * (T / 2 + 15));          // plane 0 drops the last D samples
                     const bool in1 = (it > 0) ? ((it < NIT - 1) || (r < Geo::NSAMP)) : (r >= D);   // plane 1 drops the first D
+#if CWSLG_DIAG_LDS != 1          // (diagnostic build 1: the mix without its LDS writes -- which phase owns the bank-conflict cycles)
                     if (in0) *reinterpret_cast<float2 *>(p0 + 2 * it * WSTEP) = make_float2(y0r, y1r);
                     if (in1) *reinterpret_cast<float2 *>(p1 + 2 * it * WSTEP) = make_float2(y0i, y1i);
+#else
+                    if (y0r + y1r + y0i + y1i == 123.456f && in0 && in1) p0[0] = y0r;      // keep the arithmetic alive
+#endif
                 }
             };
             if (PERSIST) mix(std::true_type{});          // (one copy only: with two, the in-place prefetch spills at 128 VGPRs)
@@ -676,7 +678,11 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
                 // column j = w - 16*chunk (0..30) feeds acc[j - v], v = 0..15; one float4 = columns 2q, 2q+1 x both branches
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
+#if CWSLG_DIAG_LDS != 2          // (diagnostic build 2: the FIR without its LDS reads)
                     const float4 c4 = src[q];
+#else
+                    const float4 c4 = make_float4(tap[q].x, tap[q].y, tap[15 - q].x, tap[15 - q].y);
+#endif
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int j = 2 * q + h;
@@ -698,7 +704,11 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
                 for (int r = 0; r < NV; ++r) {
                     const int wq = 16 * chunk + rbase + r;
                     const float s = (wq & 1) ? -sgn_plane : sgn_plane;
+#if CWSLG_DIAG_LDS != 3          // (diagnostic build 3: no output staging through LDS)
                     s_aux[2 * wq + pl] = s * acc[r];
+#else
+                    if (s * acc[r] == 123.456f) s_aux[0] = 1.0f;
+#endif
                 }
             }
         }
