@@ -55,6 +55,14 @@ public:
     void slotBoundary(int group, std::uint64_t epoch_s) { check(c_, cwslg_slot_boundary(c_, group, epoch_s)); }
     void process() { check(c_, cwslg_process(c_)); }
     void synchronize() { check(c_, cwslg_synchronize(c_)); }
+    // One block for each of several receivers in ONE call (cwslg_push_iq_many): for a host that serves thousands of streams, where a
+    // per-receiver push per block (Receiver.hpp:242-249, ReceiverPort::push below) would mean hundreds of thousands of copies a second.
+    // ids[k] = ReceiverPort::id(); blocks[k] = that receiver's n_complex samples.
+    void pushMany(const std::vector<int> &ids, const std::vector<const std::complex<float> *> &blocks, std::uint32_t n_complex)
+    {
+        if (ids.size() != blocks.size()) throw std::invalid_argument("pushMany: one block per receiver");
+        check(c_, cwslg_push_iq_many(c_, static_cast<int>(ids.size()), ids.data(), reinterpret_cast<const float *const *>(blocks.data()), n_complex));
+    }
 private:
     cwslg_ctx *c_ = nullptr;
 };

@@ -28,12 +28,18 @@ int main(int argc, char **argv)
             threw = std::string(e.what()) == "Signal outside of band (low)";      // SSBD.hpp:101
         }
         if (!threw) return 4;
+        // a second receiver with the same channel, fed block by block through Context::pushMany: its frame must equal the first one's
+        cwslgpu::ReceiverPort rx2(ctx, 192000, 2048, 28100000);
+        cwslgpu::SsbChannel chan2(rx2, 28074000.0 - 28100000.0, true, "FT8");
         std::vector<std::complex<float>> blk(2048);
         std::vector<std::int16_t> audio;
         std::uint64_t t0 = 0;
         ctx.slotBoundary(CWSLG_GROUP_FT8, 1000);
         if (chan.fetch(audio, t0)) return 5;          // first (partial) slot: nothing to decode (Instance.cpp:224-227)
-        while (std::fread(blk.data(), sizeof(blk[0]), blk.size(), f) == blk.size()) rx.push(blk.data(), 2048);
+        while (std::fread(blk.data(), sizeof(blk[0]), blk.size(), f) == blk.size()) {
+            rx.push(blk.data(), 2048);
+            ctx.pushMany({rx2.id()}, {blk.data()}, 2048);
+        }
         // every SSBD getter (SSBD.hpp:140-154) and a Tune that fails leaves the old tuning in force (:100-103)
         if (chan.GetInRate() != 192000 || chan.GetBandwidth() != 6000 || chan.GetOutSize() != 4 || chan.GetDelay() != 8 ||
             chan.GetCarrier() != -26000.0 || !chan.IsUSB()) return 8;
@@ -54,6 +60,10 @@ int main(int argc, char **argv)
         if (sink.collect() != 0) return 10;           // nothing finalised yet
         ctx.slotBoundary(CWSLG_GROUP_FT8, 1015);
         if (!chan.fetch(audio, t0)) return 6;
+        {
+            std::vector<std::int16_t> audio2; std::uint64_t t2 = 0;
+            if (!chan2.fetch(audio2, t2) || t2 != t0 || audio2 != audio) return 13;
+        }
         if (sink.collect() != 1 || sink.collect() != 0) return 11;     // delivered once
         if (delivered != 1 || sink_t0 != t0 || sink_crc != crc32(audio.data(), audio.size() * 2) || sink_tr != 15.0f || sink_id != 3 ||
             sink_f != 28074000 || sink_mode != "FT8" || sink_cwd != "/tmp/cwd3") return 12;
