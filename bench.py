@@ -379,7 +379,19 @@ def main():
                         fabric, src = tj.get("fabric_bytes_per_boundary"), "replayed: " + tj.get("source", "")
             except Exception:
                 pass
-        return {"bound": "valu", "kernels": kernels, "nbins_stored": nbins, "bins_searched": nsearch,
+        # each kernel against ITS bound: the spectra kernel is FP32 work (VALU-bound); the Costas search re-reads its band image from LDS 63 x
+        # 8 bytes per lane and bin (42 Costas terms + 21 seven-tone sums, two adjacent lags per lane) and is LDS-bandwidth-/latency-bound
+        nl = max(1, st_["sync_launches"])
+        sp_ms, se_ms = st_.get("sync_spectra_ms", 0.0) / nl, st_.get("sync_search_ms", 0.0) / nl
+        lds_bytes = float(S) * nsearch * 64 * 63 * 8
+        lds_peak_tbs = n_cu * 128 * 2.4e9 / 1e12                                   # 128 B / clk / CU at the 2.4 GHz peak clock
+        per_kernel = None
+        if sp_ms > 0 and se_ms > 0:
+            per_kernel = {"spectra": {"avg_ms": sp_ms, "bound": "valu", "achieved_tflops": 372 * per_transform * S / (sp_ms * 1e-3) / 1e12,
+                                      "frac": 372 * per_transform * S / (sp_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS},
+                          "search": {"avg_ms": se_ms, "bound": "lds", "lds_read_bytes": lds_bytes, "achieved_tbs": lds_bytes / (se_ms * 1e-3) / 1e12,
+                                     "peak_tbs": lds_peak_tbs, "frac": lds_bytes / (se_ms * 1e-3) / 1e12 / lds_peak_tbs}}
+        return {"bound": "valu", "kernels": kernels, "nbins_stored": nbins, "bins_searched": nsearch, "per_kernel": per_kernel,
                 "avg_ms": ms, "transforms": 372 * S, "flop_per_transform": per_transform, "flop_per_slot": per_slot,
                 "achieved_tflops": tfl, "peak_tflops": VALU_PEAK_TFLOPS, "frac": tfl / VALU_PEAK_TFLOPS,
                 "algorithmic_bytes": S * (240000 * 2 + 200 * 20), "fabric_bytes": fabric, "fabric_source": src}

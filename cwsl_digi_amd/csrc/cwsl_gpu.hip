@@ -199,7 +199,7 @@ struct WorkBuf {
 
 struct TimedSpan {
     hipEvent_t a, b;
-    int kind;                          // 0 demod, 1 finalize, 2 sync
+    int kind;                          // 0 demod, 1 finalize, 2 sync stage (whole), 3 / 4 its FT8 spectra / search + selection kernels
 };
 
 } // namespace cwslg
@@ -427,6 +427,8 @@ void drain_spans(cwslg_ctx *c)
         if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
             if (s.kind == 0) c->stats.demod_ms += ms;
             else if (s.kind == 1) c->stats.finalize_ms += ms;
+            else if (s.kind == 3) c->stats.sync_spectra_ms += ms;
+            else if (s.kind == 4) c->stats.sync_search_ms += ms;
             else c->stats.sync_ms += ms;
         }
         c->ev_pool.push_back({s.a, s.b});

@@ -378,6 +378,8 @@ typedef struct {
     uint64_t push_calls;           /* host pushes accepted (cwslg_push_iq: one per call; cwslg_push_iq_many: one per receiver)         */
     uint64_t push_batches;         /* cwslg_push_iq_many calls                                                                        */
     double   push_host_ms;         /* wall time spent inside host pushes (staging copy + enqueue), summed over the calling threads      */
+    double   sync_spectra_ms;      /* of sync_ms: the FT8 symbol-spectra kernel ...                                                     */
+    double   sync_search_ms;       /* ... and the FT8 Costas search + candidate selection                                                */
 } cwslg_stats;
 int cwslg_get_stats(cwslg_ctx *ctx, cwslg_stats *out);
 int cwslg_reset_stats(cwslg_ctx *ctx);
