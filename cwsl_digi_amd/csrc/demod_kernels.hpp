@@ -2071,26 +2071,34 @@ __device__ __forceinline__ void exact4_stream(const ChanWork *__restrict__ works
     v4f xs[IS_B ? ITB : ITA];
     float2 ck = make_float2(0.0f, 0.0f);
     v4f tn;
-    // this lane's loads of a tile: samples r0 + 2 NP it, it < ITA (stream A) / ITB (stream B); unconditional and clamped like issue_tile_loads
+    // this lane's loads of a tile: samples R0 + 2 pair + 2 NP it, it < ITA (stream A) / ITB (stream B); unconditional, the one load that can
+    // reach beyond the tile (stream B's last) clamped.  All but one tile per ring revolution lie in one piece: one uniform base + a lane offset.
     auto issue = [&](const TileCtx<D, T> &c, int pair) {
+        constexpr int R0 = IS_B ? RB0 : 0, NITS = IS_B ? ITB : ITA;
         const CWSLG_GLOBAL v4f *ring4 = as_global(reinterpret_cast<const v4f *>(c.ring));
-        const bool flat_run = c.base + (unsigned)Geo::NSAMP <= c.cap;        // the tile does not cross the end of the ring
-        auto load = [&](int r) -> v4f {
-            if (r > Geo::NSAMP - 2) r = Geo::NSAMP - 2;
-            unsigned idx = c.base + (unsigned)r;
-            if (!flat_run && idx >= c.cap) idx -= c.cap;
-            return ring4[idx >> 1];
-        };
-        if constexpr (!IS_B) {
+        if (c.base + (unsigned)Geo::NSAMP <= c.cap) {
+            const CWSLG_GLOBAL v4f *p = ring4 + (c.base >> 1) + (R0 >> 1);
 #pragma unroll
-            for (int it = 0; it < ITA; ++it) xs[it] = load(2 * pair + it * 2 * NP);
+            for (int it = 0; it < NITS; ++it) {
+                int q = pair + it * NP;                                       // 16-byte index relative to p
+                if (R0 + 2 * (NP - 1) + it * 2 * NP > Geo::NSAMP - 2) q = min(q, (Geo::NSAMP - 2 - R0) >> 1);   // (compile-time: stream B's last load only)
+                xs[it] = p[q];
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < NITS; ++it) {
+                int r = R0 + 2 * pair + it * 2 * NP;
+                if (r > Geo::NSAMP - 2) r = Geo::NSAMP - 2;
+                unsigned idx = c.base + (unsigned)r;
+                if (idx >= c.cap) idx -= c.cap;
+                xs[it] = ring4[idx >> 1];
+            }
+        }
+        if constexpr (!IS_B) {
             int cidx = c.ck_first + ((pair < Geo::NCK) ? pair : 0);
             if (cidx < 0) cidx = 0;
             const v2f t = as_global(reinterpret_cast<const v2f *>(c.ckpt))[cidx];
             ck = make_float2(t.x, t.y);
-        } else {
-#pragma unroll
-            for (int it = 0; it < ITB; ++it) xs[it] = load(RB0 + 2 * pair + it * 2 * NP);
         }
         tn = as_global(reinterpret_cast<const v4f *>(c.tone))[((2 * pair) % D) >> 1];   // tone[m0], tone[m0+1]
     };
@@ -2124,29 +2132,34 @@ __device__ __forceinline__ void exact4_stream(const ChanWork *__restrict__ works
                     }
                 }
             }
-            // t = in[m] * tone[m]  (SSBD.hpp:167), un-fused, into the parity arrays; x[i < 0] = 0 on the (wave-uniform) slow path
+            // t = in[m] * tone[m]  (SSBD.hpp:167), un-fused, into the parity arrays; x[i < 0] = 0 on the (wave-uniform) slow path.
+            // A lane's loads are 2 NP samples = 2 NP / D blocks apart, an EVEN number of blocks: all of them land in the same parity array,
+            // 2 NP / (2 D) rows apart -- one LDS address per lane and an immediate offset per load (the generic r / D, r % D arithmetic
+            // cost ~90 VALU instructions per wave and tile: 7 % of the kernel's, at the power limit 7 % of its energy).
             {
                 const float2 tn0 = make_float2(tn.x, tn.y), tn1 = make_float2(tn.z, tn.w);
                 const int fv = cur.first_valid;
-                auto mix_one = [&](int r, v4f x, bool slow) {
-                    if (r < Geo::NSAMP) {
-                        if (slow && r < fv) x = v4f{0.0f, 0.0f, 0.0f, 0.0f};   // fv is a multiple of D: both samples of the pair
-                        const v2f a = cmul_exact_pk(v2f{x.x, x.y}, v2f{tn0.x, tn0.y});
-                        const v2f b = cmul_exact_pk(v2f{x.z, x.w}, v2f{tn1.x, tn1.y});
-                        const int blk = r / D, m = r % D;
-                        v2f *row = reinterpret_cast<v2f *>(&s_t[blk & 1][(blk >> 1) * BP + m]);   // 16-byte aligned: one ds_write_b128
-                        row[0] = a;
-                        row[1] = b;
-                    }
-                };
+                constexpr int R0 = IS_B ? RB0 : 0, NITS = IS_B ? ITB : ITA;
+                constexpr int ROWSTEP = (2 * NP) / (2 * D);                      // rows of one parity array between consecutive loads
+                static_assert((2 * NP) % (2 * D) == 0 && R0 % (2 * D) == 0, "a lane's samples stay in one parity array");
+                const int blk0 = R0 / D + (pair >> 3);                            // block of the lane's first sample pair (D = 16: eight lanes per block)
+                v2f *row0 = reinterpret_cast<v2f *>(&s_t[blk0 & 1][(blk0 >> 1) * BP + ((2 * pair) & (D - 1))]);
+                const int r0 = R0 + 2 * pair;
                 auto mix = [&](auto slow_tag) {
                     constexpr bool SLOW = decltype(slow_tag)::value;
-                    if constexpr (!IS_B) {
 #pragma unroll
-                        for (int it = 0; it < ITA; ++it) mix_one(2 * pair + it * 2 * NP, xs[it], SLOW);
-                    } else {
-#pragma unroll
-                        for (int it = 0; it < ITB; ++it) mix_one(RB0 + 2 * pair + it * 2 * NP, xs[it], SLOW);
+                    for (int it = 0; it < NITS; ++it) {
+                        const int r = r0 + it * 2 * NP;
+                        if (R0 + 2 * (NP - 1) + it * 2 * NP >= Geo::NSAMP && r >= Geo::NSAMP) continue;     // only the last load of stream B can lie beyond the tile
+                        v4f x = xs[it];
+                        if (SLOW) {
+                            if (r < fv) x = v4f{0.0f, 0.0f, 0.0f, 0.0f};       // fv is a multiple of D: both samples of the pair
+                        }
+                        const v2f a = cmul_exact_pk(v2f{x.x, x.y}, v2f{tn0.x, tn0.y});
+                        const v2f b = cmul_exact_pk(v2f{x.z, x.w}, v2f{tn1.x, tn1.y});
+                        v2f *row = row0 + it * ROWSTEP * BP;                     // 16-byte aligned: one ds_write_b128
+                        row[0] = a;
+                        row[1] = b;
                     }
                 };
                 if (fv != 0) mix(std::true_type{});
