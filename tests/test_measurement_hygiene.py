@@ -31,7 +31,7 @@ def _summary(path):
 def _find(summary, kernel):
     want = kernel.replace(" ", "")
     base, args = want.split("<")[0], want.split("<")[1].rstrip(">").split(",") if "<" in want else []
-    hits = [k for k in summary if k.split("<")[0] == base and ("<" not in k or k.split("<")[1].split(",")[:len(args[:2])] == args[:2])]
+    hits = [k for k in summary if k.split("<")[0] == base and ("<" not in k or k.split("<")[1].rstrip(">").split(",")[:len(args[:2])] == args[:2])]
     assert len(hits) == 1, (kernel, sorted(summary))
     return summary[hits[0]]
 
