@@ -81,13 +81,13 @@ int  cwslg_set_scale_factors(cwslg_ctx *ctx, float scale_ft, float scale_wspr);
  *   on = 1, the DEFAULT of a new context ("exact"): the reference's own operation order (SSBD.hpp:160-183, un-fused float32,
  *           tap blocks oldest first).  The float frame, the int16 frame and therefore every candidate list equal the reference
  *           chain's (SSBD + Instance::prepareAudio + int16 conversion compiled from the reference's headers) BIT FOR BIT.
- *   on = 0  ("fast"): the fused polyphase form of the same filter (FMA, different summation order): about 1.9x the throughput;
+ *   on = 0  ("fast"): the fused polyphase form of the same filter (FMA, different summation order): about 1.5x the throughput of the whole path;
  *           float audio within 1e-5 of the frame's peak (measured 4e-7 with in-band signals; up to 6.6e-6 when the band is empty next
  *           to a strong out-of-band carrier, because the rounding noise scales with the INPUT level while the bound is relative to
  *           the frame's own peak -- DESIGN.md section 2 derives the bound); int16 samples differ by at most 1 LSB, and only where
  *           x*factor + 0.5 lies within that error of an integer; candidate lists equal the reference chain's keys except within 1e-3
  *           of a threshold, sync values within 1e-3.
- * Samples already pushed keep the mode they were pushed under.  A real-time receiver needs < 0.4 % of either mode's throughput. */
+ * Samples already pushed keep the mode they were pushed under.  A real-time receiver needs 0.3 % of either mode's throughput. */
 int  cwslg_set_exact(cwslg_ctx *ctx, int on);
 
 /* ---- receivers: replaces Receiver::init + the SPMC ring (Receiver.hpp:115-163, ring_buffer_spmc.h) ----
