@@ -312,6 +312,7 @@ int fail(cwslg_ctx *c, int code, const char *fmt, ...)
     } while (0)
 
 int sync_launch(cwslg_ctx *c, const std::vector<int> &emitted);
+int sync_ensure_channel(cwslg_ctx *c, Channel &ch);
 int long_sync_launch(cwslg_ctx *c, const std::vector<int> &emitted);
 
 WorkBuf *acquire_workbuf(cwslg_ctx *c, size_t bytes)
@@ -1625,6 +1626,10 @@ int cwslg_channel_open(cwslg_ctx *c, int rx_id, int32_t demod_hz, int usb, const
     if (id < 0) { c->chans.push_back(ch); id = (int)c->chans.size() - 1; } else c->chans[id] = ch;
     rx.channels.push_back(id);
     *ch_id = id;
+    // With the sync stage already enabled, the channel's spectra plane and result buffers are allocated NOW: left to the first emitting
+    // boundary, 4096 channels' allocations made that one cwslg_slot_boundary call take 60-75 ms (round 4's paced harness) while every
+    // receiver thread waited for the context lock.
+    if (c->sync_cfg.enabled && (c->chans[id].sync_ft8 || c->chans[id].sync_ft4)) (void)sync_ensure_channel(c, c->chans[id]);
     return CWSLG_OK;
 }
 
