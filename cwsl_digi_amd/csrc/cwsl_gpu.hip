@@ -245,6 +245,7 @@ struct cwslg_ctx {
     std::shared_mutex life_mu;         // shared: a fetch's copy is in flight; exclusive: a close frees device buffers (order: mu, then life_mu)
     BatchStage batch[kBatchStages];
     std::atomic<unsigned> batch_next{0};
+    std::atomic<uint64_t> push_calls_a{0}, push_host_ns_a{0};   // cwslg_push_iq's share of stats.push_calls / push_host_ms
     // in-kernel clock of timed exact-mode demod launches: a host-mapped ring of (s_memtime, s_memrealtime) pairs at the start and the end of
     // one workgroup's life (demod_exact3_kernel's `clk`), read back by drain_spans
     unsigned long long *clk_h = nullptr, *clk_dev = nullptr;
@@ -1290,11 +1291,9 @@ int cwslg_push_iq(cwslg_ctx *c, int rx_id, const float *iq, uint32_t n)
         if (rc) return rc;
         done += m;
     }
-    {
-        std::lock_guard<std::mutex> g(c->mu);
-        c->stats.push_calls++;
-        c->stats.push_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count();
-    }
+    // (atomics, folded into the stats when they are read: no third acquisition of the context mutex per push)
+    c->push_calls_a.fetch_add(1, std::memory_order_relaxed);
+    c->push_host_ns_a.fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_in).count(), std::memory_order_relaxed);
     return CWSLG_OK;
 }
 
@@ -2168,6 +2167,8 @@ int cwslg_get_stats(cwslg_ctx *c, cwslg_stats *out)
     if (!c || !out) return CWSLG_ERR_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     *out = c->stats;
+    out->push_calls += c->push_calls_a.load(std::memory_order_relaxed);
+    out->push_host_ms += 1e-6 * (double)c->push_host_ns_a.load(std::memory_order_relaxed);
     return CWSLG_OK;
 }
 
@@ -2178,6 +2179,7 @@ int cwslg_reset_stats(cwslg_ctx *c)
     c->stats = cwslg_stats{};
     c->stats.rccl_world = (uint64_t)c->rccl_world;
     c->clk_sum_mhz = 0.0;
+    c->push_calls_a.store(0); c->push_host_ns_a.store(0);
     return CWSLG_OK;
 }
 
