@@ -433,6 +433,7 @@ def main():
             roof["valu_pipe"] = vp
         else:
             roof["valu_tflops"] = 80.0 * spl / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+            roof["clock_mhz"] = float(st_.get("demod_clock_mhz", 0.0)) or None     # in-kernel (s_memtime / s_memrealtime), one tile workgroup in mid-launch
         return {"mode": MODE_TEXT[exact], "value": float(world) * spl * args.steps / dt_ / 1e6, "unit": "Msamples/s", "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": dt_ / args.steps * 1e3, "roofline": roof, "roofline_sync": roofline_sync(st_), "verify": ver}
 

@@ -439,7 +439,7 @@ void drain_spans(cwslg_ctx *c)
     if (!c->spans.empty()) return;         // (the clock slots below belong to launches that may still run)
     for (; c->clk_tail != c->clk_head; ++c->clk_tail) {
         const unsigned long long *q = c->clk_h + 4 * (c->clk_tail % kClkSlots);
-        if (q[0] && q[1] && q[2] > q[0] && q[3] > q[1] + 1000) {       // >= 10 us of the 100 MHz counter: a quotient worth having
+        if (q[0] && q[1] && q[2] > q[0] && q[3] > q[1] + 300) {        // >= 3 us of the 100 MHz counter (a tile workgroup of the fast kernel lives ~6 us)
             c->clk_sum_mhz += 100.0 * (double)(q[2] - q[0]) / (double)(q[3] - q[1]);
             c->stats.demod_clock_launches++;
             c->stats.demod_clock_mhz = c->clk_sum_mhz / (double)c->stats.demod_clock_launches;
@@ -694,8 +694,14 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
         }
     } else if (!launched) {
         c->demod_kernel_name = D == 16 ? "demod_kernel<16,256,256,0>" : D == 8 ? "demod_kernel<8,256,256,0>" : "demod_kernel<4,256,256,0>";
+        unsigned long long *clk = nullptr;
+        if (c->timing && c->clk_dev && c->clk_head - c->clk_tail < kClkSlots) {
+            const unsigned slot = c->clk_head++ % kClkSlots;
+            std::memset(c->clk_h + 4 * slot, 0, 4 * sizeof(unsigned long long));
+            clk = c->clk_dev + 4 * slot;
+        }
         hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, 0>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
-                           c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
+                           c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size(), clk);
     }
     span_end(c, eb);
     HIPCHK(c, hipGetLastError());

@@ -455,7 +455,7 @@ __device__ __forceinline__ void issue_tile_loads(const TileCtx<D, T> &c, int tid
 template <int D, int T, int NT, int MODE>
 __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const ChanWork *__restrict__ works,
                                                                      const float *__restrict__ taps,
-                                                                     int tiles_x, int n_ch)
+                                                                     int tiles_x, int n_ch, unsigned long long *__restrict__ clk = nullptr)
 {
     using Geo = DemodGeom<D, T>;
     constexpr bool PERSIST = (MODE == 1);       // in-place prefetch of the next item
@@ -497,6 +497,15 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
     const int k = lane % GL;                    // this lane's branch pair (2k, 2k+1)
     int item = xcd * per_xcd + slot;
     if (item >= hi_item) return;
+    // The shader clock in the middle of a timed launch (cwslg_set_timing): ONE workgroup, the one in the middle of the grid, reads s_memtime and
+    // s_memrealtime when it starts and when it ends (see demod_exact3_kernel); untimed launches pass clk = nullptr and execute none of it.
+    const bool clk_wg = clk != nullptr && blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0;
+    if (clk_wg) {
+        unsigned long long t_, r_;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");
+        as_global_rw(clk)[0] = t_;
+        as_global_rw(clk)[1] = r_;
+    }
     float2 tap[16];                             // H[2k][v], H[2k+1][v] = h[G*v + 2k], h[G*v + 2k + 1]
 #pragma unroll
     for (int v = 0; v < 16; ++v) tap[v] = *reinterpret_cast<const float2 *>(taps + G * v + 2 * k);
@@ -749,6 +758,12 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
         stamp_on = (stamp_iter == 100);
         STAMP(0); STAMP(7); STAMP(1);
 #endif
+    }
+    if (clk_wg) {
+        unsigned long long t_, r_;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");
+        as_global_rw(clk)[2] = t_;
+        as_global_rw(clk)[3] = r_;
     }
 }
 

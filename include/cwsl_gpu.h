@@ -371,9 +371,10 @@ typedef struct {
     uint64_t rccl_world;           /* ranks of the built-in RCCL communicator (cwslg_rccl_init), 0 without one */
     uint64_t rendezvous_flags_and; /* AND over all ranks of cwslg_set_rendezvous_flag's value at the last built-in rendezvous */
     /* ABI 4 */
-    double   demod_clock_mhz;      /* shader clock INSIDE the timed exact-mode demod launches since the last reset: mean over launches of
-                                    * delta s_memtime / delta s_memrealtime x 100 MHz, read by one workgroup at the start and the end of its
-                                    * life (0 until a timed launch has been drained).  What bench.py prices roofline.valu_pipe at.        */
+    double   demod_clock_mhz;      /* shader clock INSIDE the timed demod launches since the last reset: mean over launches of delta s_memtime /
+                                    * delta s_memrealtime x 100 MHz, read by one workgroup at the start and the end of its life (exact mode: a
+                                    * persistent workgroup, i.e. the whole launch; fast mode: the tile workgroup in the middle of the grid;
+                                    * 0 until a timed launch has been drained).  What bench.py prices roofline.valu_pipe at.              */
     uint64_t demod_clock_launches; /* launches that contributed to it                                                                 */
     uint64_t push_calls;           /* host pushes accepted (cwslg_push_iq: one per call; cwslg_push_iq_many: one per receiver)         */
     uint64_t push_batches;         /* cwslg_push_iq_many calls                                                                        */
