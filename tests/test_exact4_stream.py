@@ -27,7 +27,7 @@ def _lines(text, macro):
     return re.findall(r'"([^"\\]*)\\n\\t"', body)
 
 
-def _problem(seed, row_bytes):
+def _problem(seed, row_bytes, D=D):
     """A lane's window: 33 blocks of D mixed samples + block phases in the two parity arrays, the interleaved tap table, and the reference bits."""
     rng = np.random.default_rng(seed)
     t = (rng.standard_normal((33, D, 2)) * 1000).astype(F)            # t[n][m] = in[m] * tone[m] of block o + n
@@ -63,12 +63,14 @@ def _problem(seed, row_bytes):
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
-def test_exact3_stream_on_the_emulator_validates_it(seed):
+@pytest.mark.parametrize("d", [16, 8, 4])
+def test_exact3_stream_on_the_emulator_validates_it(seed, d):
+    """All three decimations' streams (192 / 96 / 48 kHz; the 96 and 48 kHz ones are the product's exact kernels at those rates)."""
     text = _gen("gen_exact3_asm.py")
-    row_bytes = (D + 2) * 8
-    lds, taps2, want = _problem(seed, row_bytes)
+    row_bytes = (d + 2) * 8
+    lds, taps2, want = _problem(seed, row_bytes, d)
     lane = Lane(lds.tobytes(), taps2.tobytes(), r0=0, r1=lds[0].nbytes)
-    got = lane.run(_lines(text, "EXACT3_FIR16_ASM"))
+    got = lane.run(_lines(text, "EXACT3_FIR%d_ASM" % d))
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (got, want)
 
 
