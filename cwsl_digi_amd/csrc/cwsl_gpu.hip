@@ -50,7 +50,12 @@ namespace cwslg {
 constexpr int kTile = 256;             // outputs per demod workgroup
 constexpr int kTileExact = 512;        // ... of demod_exact3_kernel (two outputs per thread, 256 threads; two tiles of 72.5 KB per CU)
 constexpr int kExactThreads = kTileExact / 2;
-constexpr int kTileMax = 512;          // the largest tile any demod kernel walks a channel with (sizes the phasor checkpoint tables)
+constexpr int kTileMax = 768;          // the largest tile any demod kernel walks a channel with (sizes the phasor checkpoint tables)
+// Fast mode: outputs per workgroup by decimation.  A tile is D (T + 31) samples, so a fixed T = 256 makes the tiles of the lower rates small
+// (48 kHz: 9 KB, 360 000 workgroups per 512-slot launch) and the launch dispatch-bound: round 4 measured demod_kernel<4, 256> at 2.03 ms per
+// 512 slots -- SLOWER than the exact kernel's 1.44 ms -- and <8, 256> at 2.17 ms.  T grows as D shrinks (the same ~37 KB of IQ per tile at
+// 96 kHz; 768 at 48 kHz, where one checkpoint per lane caps the tile at 256 lanes x 4 blocks).
+constexpr int fast_tile(int D) { return D == 16 ? 256 : D == 8 ? 512 : 768; }
 constexpr int kTileExact2 = 248;       // ... of demod_exact2_kernel, lab build (124 of 128 lanes busy; four tiles of 39.7 KB per CU)
 constexpr int kDemodThreads = 256;
 constexpr int kFinThreads = 256;
@@ -568,8 +573,9 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     HIPCHK(c, upload_workbuf(c, w, ctr_off + 64));
     // product build: ONE kernel per job -- demod_exact3_kernel in exact mode (the default), demod_kernel in fast mode.  The measured
     // alternatives (CWSLG_DEMOD_VARIANT) exist in the lab build only (-DCWSLG_LAB=1 -> libcwslgpu_lab.so).
-    int tile = c->exact ? kTileExact : kTile;
+    int tile = c->exact ? kTileExact : fast_tile(D);
 #if CWSLG_LAB
+    if (!c->exact && c->demod_variant != 0) tile = kTile;                       // the measured alternatives of the fast kernel all walk 256-output tiles
     const bool small_tile = !c->exact && c->demod_variant == 15 && D == 16;     // 192-output tiles: 31 KB of LDS, five workgroups per CU
     if (c->exact && c->demod_variant == 20) tile = kTile;                       // round 1's exact kernel: one output per thread
     if (c->exact && c->demod_variant == 21) tile = kTileExact2;
@@ -693,14 +699,14 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
 #endif
         }
     } else if (!launched) {
-        c->demod_kernel_name = D == 16 ? "demod_kernel<16,256,256,0>" : D == 8 ? "demod_kernel<8,256,256,0>" : "demod_kernel<4,256,256,0>";
+        c->demod_kernel_name = D == 16 ? "demod_kernel<16,256,256,0>" : D == 8 ? "demod_kernel<8,512,256,0>" : "demod_kernel<4,768,256,0>";
         unsigned long long *clk = nullptr;
         if (c->timing && c->clk_dev && c->clk_head - c->clk_tail < kClkSlots) {
             const unsigned slot = c->clk_head++ % kClkSlots;
             std::memset(c->clk_h + 4 * slot, 0, 4 * sizeof(unsigned long long));
             clk = c->clk_dev + 4 * slot;
         }
-        hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, 0>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
+        hipLaunchKernelGGL((demod_kernel<D, fast_tile(D), kDemodThreads, 0>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
                            c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size(), clk);
     }
     span_end(c, eb);

@@ -469,6 +469,7 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
     constexpr int NIT = (Geo::NSAMP + 2 * NT - 1) / (2 * NT);
     static_assert(GL <= 16 && T % (32 * CPW) == 0 && (2 * NT) % D == 0, "geometry");
     static_assert(kDescWords <= 64 && NT >= 128, "descriptor staging uses one wave");
+    static_assert(Geo::NCK <= NT, "phase 0: one phasor checkpoint per lane");
 
     __shared__ __attribute__((aligned(16))) float s_plane[2 * Geo::PLANE_FLOATS];
     __shared__ __attribute__((aligned(16))) float s_aux[Geo::AUX_FLOATS];
