@@ -17,6 +17,7 @@ timeout 600 python bench.py --slots 64 --steps 20 --warmup 5 --no-cpu-baseline >
 timeout 600 python bench.py --channels-per-rx 128 --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_shared_32x128.json 2> $O/bench_shared_32x128.err
 timeout 300 python bench.py --gpus 2 --same-device --dist-backend gloo --slots 512 --steps 5 --warmup 2 --no-cpu-baseline --verify 2 > $O/bench_2ranks_1gpu.json 2> $O/bench_2ranks_1gpu.err
 timeout 120 scripts/micro/pk_issue > $O/pk_issue.txt 2>&1
+timeout 300 python3 scripts/gpu_rates_exact.py > $O/rates.json 2> $O/rates.err      # both modes at 48 / 96 / 192 kHz, 512 slots, demod launch only
 RT=cwsl_digi_amd/bin/cwsl_gpu_realtime
 timeout 300 $RT --receivers 32 --channels-per-rx 128 --speed 1 --slots 3 --mode threads > $O/rt_32x128_x1.json 2> $O/rt_32x128_x1.err
 timeout 300 $RT --receivers 32 --channels-per-rx 128 --speed 8 --slots 3 --mode threads > $O/rt_32x128_x8.json 2> $O/rt_32x128_x8.err
