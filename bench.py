@@ -379,12 +379,13 @@ def main():
                         fabric, src = tj.get("fabric_bytes_per_boundary"), "replayed: " + tj.get("source", "")
             except Exception:
                 pass
-        # each kernel against ITS bound: the spectra kernel is FP32 work (VALU-bound); the Costas search re-reads its band image from LDS 63 x
-        # 8 bytes per lane and bin (42 Costas terms + 21 seven-tone sums, two adjacent lags per lane) and is LDS-bandwidth-/latency-bound
+        # each kernel against the resource it leans on: the spectra kernel is FP32 work (VALU-bound); the Costas search re-reads its band image
+        # from LDS 63 x 8 bytes per lane and bin (42 Costas terms + 21 seven-tone sums, two adjacent lags per lane) -- reported against the LDS
+        # read bandwidth, which it does NOT saturate: its wall is the per-wave dependency chain
         nl = max(1, st_["sync_launches"])
         sp_ms, se_ms = st_.get("sync_spectra_ms", 0.0) / nl, st_.get("sync_search_ms", 0.0) / nl
         lds_bytes = float(S) * nsearch * 64 * 63 * 8
-        lds_peak_tbs = n_cu * 128 * 2.4e9 / 1e12                                   # 128 B / clk / CU at the 2.4 GHz peak clock
+        lds_peak_tbs = n_cu * 256 * 2.4e9 / 1e12                                   # ds_read_b64: 256 B / clk / CU (MI355X_MICROARCH.md, LDS) at the 2.4 GHz peak clock
         per_kernel = None
         if sp_ms > 0 and se_ms > 0:
             per_kernel = {"spectra": {"avg_ms": sp_ms, "bound": "valu", "achieved_tflops": 372 * per_transform * S / (sp_ms * 1e-3) / 1e12,
