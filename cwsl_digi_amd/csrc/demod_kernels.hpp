@@ -86,6 +86,11 @@ constexpr int kCk = 4;
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
+// A complex value at an HBM address taken from a launch descriptor, through the global address space (global_load / global_store: a generic
+// pointer makes a flat_ access, which also counts in lgkmcnt and waits with the LDS traffic).  HIP's float2 is a struct and cannot be copied
+// through an address-space-qualified pointer, hence the detour over the 8-byte vector type.
+__device__ __forceinline__ float2 gld2(const float2 *p) { const v2f t = *as_global(reinterpret_cast<const v2f *>(p)); return make_float2(t.x, t.y); }
+__device__ __forceinline__ void gst2(float2 *p, float2 v) { *as_global_rw(reinterpret_cast<v2f *>(p)) = v2f{v.x, v.y}; }
 
 // One entry per active channel per demod launch.
 struct alignas(16) ChanWork {
@@ -179,7 +184,7 @@ __global__ void phasor_coarse_kernel(const PhasorJob *__restrict__ jobs, int n_j
     const PhasorJob job = jobs[j];
     float2 p = job.start;                               // (1, 0): SSBD.hpp:121
     for (unsigned c = 0; c < job.n_ckpt; c += kCoarse) {
-        job.ckpt[c] = p;
+        gst2(job.ckpt + c, p);
         for (int s = 0; s < kCoarse * kCk; ++s) p = cmul_exact(p, job.inc);
     }
 }
@@ -191,11 +196,11 @@ __global__ void phasor_fine_kernel(const PhasorJob *__restrict__ jobs)
     const unsigned seg = blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned c0 = seg * kCoarse;
     if (c0 >= job.n_ckpt) return;
-    float2 p = job.ckpt[c0];
+    float2 p = gld2(job.ckpt + c0);
     for (unsigned c = c0 + 1; c < c0 + kCoarse && c < job.n_ckpt; ++c) {
 #pragma unroll
         for (int s = 0; s < kCk; ++s) p = cmul_exact(p, job.inc);
-        job.ckpt[c] = p;
+        gst2(job.ckpt + c, p);
     }
 }
 

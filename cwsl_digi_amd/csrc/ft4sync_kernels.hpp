@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void ft4_dft567_mfma_kernel(const Ft4Work *__r
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         const int cr = c0 + (v & 3) + 8 * (v >> 2) + 4 * h;
-        if (cr < F4C_NA) w->y[cr * 64 + rev6(b)] = cmul_f(make_float2(yr[v], yi[v]), tb.wn2[b * cr]);
+        if (cr < F4C_NA) gst2(w->y + cr * 64 + rev6(b), cmul_f(make_float2(yr[v], yi[v]), tb.wn2[b * cr]));
     }
 }
 
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(64) void ft4_fft64_unpack_kernel(const Ft4Work *__r
     const Ft4Work *w = works + blockIdx.y;
     const int p = blockIdx.x, lane = threadIdx.x;             // rows p and 567 - p (p = 0: row 0 alone)
     const int c0 = p, c1 = (p == 0) ? 0 : F4C_NA - p;
-    s_r[0][lane] = w->y[c0 * 64 + lane];
-    s_r[1][lane] = w->y[c1 * 64 + lane];
+    s_r[0][lane] = gld2(w->y + c0 * 64 + lane);
+    s_r[1][lane] = gld2(w->y + c1 * 64 + lane);
     if (lane < 32) s_w64[lane] = tb.w64[lane];
     wave_sync_lds();
     for (int len = 2; len <= 64; len <<= 1) {
@@ -179,20 +179,20 @@ __global__ __launch_bounds__(64) void ft4_fft64_unpack_kernel(const Ft4Work *__r
     }
     // Z[c + 567 d] = row_c[d];  N2 - (c + 567 d) = (567 - c) + 567 (63 - d)   (c > 0)
     const int d = lane;
-    float2 *cx = w->cx;
+    float2 *cx = w->cx;          // (stored through gst2: HBM address)
     if (p > 0) {
         const int k0 = c0 + F4C_NA * d, k1 = c1 + F4C_NA * d;
         float2 B = s_r[1][63 - d]; B.y = -B.y;
-        cx[k0] = unpack_bin(s_r[0][d], B, tb.w2n[k0]);
+        gst2(cx + (k0), unpack_bin(s_r[0][d], B, tb.w2n[k0]));
         B = s_r[0][63 - d]; B.y = -B.y;
-        cx[k1] = unpack_bin(s_r[1][d], B, tb.w2n[k1]);
+        gst2(cx + (k1), unpack_bin(s_r[1][d], B, tb.w2n[k1]));
     } else {
         const int k0 = F4C_NA * d;
         float2 B = s_r[0][(64 - d) & 63]; B.y = -B.y;         // d = 0 pairs with itself
-        cx[k0] = unpack_bin(s_r[0][d], B, tb.w2n[k0]);
+        gst2(cx + (k0), unpack_bin(s_r[0][d], B, tb.w2n[k0]));
         if (d == 0) {                                         // k = N2: Z[0] with conj(Z[0])
             float2 B0 = s_r[0][0]; B0.y = -B0.y;
-            cx[F4C_N2] = unpack_bin(s_r[0][0], B0, tb.w2n[F4C_N2]);
+            gst2(cx + (F4C_N2), unpack_bin(s_r[0][0], B0, tb.w2n[F4C_N2]));
         }
     }
 }
@@ -270,10 +270,10 @@ __global__ __launch_bounds__(256) void ft4_refine_kernel(const Ft4Work *__restri
     __shared__ unsigned long long s_key[4];
     const Ft4Work *w = works + blockIdx.y;
     const int cand = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    int ncand = *w->ncand;
+    int ncand = *as_global(w->ncand);
     if (ncand > max_cand) ncand = max_cand;
     if (cand >= ncand) return;                      // workgroup-uniform
-    const float f0 = w->cand[cand].freq_hz;
+    const float f0 = as_global(w->cand)[cand].freq_hz;
     const float df = 12000.0f / (float)F4C_NMAX;
     const int i0 = (int)lroundf(f0 / df);
 
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void ft4_refine_kernel(const Ft4Work *__restri
         float2 v = make_float2(0.f, 0.f);
         const int idx = i0 + k;
         if (k >= F4C_KLO && k <= F4C_KHI && idx >= 0 && idx <= F4C_N2) {
-            const float2 x = w->cx[idx];
+            const float2 x = gld2(w->cx + idx);
             const float wk = tb.win[k - F4C_KLO];
             v = make_float2((x.x * wk) / 4032.0f, (x.y * wk) / 4032.0f);
         }
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void ft4_refine_kernel(const Ft4Work *__restri
         }
         __syncthreads();
         if (cand == 0 && w->cd_dbg)
-            for (int m = tid; m < F4C_NP; m += 256) w->cd_dbg[m] = s_cd[m & 3][m >> 2];
+            for (int m = tid; m < F4C_NP; m += 256) gst2(w->cd_dbg + m, s_cd[m & 3][m >> 2]);
     }
     // ---- the search of ft4_decode: 3 segments x (coarse, fine)
     F4Cd cd{s_cd};
@@ -399,14 +399,13 @@ __global__ __launch_bounds__(256) void ft4_refine_kernel(const Ft4Work *__restri
         const float f1 = f0 + (float)idfbest;
         if (f1 <= 10.0f || f1 >= 4990.0f) continue;
         if (tid == 0) {
-            Ft4Rec r;
-            r.f0_hz = f0; r.f1_hz = f1; r.dt_s = (float)ibest / 666.67f - 0.5f; r.sync = smax;
-            r.ibest = ibest; r.idf = idfbest; r.seg = iseg; r.cand = cand;
-            w->rec[cand * 3 + nrec] = r;
+            CWSLG_GLOBAL Ft4Rec *r = as_global_rw(w->rec) + (cand * 3 + nrec);
+            r->f0_hz = f0; r->f1_hz = f1; r->dt_s = (float)ibest / 666.67f - 0.5f; r->sync = smax;
+            r->ibest = ibest; r->idf = idfbest; r->seg = iseg; r->cand = cand;
         }
         ++nrec;
     }
-    if (tid == 0) w->nrec[cand] = nrec;
+    if (tid == 0) as_global_rw(w->nrec)[cand] = nrec;
 }
 
 }  // namespace cwslg

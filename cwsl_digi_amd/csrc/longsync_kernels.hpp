@@ -115,7 +115,7 @@ __global__ __launch_bounds__(FFTB_S1_NT, 4) void fftb_stage1_kernel(const LongWo
         }
 #pragma unroll
         for (int j = 0; j < CB; ++j)
-            yout[(size_t)(c0 + j) * NB + b] = lcmul(make_float2(P[j] - Q[j], R[j] + S[j]), tb.wn[b * (c0 + j)]);
+            gst2(yout + (size_t)(c0 + j) * NB + b, lcmul(make_float2(P[j] - Q[j], R[j] + S[j]), tb.wn[b * (c0 + j)]));
     }
 }
 
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * ((NA + 31) / 32)) void fftb_stage1_mfma_kernel
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         const int cr = c0 + (v & 3) + 8 * (v >> 2) + 4 * h;
-        if (cr < NA) yout[(size_t)cr * NB + b] = lcmul(make_float2(P[v] - Q[v], R[v] + S[v]), tb.wn[b * cr]);
+        if (cr < NA) gst2(yout + (size_t)cr * NB + b, lcmul(make_float2(P[v] - Q[v], R[v] + S[v]), tb.wn[b * cr]));
     }
 }
 
@@ -301,8 +301,8 @@ __global__ __launch_bounds__(256) void wspr_combine_kernel(const LongWork *__res
         float2 A[16], B[16];
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
-            A[p] = w->y[(size_t)p * WSPR_M + (size_t)c * 1024 + d];
-            B[p] = w->y[(size_t)p * WSPR_M + (size_t)cm * 1024 + dm];
+            A[p] = gld2(w->y + (size_t)p * WSPR_M + (size_t)c * 1024 + d);
+            B[p] = gld2(w->y + (size_t)p * WSPR_M + (size_t)cm * 1024 + dm);
         }
         const float2 *Tc = T + (size_t)c * 1024 + d;
         float fr = 0.0f, fi = 0.0f;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void wspr_combine_kernel(const LongWork *__res
             const float2 tt = lcmul(Y, Tc[(size_t)(p + 16) * WSPR_M]);
             fr = fr + tt.x; fi = fi + tt.y;
         }
-        w->aux[c + 45 * d] = make_float2(fr, -fi);
+        gst2(w->aux + c + 45 * d, make_float2(fr, -fi));
     }
 }
 
@@ -330,10 +330,10 @@ __global__ __launch_bounds__(256) void wspr_iq_kernel(const LongWork *__restrict
     if (i >= WSPR_IQ_LEN) return;
     float2 o = make_float2(0.f, 0.f);
     if (i < WSPR_M) {
-        const float2 zc = (w->aux + WSPR_M)[(size_t)(i % 45) * 1024 + i / 45];
+        const float2 zc = gld2(w->aux + WSPR_M + (size_t)(i % 45) * 1024 + i / 45);
         o = make_float2((float)((double)zc.x / 1000.0), (float)((double)(-zc.y) / 1000.0));
     }
-    w->iq[i] = o;
+    gst2(w->iq + i, o);
 }
 
 // 359 windowed 512-point spectra.  grid (359, channels), 256 threads.  ps/sq stored time-major [i][j].
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void wspr_spectra_kernel(const LongWork *__res
     const int i = blockIdx.x, tid = threadIdx.x;
     s_w[tid] = w512[tid];
     for (int j = tid; j < 512; j += 256) {
-        const float2 v = w->iq[i * 128 + j];
+        const float2 v = gld2(w->iq + i * 128 + j);
         const float wj = win[j];
         s_r[__brev((unsigned)j) >> 23] = make_float2(v.x * wj, v.y * wj);
     }
@@ -363,8 +363,8 @@ __global__ __launch_bounds__(256) void wspr_spectra_kernel(const LongWork *__res
     for (int j = tid; j < 512; j += 256) {
         const float2 v = s_r[(j + 256) & 511];
         const float p = v.x * v.x + v.y * v.y;
-        w->ps[(size_t)i * 512 + j] = p;
-        w->sq[(size_t)i * 512 + j] = sqrtf(p);
+        as_global_rw(w->ps)[(size_t)i * 512 + j] = p;
+        as_global_rw(w->sq)[(size_t)i * 512 + j] = sqrtf(p);
     }
 }
 
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(512) void wspr_peaks_kernel(const LongWork *__restr
     const int tid = threadIdx.x;
     {
         float s = 0.0f;
-        for (int i = 0; i < WSPR_NFFTS; ++i) s = s + w->ps[(size_t)i * 512 + tid];
+        for (int i = 0; i < WSPR_NFFTS; ++i) s = s + as_global(w->ps)[(size_t)i * 512 + tid];
         s_avg[tid] = s;
     }
     __syncthreads();
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(512) void wspr_peaks_kernel(const LongWork *__restr
         if (sm < min_snr) sm = (float)(0.1 * (double)min_snr);
     }
     __syncthreads();
-    if (tid < 411) { s_sm[tid] = sm; w->vec[tid] = sm; }
+    if (tid < 411) { s_sm[tid] = sm; as_global_rw(w->vec)[tid] = sm; }
     __syncthreads();
     const float df = 0.732421875f;                       // 375/256/2
     int flag = 0;
@@ -451,11 +451,10 @@ __global__ __launch_bounds__(512) void wspr_peaks_kernel(const LongWork *__restr
         const float v = s_snr[tid];
         int rank = 0;
         for (int x = 0; x < npk; ++x) { const float o = s_snr[x]; rank += (o > v || (o == v && x < tid)) ? 1 : 0; }
-        WsprCand c;
-        c.freq_hz = s_f[tid]; c.snr_db = v; c.drift = 0.0f; c.sync = 0.0f; c.shift = 0;
-        reinterpret_cast<WsprCand *>(w->cand)[rank] = c;
+        CWSLG_GLOBAL WsprCand *c = as_global_rw(reinterpret_cast<WsprCand *>(w->cand)) + rank;
+        c->freq_hz = s_f[tid]; c->snr_db = v; c->drift = 0.0f; c->sync = 0.0f; c->shift = 0;
     }
-    if (tid == 0) *w->ncand = npk;
+    if (tid == 0) *as_global_rw(w->ncand) = npk;
 }
 
 // Coarse (freq, shift, drift) search of one candidate.  grid (WSPR_MAXCAND, channels), 256 threads: 5 x 32 x 9 = 1440 combinations,
@@ -467,8 +466,8 @@ __global__ __launch_bounds__(256) void wspr_coarse_kernel(const LongWork *__rest
     __shared__ float s_sq[WSPR_NFFTS * 20];
     const LongWork *w = works + blockIdx.y;
     const int j = blockIdx.x, tid = threadIdx.x;
-    if (j >= *w->ncand) return;
-    WsprCand *cand = reinterpret_cast<WsprCand *>(w->cand) + j;
+    if (j >= *as_global(w->ncand)) return;
+    CWSLG_GLOBAL WsprCand *cand = as_global_rw(reinterpret_cast<WsprCand *>(w->cand)) + j;
     if (tid < 162) s_sgn[tid] = (float)(2 * (int)pr3[tid] - 1);
     __syncthreads();
     const float df = 0.732421875f;
@@ -478,7 +477,7 @@ __global__ __launch_bounds__(256) void wspr_coarse_kernel(const LongWork *__rest
     const int jb = if0 - 10;
     for (int e = tid; e < WSPR_NFFTS * 20; e += 256) {
         const int ii = e / 20, jc = e - ii * 20, jj = jb + jc;
-        s_sq[e] = (jj >= 0 && jj < 512) ? w->sq[(size_t)ii * 512 + jj] : 0.0f;
+        s_sq[e] = (jj >= 0 && jj < 512) ? as_global(w->sq)[(size_t)ii * 512 + jj] : 0.0f;
     }
     __syncthreads();
     unsigned long long best = 0ull;
@@ -573,13 +572,13 @@ __global__ __launch_bounds__(256) void fst4w_band_kernel(const LongWork *__restr
     float fr = 0.0f, fi = 0.0f;
     for (int a = 0; a < F4W_R; ++a) {
         const int p = (a < 22) ? a : (a < 44 ? a - 22 : 22);
-        const float2 A = w->y[(size_t)p * F4W_M + (size_t)c * 256 + d], B = w->y[(size_t)p * F4W_M + (size_t)cm * 256 + dm];
+        const float2 A = gld2(w->y + (size_t)p * F4W_M + (size_t)c * 256 + d), B = gld2(w->y + (size_t)p * F4W_M + (size_t)cm * 256 + dm);
         const bool second = a >= 22 && a < 44;
         const float2 Y = second ? make_float2((A.y + B.y) * 0.5f, (B.x - A.x) * 0.5f) : make_float2((A.x + B.x) * 0.5f, (A.y - B.y) * 0.5f);
         const float2 tt = lcmul(Y, Tc[(size_t)a * (125 * F4W_TP)]);
         fr = fr + tt.x; fi = fi + tt.y;
     }
-    w->aux[k - jlo] = make_float2(fr, fi);
+    gst2(w->aux + (k - jlo), make_float2(fr, fi));
 }
 
 struct Fst4wParams { int ina, inb, ia, ib, ndh, jlo, nnw; float df1, df2, minsync; };
@@ -600,7 +599,7 @@ __global__ __launch_bounds__(512) void fst4w_cand_kernel(const LongWork *__restr
         const int j0 = (int)lroundf((float)i * P.df2 / P.df1);
         float acc = 0.0f;
         for (int j = j0 - P.ndh; j <= j0 + P.ndh; ++j) {
-            const float2 v = w->aux[j - P.jlo];
+            const float2 v = gld2(w->aux + (j - P.jlo));
             acc = acc + v.x * v.x + v.y * v.y;
         }
         s_s[i - lo] = acc;
@@ -612,7 +611,7 @@ __global__ __launch_bounds__(512) void fst4w_cand_kernel(const LongWork *__restr
     for (int i = ina + tid; i <= inb; i += 512) s_s2[i - lo] = s_s[i - 3 - lo] + s_s[i - 1 - lo] + s_s[i + 1 - lo] + s_s[i + 3 - lo];
     __syncthreads();
     const int plo = ina + 3, npts = inb - ina + 1 - 6;
-    if (npts < 1) { if (tid == 0) *w->ncand = 0; return; }
+    if (npts < 1) { if (tid == 0) *as_global_rw(w->ncand) = 0; return; }
     int jp = (int)lroundf((float)npts * 0.01f * 30.0f);
     if (jp < 1) jp = 1;
     if (jp > npts) jp = npts;
@@ -628,13 +627,13 @@ __global__ __launch_bounds__(512) void fst4w_cand_kernel(const LongWork *__restr
     __syncthreads();
     for (int i = tid; i < P.nnw; i += 512) {             // the normalised comb spectrum, for the parity tests
         const int l = i - lo;
-        w->vec[i] = (l >= 0 && l < width) ? s_s2[l] : 0.0f;
+        as_global_rw(w->vec)[i] = (l >= 0 && l < width) ? s_s2[l] : 0.0f;
     }
     int ia = P.ia, ib = P.ib;
     if (ia < 3) ia = 3;
     if (ib > P.nnw - 2) ib = P.nnw - 2;
     const float xdb[7] = {0.25f, 0.50f, 0.75f, 1.0f, 0.75f, 0.50f, 0.25f};
-    Fst4wCand *out = reinterpret_cast<Fst4wCand *>(w->cand);
+    CWSLG_GLOBAL Fst4wCand *out = as_global_rw(reinterpret_cast<Fst4wCand *>(w->cand));
     int ncand = 0;
     while (ncand < F4W_MAXCAND) {
         unsigned long long best = 0ull;
@@ -662,11 +661,11 @@ __global__ __launch_bounds__(512) void fst4w_cand_kernel(const LongWork *__restr
                 s_s2[k - lo] = (v > 0.0f) ? v : 0.0f;
             }
         }
-        if (tid == 0) { Fst4wCand c; c.freq_hz = P.df2 * (float)ip; c.snr = pval; c.bin = ip; c.pad_ = 0; out[ncand] = c; }
+        if (tid == 0) { CWSLG_GLOBAL Fst4wCand *c = out + ncand; c->freq_hz = P.df2 * (float)ip; c->snr = pval; c->bin = ip; c->pad_ = 0; }
         ++ncand;
         __syncthreads();
     }
-    if (tid == 0) *w->ncand = ncand;
+    if (tid == 0) *as_global_rw(w->ncand) = ncand;
 }
 
 } // namespace cwslg

@@ -1098,8 +1098,8 @@ __global__ __launch_bounds__(SYNC2D_NT, 4) void ft8_sync2d_v2_kernel(const SyncW
             float r1; int l1;
             wave_first_max(b1 ? nb : na, b1 ? j + 1 : j, r1, l1);
             if (lane == 0) {
-                w->red[bin] = r1;  w->jpeak[bin] = l1;
-                w->red2[bin] = r2; w->jpeak2[bin] = l2;
+                as_global_rw(w->red)[bin] = r1;  as_global_rw(w->jpeak)[bin] = l1;
+                as_global_rw(w->red2)[bin] = r2; as_global_rw(w->jpeak2)[bin] = l2;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();               // c0 is rewritten by the next bin
@@ -1182,8 +1182,8 @@ __device__ __forceinline__ void sync2d_search_band(const SyncWork *w, unsigned s
         float r1; int l1;
         wave_first_max(b1 ? nb : na, b1 ? j + 1 : j, r1, l1);
         if (lane == 0) {
-            w->red[bin] = r1;  w->jpeak[bin] = l1;
-            w->red2[bin] = r2; w->jpeak2[bin] = l2;
+            as_global_rw(w->red)[bin] = r1;  as_global_rw(w->jpeak)[bin] = l1;       // (HBM addresses: global_store, not flat_store)
+            as_global_rw(w->red2)[bin] = r2; as_global_rw(w->jpeak2)[bin] = l2;
         }
         if (rr == rr0) SSTAMP(5);
         rr = rn;
@@ -1300,7 +1300,7 @@ __device__ void ft8_candidates_body(const SyncWork *w, int ia, int ib, float syn
     const int iz = ib - ia + 1;
     const float df = 12000.0f / 3840.0f, tstep = 480.0f / 12000.0f;
     for (int i = ia + tid; i <= ib; i += NT) {
-        s_red[i] = w->red[i]; s_red2[i] = w->red2[i]; s_jp[i] = (short)w->jpeak[i]; s_jp2[i] = (short)w->jpeak2[i];
+        s_red[i] = as_global(w->red)[i]; s_red2[i] = as_global(w->red2)[i]; s_jp[i] = (short)as_global(w->jpeak)[i]; s_jp2[i] = (short)as_global(w->jpeak2)[i];
     }
     for (int i = tid; i < FT8_NH1 + 2; i += NT) { s_first[i] = -1; s_second[i] = -1; }
     const int npct = (int)lroundf(0.40f * (float)iz);
@@ -1320,7 +1320,7 @@ __device__ void ft8_candidates_body(const SyncWork *w, int ia, int ib, float syn
     if (tid == 0 && npct >= 1) s_base[0] = s_red[s_ki[npct - 1]];
     for (int r = tid; r < lim; r += NT) s_desc[r] = s_ki[iz - 1 - r];
     __syncthreads();
-    if (npct < 1) { if (tid == 0) *w->ncand = 0; return; }
+    if (npct < 1) { if (tid == 0) *as_global_rw(w->ncand) = 0; return; }
     const float base = s_base[0], base2 = s_base[1];
     for (int i = ia + tid; i <= ib; i += NT) { s_red[i] = s_red[i] / base; s_red2[i] = s_red2[i] / base2; }
     __syncthreads();
@@ -1472,16 +1472,15 @@ __device__ void ft8_candidates_body(const SyncWork *w, int ia, int ib, float syn
         ++nout;
         if (r < maxcand) {
             const int i = (int)(s_lo[r] & 0xFFFu);
-            SyncChannelBuffers::Cand c;
-            c.freq_bin = s_cbin[i]; c.time_step = s_clag[i]; c.sync = s_csync[i]; c.freq_hz = s_cf[i]; c.dt_s = s_ct[i];
-            w->cand[r] = c;
+            CWSLG_GLOBAL SyncChannelBuffers::Cand *c = as_global_rw(w->cand) + r;
+            c->freq_bin = s_cbin[i]; c->time_step = s_clag[i]; c->sync = s_csync[i]; c->freq_hz = s_cf[i]; c->dt_s = s_ct[i];
         }
     }
     if (tid == 0) s_n = 0;
     __syncthreads();
     if (nout) atomicAdd(&s_n, nout);
     __syncthreads();
-    if (tid == 0) *w->ncand = min(s_n, maxcand);
+    if (tid == 0) *as_global_rw(w->ncand) = min(s_n, maxcand);
 }
 
 // grid (n_channels), NT threads: the candidate selection as its own launch (behind ft8_sync2d_v3_kernel; ft8_sync_chan_kernel runs the same body itself).
