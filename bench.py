@@ -204,16 +204,34 @@ def main():
     S = args.slots if args.slots > 0 else 4096
     ctx = P.Context(local_rank)
     rendezvous = None
+    builtin_failed = None
     if world > 1:
         rendezvous = args.rendezvous
         if rendezvous == "auto":
             rendezvous = "builtin" if (args.dist_backend == "nccl" and not args.same_device) else "torch"
         if rendezvous == "builtin":
             # the library's own RCCL communicator: rank 0 makes the ncclUniqueId, torch.distributed only carries its 128 bytes
-            box = [P.rccl_unique_id() if rank == 0 else None]
+            try:
+                box = [P.rccl_unique_id() if rank == 0 else b""]
+            except Exception as e:                  # noqa: BLE001 -- reported below, on every rank
+                box, builtin_failed = [b""], "rank 0: %s" % e
             dist.broadcast_object_list(box, src=0)
-            ctx.rccl_init(box[0], rank, world)
-        else:
+            if box[0]:
+                try:
+                    ctx.rccl_init(box[0], rank, world)
+                except Exception as e:              # noqa: BLE001
+                    builtin_failed = "rank %d: %s" % (rank, e)
+            # every rank must end up on the SAME rendezvous: agree (over the process group torch already has) whether the communicator came up everywhere
+            ok = torch.tensor([0 if (builtin_failed or not box[0]) else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                why = [None] * world
+                dist.all_gather_object(why, builtin_failed)
+                builtin_failed = "; ".join(w for w in why if w) or "a rank could not make the ncclUniqueId"
+                print(f"bench.py rank {rank}: the built-in RCCL rendezvous did not come up ({builtin_failed}): this run uses the torch.distributed "
+                      f"callback rendezvous instead -- the record says so (multi_gpu.rendezvous / builtin_failed)", file=sys.stderr)
+                rendezvous = "torch"
+        if rendezvous != "builtin":
             shard.install_rendezvous(ctx, dev)  # cwslg_slot_boundary[_end] ends in torch.distributed's all-reduce (callback form)
     SYNC_ARGS = (1.5, 200, 200, 3000)                  # jt9 -8 defaults used by the reference: syncmin 1.5, 200..3000 Hz (-H highestdecodefreq)
     if args.sync:
@@ -500,7 +518,7 @@ def main():
                                     f"cwslg_slot_boundary_end (torch.distributed)") if world > 1 else "single GPU"},
             "mode": rec["mode"],
             "realtime_ft8_slots": rec["value"] / 0.192,
-            "multi_gpu": None if world == 1 else {"rendezvous": rendezvous, "rccl_world": int(st.get("rccl_world", 0)),
+            "multi_gpu": None if world == 1 else {"rendezvous": rendezvous, "builtin_failed": builtin_failed, "rccl_world": int(st.get("rccl_world", 0)),
                                                   "rendezvous_calls": int(st["rendezvous_calls"]), "rendezvous_frames": int(st["rendezvous_frames"]),
                                                   "rank_ms_per_step_min": min(st["rank_ms_per_step"]), "rank_ms_per_step_max": max(st["rank_ms_per_step"])},
             "roofline": rec["roofline"],

@@ -96,26 +96,28 @@ __global__ __launch_bounds__(FFTB_S1_NT, 4) void fftb_stage1_kernel(const LongWo
     for (int cg = wvu; cg < NA / CB; cg += FFTB_S1_NT / 64) {
         const int c0 = cg * CB;
         const float2 *__restrict__ wrow = wfull + (size_t)c0 * NA;    // a __restrict__ kernel argument: provably read-only, so scalar loads
-        float P[CB], Q[CB], R[CB], S[CB];
+        // Round 4: the four chains of an output as TWO packed chains, (P, S) += (x.x, x.y) * wa.x and (R, Q) += (x.x, x.y) * wa.y.  The twiddle is a
+        // scalar-register operand, and gfx950 issues a one-lane-wide FP32 operation with a scalar source at half rate (4.2 cycles per wave64
+        // instruction against 2.35: scripts/micro/pk_issue.hip) -- v_pk_fma_f32 takes the same 4.25 cycles for two of them, with or without
+        // a scalar source.  Each lane of the packed operation is a correctly rounded fmaf on the same operands in the same order: same bits.
+        v2f PS[CB], RQ[CB];
 #pragma unroll
-        for (int j = 0; j < CB; ++j) { P[j] = Q[j] = R[j] = S[j] = 0.f; }
+        for (int j = 0; j < CB; ++j) { PS[j] = v2f{0.f, 0.f}; RQ[j] = v2f{0.f, 0.f}; }
         for (int a0 = 0; a0 < NA; a0 += 5) {
 #pragma unroll
             for (int u = 0; u < 5; ++u) {
-                const float2 x = s_z[a0 + u][lane];
+                const v2f x = *reinterpret_cast<const v2f *>(&s_z[a0 + u][lane]);
 #pragma unroll
                 for (int j = 0; j < CB; ++j) {
                     const float2 wa = wrow[j * NA + a0 + u];
-                    P[j] = __builtin_fmaf(x.x, wa.x, P[j]);
-                    Q[j] = __builtin_fmaf(x.y, wa.y, Q[j]);
-                    R[j] = __builtin_fmaf(x.x, wa.y, R[j]);
-                    S[j] = __builtin_fmaf(x.y, wa.x, S[j]);
+                    PS[j] = __builtin_elementwise_fma(x, v2f{wa.x, wa.x}, PS[j]);
+                    RQ[j] = __builtin_elementwise_fma(x, v2f{wa.y, wa.y}, RQ[j]);
                 }
             }
         }
 #pragma unroll
         for (int j = 0; j < CB; ++j)
-            gst2(yout + (size_t)(c0 + j) * NB + b, lcmul(make_float2(P[j] - Q[j], R[j] + S[j]), tb.wn[b * (c0 + j)]));
+            gst2(yout + (size_t)(c0 + j) * NB + b, lcmul(make_float2(PS[j].x - RQ[j].y, RQ[j].x + PS[j].y), tb.wn[b * (c0 + j)]));
     }
 }
 

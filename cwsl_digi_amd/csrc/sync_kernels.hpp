@@ -148,6 +148,33 @@ __device__ __forceinline__ void stage1_load_tw(const float2 *__restrict__ wn, in
     }
 }
 
+// W_NA^k = (cos, -sin)(2 pi k / NA), k <= NA / 2, as COMPILE-TIME constants (NA = 15: FT8, NA = 9: FT4): the values of spec v2's table --
+// float(cos), float(-sin) of the double angle, W^0 exact -- written out as hexadecimal floats; sync_ensure_shared recomputes the table at
+// start-up and refuses to run if a single bit differs.  Round 4: they used to arrive as kernel arguments, i.e. in SCALAR registers,
+// and on gfx950 a one-lane-wide FP32 operation with a scalar-register source issues at HALF rate (4.2 against 2.35 cycles per wave64
+// instruction and SIMD; literal and inline constants run at full rate: scripts/micro/pk_issue.hip, profiles/r4_pk_issue.txt) -- 160 of the
+// ~500 arithmetic instructions of a transform.  As literals they are folded into the instruction word.
+template <int NA> __host__ __device__ constexpr float small_wr(int k);
+template <int NA> __host__ __device__ constexpr float small_wi(int k);
+template <> __host__ __device__ constexpr float small_wr<15>(int k)
+{
+    return k == 0 ? 1.0f : k == 1 ? 0x1.d3bc3ap-1f : k == 2 ? 0x1.56984ap-1f : k == 3 ? 0x1.3c6ef4p-2f : k == 4 ? -0x1.ac260ap-4f
+         : k == 5 ? -0x1.0p-1f : k == 6 ? -0x1.9e377ap-1f : -0x1.f4cfc4p-1f;
+}
+template <> __host__ __device__ constexpr float small_wi<15>(int k)
+{
+    return k == 0 ? 0.0f : k == 1 ? -0x1.a07f92p-2f : k == 2 ? -0x1.7c7d7ap-1f : k == 3 ? -0x1.e6f0e2p-1f : k == 4 ? -0x1.fd31fap-1f
+         : k == 5 ? -0x1.bb67aep-1f : k == 6 ? -0x1.2cf23p-1f : -0x1.a9cd9ap-3f;
+}
+template <> __host__ __device__ constexpr float small_wr<9>(int k)
+{
+    return k == 0 ? 1.0f : k == 1 ? 0x1.8836fap-1f : k == 2 ? 0x1.63a1a8p-3f : k == 3 ? -0x1.0p-1f : -0x1.e11f64p-1f;
+}
+template <> __host__ __device__ constexpr float small_wi<9>(int k)
+{
+    return k == 0 ? 0.0f : k == 1 ? -0x1.491b76p-1f : k == 2 ? -0x1.f838b8p-1f : k == 3 ? -0x1.bb67aep-1f : -0x1.5e3a88p-2f;
+}
+
 template <int HALF, int NA, int NPACK>
 __device__ __forceinline__ void spectra_stage1(const float *s_x, float2 (*s_y)[SY_PITCH], const SyncTables &tb,
                                                const Stage1Tw<NA> &twp, int b)
@@ -174,8 +201,8 @@ __device__ __forceinline__ void spectra_stage1(const float *s_x, float2 (*s_y)[S
 #pragma unroll
         for (int a = 1; a < AMAX; ++a) {
             const int idx = (a * c) % NA;
-            const float wr = (idx <= NA / 2) ? tb.war[idx] : tb.war[NA - idx];
-            const float wi = (idx <= NA / 2) ? tb.wai[idx] : -tb.wai[NA - idx];
+            const float wr = small_wr<NA>((idx <= NA / 2) ? idx : NA - idx);
+            const float wi = (idx <= NA / 2) ? small_wi<NA>(idx) : -small_wi<NA>(NA - idx);
             P = __builtin_fmaf(z[a].x, wr, P);
             Q = __builtin_fmaf(z[a].y, wi, Q);
             R = __builtin_fmaf(z[a].x, wi, R);
@@ -397,14 +424,18 @@ __device__ __forceinline__ void spectra_stage1_regs(const float2 (&z)[AMAX], flo
         for (int a = 1; a < AMAX; ++a) { s0.x = s0.x + z[a].x; s0.y = s0.y + z[a].y; }
         s_y[0][b] = s0;                                  // W_NZ^0 = 1: no multiply
     }
+    // the chains start from a +0 the compiler cannot see through: fmaf(z, W, 0) would be a VOP3 v_fma_f32, which takes no literal --
+    // the constant would go back into a scalar register (half rate); with a register addend it is v_fmamk_f32 (VOP2 + literal)
+    float zero = 0.0f;
+    asm volatile("" : "+v"(zero));
 #pragma unroll
     for (int c = C0; c <= C1; ++c) {
-        float P = 0.f, Q = 0.f, R = 0.f, S = 0.f;
+        float P = zero, Q = zero, R = zero, S = zero;
 #pragma unroll
         for (int a = 1; a < AMAX; ++a) {
             const int idx = (a * c) % NA;
-            const float wr = (idx <= NA / 2) ? tb.war[idx] : tb.war[NA - idx];
-            const float wi = (idx <= NA / 2) ? tb.wai[idx] : -tb.wai[NA - idx];
+            const float wr = small_wr<NA>((idx <= NA / 2) ? idx : NA - idx);
+            const float wi = (idx <= NA / 2) ? small_wi<NA>(idx) : -small_wi<NA>(NA - idx);
             P = __builtin_fmaf(z[a].x, wr, P);
             Q = __builtin_fmaf(z[a].y, wi, Q);
             R = __builtin_fmaf(z[a].x, wi, R);

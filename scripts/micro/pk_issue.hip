@@ -18,6 +18,7 @@ __global__ void k(unsigned long long *out, float seed)
     for (int c = 0; c < CH; ++c) a[c] = v2f{seed + c, seed - c};
     const v2f b = v2f{seed * 0.5f, seed * 0.25f};
     unsigned long long t0, t1;
+    const unsigned long long sp = __builtin_amdgcn_readfirstlane(__float_as_uint(seed)) * 0x100000001ull;
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
     __syncthreads();
@@ -32,7 +33,24 @@ __global__ void k(unsigned long long *out, float seed)
                 else if (KIND == 1) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[c]) : "v"(b));
                 else if (KIND == 2) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[c].x) : "v"(b.x));
                 else if (KIND == 3) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(a[c]) : "v"(b));
-                else asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[c].x) : "v"(b.x));
+                else if (KIND == 4) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(a[c].x) : "v"(b.x));
+                else if (KIND == 5) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[c].x) : "v"(b.x), "v"(b.y));
+                else if (KIND == 6) asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(a[c].x) : "v"(b.x));
+                else if (KIND == 7) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[c].x) : "v"(b.x), "v"(b.y));
+                else if (KIND == 8) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(a[c].x) : "v"(b.x), "v"(b.y), "v"(a[(c + 1) % CH].y));
+                else if (KIND == 9) asm volatile("v_fmac_f32_e32 %0, %2, %3\n\tv_add_f32_e32 %1, %2, %1" : "+v"(a[c].x), "+v"(a[c].y) : "v"(b.x), "v"(b.y));
+                else if (KIND == 10) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(a[c]) : "v"(b), "v"(a[(c + 3) % CH]));
+                else if (KIND == 11) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[c].x) : "s"(seed), "v"(b.y));
+                else if (KIND == 12) asm volatile("v_sub_f32_e32 %0, %1, %0" : "+v"(a[c].x) : "v"(b.x));
+                else if (KIND == 13) asm volatile("v_mul_f32_e32 %0, %1, %0" : "+v"(a[c].x) : "s"(seed));
+                else if (KIND == 14) asm volatile("v_add_f32_e32 %0, %1, %0" : "+v"(a[c].x) : "s"(seed));
+                else if (KIND == 15) asm volatile("v_mul_f32_e32 %0, 0x3b5a740e, %0" : "+v"(a[c].x));
+                else if (KIND == 16) asm volatile("v_mul_f32_e32 %0, 2.0, %0" : "+v"(a[c].x));
+                else if (KIND == 17) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[c].x) : "s"(seed), "v"(b.y));
+                else if (KIND == 18) asm volatile("v_mul_f32_e64 %0, %1, -%0" : "+v"(a[c].x) : "v"(b.x));
+                else if (KIND == 19) asm volatile("v_fmac_f32_e32 %0, %1, %1" : "+v"(a[c].x) : "v"(b.x));
+                else if (KIND == 20) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(a[c]) : "s"(sp), "v"(b));
+                else asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(a[c]) : "s"(sp));
             }
         }
     }
@@ -54,7 +72,7 @@ void run(const char *name, int threads, int blocks)
     hipLaunchKernelGGL((k<KIND>), dim3(blocks), dim3(threads), 0, 0, d, 1.0f);
     hipDeviceSynchronize();
     std::vector<unsigned long long> h(waves * 4); hipMemcpy(h.data(), d, waves * 32, hipMemcpyDeviceToHost);
-    const double n_inst = 256.0 * 8 * 8;
+    const double n_inst = 256.0 * 8 * 8 * (KIND == 9 ? 2 : 1);
     struct Acc { unsigned long long t0 = ~0ull, t1 = 0; int n = 0; double sum = 0; };
     std::map<unsigned long long, Acc> by_simd;
     for (size_t w = 0; w < waves; ++w) {
@@ -80,6 +98,10 @@ void run(const char *name, int threads, int blocks)
 }
 int main()
 {
-    for (int t : {256, 512, 768, 1024}) { run<0>("pk_add", t, 256); run<1>("pk_mul", t, 256); run<2>("add", t, 256); run<3>("pk_fma", t, 256); run<4>("fma", t, 256); }
+    for (int t : {512, 1024}) { run<0>("pk_add", t, 256); run<1>("pk_mul", t, 256); run<2>("add", t, 256); run<3>("pk_fma", t, 256); run<4>("fma", t, 256);
+        run<5>("fmac_e32", t, 256); run<6>("mul_e32", t, 256); run<7>("fma_acc", t, 256); run<8>("fma_3src", t, 256); run<9>("fmac+add(x2)", t, 256);
+        run<10>("pk_fma_mods", t, 256); run<11>("fmac_sgpr", t, 256); run<12>("sub_e32", t, 256);
+        run<13>("mul_sgpr", t, 256); run<14>("add_sgpr", t, 256); run<15>("mul_literal", t, 256); run<16>("mul_inline2.0", t, 256); run<17>("fma_sgpr", t, 256);
+        run<18>("mul_e64_neg", t, 256); run<19>("fmac_same", t, 256); run<20>("pk_fma_sgpr", t, 256); run<21>("pk_mul_sgpr", t, 256); }
     return 0;
 }

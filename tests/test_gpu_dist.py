@@ -142,3 +142,23 @@ def test_bench_py_gpus_2_launches_two_ranks_on_this_gpu():
     assert line["multi_gpu"]["rendezvous_calls"] == 3 and line["multi_gpu"]["rendezvous_frames"] == 128
     assert line["mode"].startswith("exact") and line["verify"]["max_rel_err"] == 0.0 and line["verify"]["int16_mismatches"] == 0
     assert line["value"] > 0 and line["config"]["slots_per_gpu"] == 64
+
+
+def test_bench_py_falls_back_loudly_when_the_builtin_communicator_cannot_come_up():
+    """Two ranks on ONE device with the built-in rendezvous forced: RCCL refuses the duplicate GPU, so cwslg_rccl_init fails -- the ranks must
+    agree on that, say so on stderr and in the record, and finish the run on the torch.distributed callback rendezvous (the SCALE record of an
+    8-GPU node must not be lost to a communicator that did not come up)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--same-device", "--dist-backend", "gloo", "--rendezvous", "builtin",
+                        "--slots", "64", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--verify", "1", "--primary-only"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    mg = line["multi_gpu"]
+    assert line["n_gpus"] == 2 and mg["rendezvous"] == "torch" and mg["builtin_failed"], mg
+    assert mg["rendezvous_calls"] == 2 and mg["rendezvous_frames"] == 128
+    assert "did not come up" in p.stderr
