@@ -44,11 +44,9 @@ struct SyncConfig {
     int ia = 64, ib = 960, nbins = 976;   // derived: bin range and stored row length (ib+13 rounded up to 16)
 };
 
-struct SyncTables {                       // device pointers: W_NZ, W_128, W_2NZ twiddles, optional window
+struct SyncTables {                       // device pointers: W_NZ, W_128, 0.5 W_2NZ twiddles, optional window
     const float2 *w1920, *w128, *w3840;
     const float *win;
-    float war[8], wai[8];                 // W_NA^k for k <= NA/2, by value (kernel argument -> scalar registers);
-                                          // the other half is its bitwise conjugate (spec v2, oracle/sync_oracle.c)
 };
 
 struct SyncShared {
@@ -135,16 +133,31 @@ __device__ __forceinline__ int sy_col(int i) { return i ^ ((i >> 3) & 15); }
 // the W_NZ^(bc) twiddles of one thread's outputs, fetched at the top of the kernel so that their L2 latency runs under
 // the frame load instead of after the first barrier
 template <int NA>
-struct Stage1Tw { float2 v[2 * (NA / 2 - (NA / 2) / 2)]; };
+struct Stage1Tw { float2 v[(NA == 15) ? 8 : 2 * (NA / 2 - (NA / 2) / 2)]; };
+// NA = 15 (spec v3, prime-factor stage 1): the outputs of a lane are c = (10 k1 + 6 k2) mod 15 for ITS k2 -- HALF 0 (waves 0-1): k2 = 0, 1, 4,
+// HALF 1 (waves 2-3): k2 = 2, 3 -- in the order (k2, k1); output 0 takes no twiddle
+__host__ __device__ constexpr int pfa15_k2(int half, int i) { return half ? (i == 0 ? 2 : 3) : (i == 0 ? 0 : i == 1 ? 1 : 4); }
+__host__ __device__ constexpr int pfa15_c(int k1, int k2) { return (10 * k1 + 6 * k2) % 15; }
 template <int HALF, int NA>
 __device__ __forceinline__ void stage1_load_tw(const float2 *__restrict__ wn, int b, Stage1Tw<NA> &tw)
 {
-    constexpr int NPAIR = NA / 2, SPLIT = NPAIR / 2;
-    constexpr int C0 = HALF ? SPLIT + 1 : 1, C1 = HALF ? NPAIR : SPLIT;
+    if constexpr (NA == 15) {
+        int n = 0;
 #pragma unroll
-    for (int c = C0; c <= C1; ++c) {
-        tw.v[2 * (c - C0)] = wn[b * c];
-        tw.v[2 * (c - C0) + 1] = wn[b * (NA - c)];
+        for (int i = 0; i < (HALF ? 2 : 3); ++i)
+#pragma unroll
+            for (int k1 = 0; k1 < 3; ++k1) {
+                const int c = pfa15_c(k1, pfa15_k2(HALF, i));
+                if (c != 0) tw.v[n++] = wn[b * c];
+            }
+    } else {
+        constexpr int NPAIR = NA / 2, SPLIT = NPAIR / 2;
+        constexpr int C0 = HALF ? SPLIT + 1 : 1, C1 = HALF ? NPAIR : SPLIT;
+#pragma unroll
+        for (int c = C0; c <= C1; ++c) {
+            tw.v[2 * (c - C0)] = wn[b * c];
+            tw.v[2 * (c - C0) + 1] = wn[b * (NA - c)];
+        }
     }
 }
 
@@ -175,55 +188,106 @@ template <> __host__ __device__ constexpr float small_wi<9>(int k)
     return k == 0 ? 0.0f : k == 1 ? -0x1.491b76p-1f : k == 2 ? -0x1.f838b8p-1f : k == 3 ? -0x1.bb67aep-1f : -0x1.5e3a88p-2f;
 }
 
+// W_5^k = (cos, -sin)(2 pi k / 5), k <= 2, and -sin(2 pi / 3): spec v3's prime-factor stage 1 (checked against the host's libm like W_15 / W_9)
+__host__ __device__ constexpr float w5_r(int k) { return k == 0 ? 1.0f : k == 1 ? 0x1.3c6ef4p-2f : -0x1.9e377ap-1f; }
+__host__ __device__ constexpr float w5_i(int k) { return k == 0 ? 0.0f : k == 1 ? -0x1.e6f0e2p-1f : -0x1.2cf23p-1f; }
+__host__ __device__ constexpr float w5r_at(int m) { return m <= 2 ? w5_r(m) : w5_r(5 - m); }          // m = (n2 k2) mod 5
+__host__ __device__ constexpr float w5i_at(int m) { return m <= 2 ? w5_i(m) : -w5_i(5 - m); }
+
+constexpr float W3_S = -0x1.bb67aep-1f;                  // float(-sin(2 pi / 3))
+
+// Spec v3 stage 1 for NA = 15: the 15-point DFT of the EIGHT live inputs of column b (z_7 = 0 in the columns that have seven) by the
+// prime-factor algorithm, a = (5 n1 + 3 n2) mod 15, c = (10 k1 + 6 k2) mod 15 (oracle/sync_oracle.c, dft15_pfa8): five-point sums over the
+// live n2 of each n1 in conjugate pairs (k2, 5 - k2), then three-point DFTs over n1, then the twiddle W_NZ^(bc).  A lane does this for ITS
+// k2 (HALF 0: 0, 1, 4; HALF 1: 2, 3): 128 / 96 arithmetic instructions against the 146 / 176 of spec v2's pruned direct form.
+template <int HALF>
+__device__ __forceinline__ void stage1_pfa15(const float2 (&z)[8], float2 (*s_y)[SY_PITCH], const float2 *tw, int b)
+{
+    constexpr int KP = HALF ? 2 : 1;                       // the lane's conjugate pair (KP, 5 - KP)
+    float2 Ya[3], Yb[3];                                   // Y[n1][KP], Y[n1][5 - KP]
+    {   // n1 = 0: a = 0 (n2 = 0), 3 (n2 = 1), 6 (n2 = 2)
+        constexpr float w1r = w5r_at((1 * KP) % 5), w1i = w5i_at((1 * KP) % 5), w2r = w5r_at((2 * KP) % 5), w2i = w5i_at((2 * KP) % 5);
+        float P = z[3].x * w1r, Q = z[3].y * w1i, R = z[3].x * w1i, S = z[3].y * w1r;
+        P = __builtin_fmaf(z[6].x, w2r, P); Q = __builtin_fmaf(z[6].y, w2i, Q); R = __builtin_fmaf(z[6].x, w2i, R); S = __builtin_fmaf(z[6].y, w2r, S);
+        Ya[0] = make_float2(z[0].x + (P - Q), z[0].y + (R + S));
+        Yb[0] = make_float2(z[0].x + (P + Q), z[0].y + (S - R));
+    }
+    {   // n1 = 1: a = 5 (n2 = 0), 2 (n2 = 4)
+        constexpr float wr = w5r_at((4 * KP) % 5), wi = w5i_at((4 * KP) % 5);
+        const float P = z[2].x * wr, Q = z[2].y * wi, R = z[2].x * wi, S = z[2].y * wr;
+        Ya[1] = make_float2(z[5].x + (P - Q), z[5].y + (R + S));
+        Yb[1] = make_float2(z[5].x + (P + Q), z[5].y + (S - R));
+    }
+    {   // n1 = 2: a = 1 (n2 = 2), 4 (n2 = 3), 7 (n2 = 4); no n2 = 0 input
+        constexpr float w1r = w5r_at((2 * KP) % 5), w1i = w5i_at((2 * KP) % 5), w2r = w5r_at((3 * KP) % 5), w2i = w5i_at((3 * KP) % 5),
+                        w3r = w5r_at((4 * KP) % 5), w3i = w5i_at((4 * KP) % 5);
+        float P = z[1].x * w1r, Q = z[1].y * w1i, R = z[1].x * w1i, S = z[1].y * w1r;
+        P = __builtin_fmaf(z[4].x, w2r, P); Q = __builtin_fmaf(z[4].y, w2i, Q); R = __builtin_fmaf(z[4].x, w2i, R); S = __builtin_fmaf(z[4].y, w2r, S);
+        P = __builtin_fmaf(z[7].x, w3r, P); Q = __builtin_fmaf(z[7].y, w3i, Q); R = __builtin_fmaf(z[7].x, w3i, R); S = __builtin_fmaf(z[7].y, w3r, S);
+        Ya[2] = make_float2(P - Q, R + S);
+        Yb[2] = make_float2(P + Q, S - R);
+    }
+    int n = 0;
+    auto three = [&](const float2 y0, const float2 y1, const float2 y2, int k2) {        // three-point DFT over n1 -> outputs c(k1, k2), twiddled
+        const float2 x0 = make_float2((y0.x + y1.x) + y2.x, (y0.y + y1.y) + y2.y);
+        const float2 t = make_float2(y1.x + y2.x, y1.y + y2.y), d = make_float2(y1.x - y2.x, y1.y - y2.y);
+        const float2 m = make_float2(__builtin_fmaf(t.x, -0.5f, y0.x), __builtin_fmaf(t.y, -0.5f, y0.y));
+        const float2 x1 = make_float2(__builtin_fmaf(-W3_S, d.y, m.x), __builtin_fmaf(W3_S, d.x, m.y));
+        const float2 x2 = make_float2(__builtin_fmaf(W3_S, d.y, m.x), __builtin_fmaf(-W3_S, d.x, m.y));
+        const int c0 = pfa15_c(0, k2), c1 = pfa15_c(1, k2), c2 = pfa15_c(2, k2);
+        if (c0 == 0) s_y[0][b] = x0;                       // W_NZ^0 = 1: no multiply
+        else s_y[c0][b] = cmul_f(x0, tw[n++]);
+        s_y[c1][b] = cmul_f(x1, tw[n++]);
+        s_y[c2][b] = cmul_f(x2, tw[n++]);
+    };
+    if (HALF == 0) {
+        const float2 d0 = make_float2((z[0].x + z[3].x) + z[6].x, (z[0].y + z[3].y) + z[6].y);       // the k2 = 0 sums, sequential in ascending n2
+        const float2 d1 = make_float2(z[5].x + z[2].x, z[5].y + z[2].y);
+        const float2 d2 = make_float2((z[1].x + z[4].x) + z[7].x, (z[1].y + z[4].y) + z[7].y);
+        three(d0, d1, d2, 0);
+    }
+    three(Ya[0], Ya[1], Ya[2], KP);
+    three(Yb[0], Yb[1], Yb[2], 5 - KP);
+}
+
+template <int HALF, int NA, int AMAX>
+__device__ __forceinline__ void spectra_stage1_regs(const float2 (&z)[AMAX], float2 (*s_y)[SY_PITCH], const Stage1Tw<NA> &twp, int b);
+
 template <int HALF, int NA, int NPACK>
-__device__ __forceinline__ void spectra_stage1(const float *s_x, float2 (*s_y)[SY_PITCH], const SyncTables &tb,
-                                               const Stage1Tw<NA> &twp, int b)
+__device__ __forceinline__ void spectra_stage1(const float *s_x, float2 (*s_y)[SY_PITCH], const Stage1Tw<NA> &twp, int b)
 {
     constexpr int AMAX = (NPACK + 127) / 128;            // 8 (FT8), 9 (FT4)
-    constexpr int NPAIR = NA / 2, SPLIT = NPAIR / 2;
-    constexpr int C0 = HALF ? SPLIT + 1 : 1, C1 = HALF ? NPAIR : SPLIT;
     float2 z[AMAX];
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) {
         const int m = 128 * a + b;                       // a zero input adds exactly nothing to an fmaf chain
         z[a] = (m < NPACK) ? make_float2(s_x[2 * m], s_x[2 * m + 1]) : make_float2(0.f, 0.f);
     }
-    const float2 *tw = twp.v;
-    if (HALF == 0) {
-        float2 s0 = z[0];
-#pragma unroll
-        for (int a = 1; a < AMAX; ++a) { s0.x = s0.x + z[a].x; s0.y = s0.y + z[a].y; }
-        s_y[0][b] = s0;                                  // W_NZ^0 = 1: no multiply
-    }
-#pragma unroll
-    for (int c = C0; c <= C1; ++c) {
-        float P = 0.f, Q = 0.f, R = 0.f, S = 0.f;
-#pragma unroll
-        for (int a = 1; a < AMAX; ++a) {
-            const int idx = (a * c) % NA;
-            const float wr = small_wr<NA>((idx <= NA / 2) ? idx : NA - idx);
-            const float wi = (idx <= NA / 2) ? small_wi<NA>(idx) : -small_wi<NA>(NA - idx);
-            P = __builtin_fmaf(z[a].x, wr, P);
-            Q = __builtin_fmaf(z[a].y, wi, Q);
-            R = __builtin_fmaf(z[a].x, wi, R);
-            S = __builtin_fmaf(z[a].y, wr, S);
-        }
-        const float2 yc = make_float2(z[0].x + (P - Q), z[0].y + (R + S));
-        const float2 yn = make_float2(z[0].x + (P + Q), z[0].y + (S - R));
-        s_y[c][b] = cmul_f(yc, tw[2 * (c - C0)]);        // natural order; pass A gathers the bit-reversed inputs
-        s_y[NA - c][b] = cmul_f(yn, tw[2 * (c - C0) + 1]);
-    }
+    spectra_stage1_regs<HALF, NA, AMAX>(z, s_y, twp, b);
 }
 
-// radix-2 DIT butterfly on two registers: (u, v) -> (u + w v, u - w v)
+// radix-2 DIT butterfly on two registers: (u, v) -> (u + w v, u - w v), spec v3: three fmaf-class operations per component (the
+// difference is 2 u - (u + w v)), six per butterfly against spec v2's eight (product, then sum and difference)
 __device__ __forceinline__ void bfly(float2 &u, float2 &v, float2 w)
 {
-    const float2 t = cmul_f(v, w);
-    const float2 a = make_float2(u.x + t.x, u.y + t.y);
-    const float2 d = make_float2(u.x - t.x, u.y - t.y);
-    u = a;
-    v = d;
+    const float ar = __builtin_fmaf(v.x, w.x, __builtin_fmaf(-v.y, w.y, u.x));
+    const float ai = __builtin_fmaf(v.x, w.y, __builtin_fmaf(v.y, w.x, u.y));
+    const float dr = __builtin_fmaf(2.0f, u.x, -ar);
+    const float di = __builtin_fmaf(2.0f, u.y, -ai);
+    u = make_float2(ar, ai);
+    v = make_float2(dr, di);
 }
+// |X[K]|^2 from Z[K] = A and Z[NZ - K] = B (spec v3 stage 3; wh = 0.5 W_2NZ^K, the table is stored scaled)
+__device__ __forceinline__ float unpack_power(float2 A, float2 B, float2 wh)
+{
+    B.y = -B.y;
+    const float sr = A.x + B.x, si = A.y + B.y;
+    const float2 o = make_float2(A.x - B.x, A.y - B.y);
+    const float2 t = cmul_f(o, wh);
+    const float xr = __builtin_fmaf(sr, 0.5f, t.y), xi = __builtin_fmaf(si, 0.5f, -t.x);
+    return __builtin_fmaf(xr, xr, xi * xi);
+}
+
 __device__ __forceinline__ void bfly_one(float2 &u, float2 &v)        // w = W^0 = (1, 0)
 {
     const float2 a = make_float2(u.x + v.x, u.y + v.y);
@@ -285,8 +349,8 @@ __global__ __launch_bounds__(256) void symbol_spectra_kernel(const SyncWork *__r
     __syncthreads();
 
     // stage 1 (wave-uniform split of the conjugate pairs of outputs between waves 0-1 and waves 2-3)
-    if (tid < 128) spectra_stage1<0, NA, NPACK>(s_x, s_y, tb, tw1, tid & 127);
-    else spectra_stage1<1, NA, NPACK>(s_x, s_y, tb, tw1, tid & 127);
+    if (tid < 128) spectra_stage1<0, NA, NPACK>(s_x, s_y, tw1, tid & 127);
+    else spectra_stage1<1, NA, NPACK>(s_x, s_y, tw1, tid & 127);
     __syncthreads();
 
     // stage 2, pass A: DIT stages len = 2,4,8 on logical points 8g..8g+7 of row c; the DIT input order is
@@ -349,14 +413,7 @@ __global__ __launch_bounds__(256) void symbol_spectra_kernel(const SyncWork *__r
     float *out = w->spectra + (size_t)j * nbins;
     auto power_at = [&](int k) -> float {                  // generic indexing (any k <= NZ)
         const int k2 = (NZ - k) % NZ, kk = k % NZ;
-        const float2 A = s_y[kk % NA][sy_col(kk / NA)];
-        float2 B = s_y[k2 % NA][sy_col(k2 / NA)];
-        B.y = -B.y;
-        const float er = (A.x + B.x) * 0.5f, ei = (A.y + B.y) * 0.5f;
-        const float2 o = make_float2((A.x - B.x) * 0.5f, (A.y - B.y) * 0.5f);
-        const float2 t = cmul_f(o, tb.w3840[k]);
-        const float xr = er + t.y, xi = ei - t.x;
-        return __builtin_fmaf(xr, xr, xi * xi);
+        return unpack_power(s_y[kk % NA][sy_col(kk / NA)], s_y[k2 % NA][sy_col(k2 / NA)], tb.w3840[k]);
     };
     if (staged) {
         // residue-major walk: item (r, chunk) = bins k = NA (64 chunk + lane) + r.  Row k % NA = r and row (NZ-k) % NA
@@ -371,10 +428,7 @@ __global__ __launch_bounds__(256) void symbol_spectra_kernel(const SyncWork *__r
             const float2 A = s_y[r][sy_col(q)];
             const int r2 = (r == 0) ? 0 : NA - r;
             const int q2 = (r == 0) ? ((q == 0) ? 0 : 128 - q) : 127 - q;     // (NZ - k) / NA ; k = 0 pairs with itself
-            float2 B = s_y[r2][sy_col(q2)];
-            B.y = -B.y;
-            const float er = (A.x + B.x) * 0.5f, ei = (A.y + B.y) * 0.5f;
-            const float2 o = make_float2((A.x - B.x) * 0.5f, (A.y - B.y) * 0.5f);
+            const float2 B = s_y[r2][sy_col(q2)];
             float2 wk;
             switch (pre) {                                   // the first W3PRE twiddles were fetched at the top
             case 0: wk = w3[0]; break;
@@ -383,9 +437,7 @@ __global__ __launch_bounds__(256) void symbol_spectra_kernel(const SyncWork *__r
             case 3: wk = w3[3]; break;
             default: wk = tb.w3840[k]; break;
             }
-            const float2 t = cmul_f(o, wk);
-            const float xr = er + t.y, xi = ei - t.x;
-            s_pw[k] = __builtin_fmaf(xr, xr, xi * xi);
+            s_pw[k] = unpack_power(A, B, wk);
         }
         for (int k = NA * 64 * nfull + tid; k < nbins; k += 256)              // ragged tail (FT8: 16 bins, FT4: bin 1152 + pad)
             s_pw[k] = (k <= NZ) ? power_at(k) : 0.0f;
@@ -412,9 +464,13 @@ __global__ __launch_bounds__(256) void symbol_spectra_kernel(const SyncWork *__r
 //     15 KB of loads per transform, the loop over residues and one barrier.
 // Needs nbins <= NIN + 32 (the power row is staged in LDS).
 template <int HALF, int NA, int AMAX>
-__device__ __forceinline__ void spectra_stage1_regs(const float2 (&z)[AMAX], float2 (*s_y)[SY_PITCH], const SyncTables &tb,
-                                                    const Stage1Tw<NA> &twp, int b)
+__device__ __forceinline__ void spectra_stage1_regs(const float2 (&z)[AMAX], float2 (*s_y)[SY_PITCH], const Stage1Tw<NA> &twp, int b)
 {
+    if constexpr (NA == 15) {                            // spec v3: prime-factor 3 x 5 on the eight live inputs
+        static_assert(AMAX == 8, "FT8: 960 packed inputs = 8 rows of 128");
+        stage1_pfa15<HALF>(z, s_y, twp.v, b);
+        return;
+    }
     constexpr int NPAIR = NA / 2, SPLIT = NPAIR / 2;
     constexpr int C0 = HALF ? SPLIT + 1 : 1, C1 = HALF ? NPAIR : SPLIT;
     const float2 *tw = twp.v;
@@ -448,44 +504,30 @@ __device__ __forceinline__ void spectra_stage1_regs(const float2 (&z)[AMAX], flo
     }
 }
 
-// |X[K]|^2 from Z[K] = A and Z[NZ - K] = B (spec v2 stage 3)
-__device__ __forceinline__ float unpack_power(float2 A, float2 B, float2 wk)
-{
-    B.y = -B.y;
-    const float er = (A.x + B.x) * 0.5f, ei = (A.y + B.y) * 0.5f;
-    const float2 o = make_float2((A.x - B.x) * 0.5f, (A.y - B.y) * 0.5f);
-    const float2 t = cmul_f(o, wk);
-    const float xr = er + t.y, xi = ei - t.x;
-    return __builtin_fmaf(xr, xr, xi * xi);
-}
-
 #ifndef CWSLG_SPEC_JPER
 #define CWSLG_SPEC_JPER 12
 #endif
 #ifndef CWSLG_SPEC_WAVES
 #define CWSLG_SPEC_WAVES 4
 #endif
-// arr[idx] for a per-lane idx in 0..7 of a by-value (scalar-register) table: a select chain, not a scratch array
-__device__ __forceinline__ float pick8(const float (&arr)[8], int idx)
-{
-    float v = arr[0];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) v = (idx == k) ? arr[k] : v;
-    return v;
-}
-
 constexpr int SPEC_JPER = CWSLG_SPEC_JPER;   // symbol steps per workgroup (FT8: 372 = 31 x 12); -D overrides are for A/B builds only
-// S1MFMA: stage 1 on the matrix cores.  The 28 (FT8) / 16 (FT4) fmaf chains P, Q, R, S of a column and the running sum of output 0 are
-// rows of ONE 32 x 32 accumulator tile per wave (32 columns): row = chain + 8 * (pair mod 4) + 4 * (pair / 4).  Step a is a single
-// v_mfma_f32_32x32x2_f32 whose two k-slots carry (coefficient for Re z_a, Re z_a) and (coefficient for Im z_a, Im z_a); a chain that
-// does not use a slot has coefficient 0 there, which adds exactly nothing, and the matrix core accumulates k-slots in order as
-// correctly rounded fmaf -- so every chain is the restatement's, bit for bit (same tests).  The output mapping of the instruction puts
-// all four chains of a pair into ONE lane (lanes 0-31: pairs 1-4, lanes 32-63: pairs 5-7 and output 0), which therefore finishes its
-// outputs without any cross-lane traffic.  Stage 1 is 190 of the kernel's ~690 VALU instructions per wave and the matrix pipe is idle
-// otherwise -- but MEASURED SLOWER (sync stage 1.56 against 1.29 ms per 512 slots, same box): the seven matrix instructions of a wave
-// are one dependent chain (64 cycles each, half their multiplies by zero) and do not overlap the other waves' VALU work the way
-// the instruction counts suggest.  Kept as CWSLG_SYNC_VARIANT bit 4; the default is the VALU form.
-template <int NA, int NIN, int STEP, bool WINDOW, bool S1MFMA>
+// (Rounds 2-3 carried a matrix-core form of spec v2's stage 1 -- its fmaf chains as v_mfma_f32_32x32x2_f32 steps -- as a lab variant: measured
+// slower twice, 1.56 against 1.29 ms per 512 slots and 6.3 against 5.2 ms per 4096; it went with spec v2's stage 1.)
+#if defined(CWSLG_STAMP) && defined(CWSLG_STAMP_SPEC)
+// diagnostic build only (scripts/gpu_stamps_spectra.py): s_memtime of waves 0 and 2 at the phase seams of the workgroup's THIRD transform
+#define PSTAMP(slot)                                                                                                               \
+    do {                                                                                                                           \
+        const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                                                  \
+        if (j == j0 + 2 && (tid_ & 127) == 0 && wg_ < 32768) {                                                                     \
+            unsigned long long t_;                                                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                             \
+            g_stamps[16 * wg_ + 8 * (tid_ >> 7) + (slot)] = t_;                                                                    \
+        }                                                                                                                          \
+    } while (0)
+#else
+#define PSTAMP(slot) do { } while (0)
+#endif
+template <int NA, int NIN, int STEP, bool WINDOW>
 __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kernel(const SyncWork *__restrict__ works, SyncTables tb, int nbins, int nsteps)
 {
     constexpr int NZ = NA * 128;
@@ -497,13 +539,12 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     static_assert(NGRP <= 256, "geometry");
     __shared__ __attribute__((aligned(16))) float s_pw[NIN + 32];     // one power row: nbins <= NIN + 32 (FT8: the widest search stores 1952)
     __shared__ float2 s_y[NA][SY_PITCH];
-    __shared__ float2 s_w128[64];
+    __shared__ float2 s_w128[66];                          // W_128^k, k < 64; [64], [65]: the unpack twiddles of bins NA * 64 and NZ (izero lane)
     const SyncWork *w = works + blockIdx.y;
     const int j0 = blockIdx.x * SPEC_JPER;
     const int jend = min(j0 + SPEC_JPER, nsteps);
     const int tid_ = threadIdx.x;
-    const int hh_ = S1MFMA ? ((tid_ >> 5) & 1) : 0;        // S1MFMA: which k-slot (Re / Im) and which half of the pairs this lane serves
-    const int b_ = S1MFMA ? 32 * (tid_ >> 6) + (tid_ & 31) : (tid_ & 127);
+    const int b_ = tid_ & 127;
     const float fac = 1.0f / 300.0f;
     // Barriers are lds_barrier() (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also wait for vmcnt(0), i.e. for
     // the prefetched window, at the first barrier behind its issue.
@@ -525,38 +566,8 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         }
     }
     Stage1Tw<NA> tw1;
-    float2 twm[8];                                        // S1MFMA: W_NZ^(b c), W_NZ^(b (NA - c)) of this lane's (up to) four pairs
-    float coefA[AMAX];                                    // S1MFMA: this lane's A operand of step a (row tid & 31, k-slot hh)
-    if (S1MFMA) {
-        constexpr int NPAIR = NA / 2;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int c = 1 + p + 4 * hh_;
-            twm[2 * p] = (c <= NPAIR) ? tb.w1920[b_ * c] : make_float2(0.f, 0.f);
-            twm[2 * p + 1] = (c <= NPAIR) ? tb.w1920[b_ * (NA - c)] : make_float2(0.f, 0.f);
-        }
-        const int row = tid_ & 31;
-        const int q = row & 3, rc = 1 + (row >> 3) + 4 * ((row >> 2) & 1);      // chain (P, Q, R, S) and pair of this accumulator row
-        const bool s0row = (row >> 3) == 3 && ((row >> 2) & 1) == 1;             // rows 28..31: output 0 (28: Re, 29: Im)
-#pragma unroll
-        for (int a = 1; a < AMAX; ++a) {
-            float cf = 0.0f;
-            if (s0row) cf = (q == hh_ && q < 2) ? 1.0f : 0.0f;                   // fmaf(z, 1, acc) = acc + z exactly
-            else if (rc <= NPAIR) {
-                const int idx = (a * rc) % NA;
-                const int ix = (idx <= NA / 2) ? idx : NA - idx;
-                const float wr = pick8(tb.war, ix);
-                const float wi = (idx <= NA / 2) ? pick8(tb.wai, ix) : -pick8(tb.wai, ix);
-                // P = sum zr wr, Q = sum zi wi, R = sum zr wi, S = sum zi wr: slot 0 multiplies Re z, slot 1 Im z
-                cf = (q == 0) ? (hh_ ? 0.0f : wr) : (q == 1) ? (hh_ ? wi : 0.0f) : (q == 2) ? (hh_ ? 0.0f : wi) : (hh_ ? wr : 0.0f);
-            }
-            coefA[a] = cf;
-        }
-        coefA[0] = 0.0f;
-    } else {
-        if (tid_ < 128) stage1_load_tw<0, NA>(tb.w1920, b_, tw1);
-        else stage1_load_tw<1, NA>(tb.w1920, b_, tw1);
-    }
+    if (tid_ < 128) stage1_load_tw<0, NA>(tb.w1920, b_, tw1);
+    else stage1_load_tw<1, NA>(tb.w1920, b_, tw1);
     // the unpack twiddles W_2NZ^K of this thread's items (bins K1, K2 of each; the two upper bins of an item are rare for
     // FT8's default range and fetched on demand)
     float2 w3[IPT][2];
@@ -586,7 +597,7 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     // LDS byte offsets of the last stage's operands and of pass B's eight points, computed ONCE (from the real thread index): the
     // opaque copy below keeps everything else out of registers, but these 24 are worth theirs -- recomputed per transform they were
     // ~90 of a wave's ~610 VALU instructions (swizzle, row pitch products, shifts).
-    unsigned au1[IPT], av1[IPT], au2[IPT], av2[IPT], aw1[IPT], aw2[IPT], ap1[IPT], ap2[IPT];
+    unsigned au1[IPT], au2[IPT], aw1[IPT], aw2[IPT], ap1[IPT], ap2[IPT];
     bool iskip[IPT], izero[IPT];
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
@@ -597,8 +608,11 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         iskip[i] = it >= NITEM || (r == 0 && q > 32);
         izero[i] = r == 0 && q == 0;
         const int rr = iskip[i] ? 0 : r, rr2 = iskip[i] ? 0 : r2;
-        au1[i] = 8u * (unsigned)(rr * SY_PITCH + sy_col(q));   av1[i] = 8u * (unsigned)(rr * SY_PITCH + sy_col(q + 64));
-        au2[i] = 8u * (unsigned)(rr2 * SY_PITCH + sy_col(k2)); av2[i] = 8u * (unsigned)(rr2 * SY_PITCH + sy_col(k2 + 64));
+        // the partner column k + 64 is not kept: sy_col(k + 64) = 64 + (sy_col(k) ^ 8) for k < 64, and a row starts at a multiple of 128 bytes,
+        // so its byte address is (address of column k ^ 64) + 512 -- one XOR at the point of use, the 512 rides in the instruction's offset field
+        static_assert((SY_PITCH * 8) % 128 == 0, "row pitch");
+        au1[i] = 8u * (unsigned)(rr * SY_PITCH + sy_col(q));
+        au2[i] = 8u * (unsigned)(rr2 * SY_PITCH + sy_col(k2));
         aw1[i] = 8u * (unsigned)q; aw2[i] = 8u * (unsigned)k2;
         ap1[i] = 4u * (unsigned)(NA * q + r); ap2[i] = 4u * (unsigned)(NA * k2 + r2);
     }
@@ -609,6 +623,11 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         for (int q = 0; q < 8; ++q) aB[q] = 8u * (unsigned)((tid_ < NGRP ? c : 0) * SY_PITCH + sy_col(64 * blk + r + 8 * q));
     }
     if (tid_ >= 64 && tid_ < 128) s_w128[tid_ - 64] = tb.w128[tid_ - 64];
+    // the two self-paired bins' twiddles go through LDS: fetched inside the loop (round 3) they were a global load on wave 0's path in EVERY
+    // transform, whose vmcnt wait also drained the prefetched window -- ~550 cycles that the other three waves then spent at the barrier
+    // (s_memtime stamps, scripts/gpu_stamps_spectra.py)
+    if (tid_ == 128) s_w128[64] = tb.w3840[NA * 64];
+    if (tid_ == 129) s_w128[65] = tb.w3840[NZ];
     // every loop-invariant load (twiddles, window) is waited for HERE, with the builtin the compiler's wait-count pass
     // understands: otherwise it keeps conservative vmcnt waits for them inside the loop (the first iteration could still
     // need them), and from the second iteration on those waits drain the prefetch in the middle of stage 1
@@ -619,27 +638,19 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     // registers across it (168 VGPRs, 3 workgroups per CU)
     int t = tid_;
     asm volatile("" : "+v"(t));
-    const int tid = t, b = S1MFMA ? 32 * (t >> 6) + (t & 31) : (t & 127);
+    const int tid = t, b = t & 127;
     char *const sy_bytes = reinterpret_cast<char *>(&s_y[0][0]);
     const char *const w128_bytes = reinterpret_cast<const char *>(&s_w128[0]);
     char *const pw_bytes = reinterpret_cast<char *>(&s_pw[0]);
+    PSTAMP(0);
     float2 z[AMAX];
-    float zk[AMAX];                                       // S1MFMA: Re (lanes 0-31) or Im (lanes 32-63) of z_a, the B operand of step a
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) {
         const bool live = 128 * a + b < NPACK;
-        if (!S1MFMA || a == 0) {
-            float lo = fac * (float)(short)(raw[a] & 0xFFFFu);
-            float hi = fac * (float)(short)(raw[a] >> 16);
-            if (WINDOW) { lo = lo * wn[WINDOW ? a : 0].x; hi = hi * wn[WINDOW ? a : 0].y; }
-            z[a] = live ? make_float2(lo, hi) : make_float2(0.f, 0.f);
-            zk[a] = 0.0f;
-        } else {
-            float x = fac * (float)(short)(hh_ ? (raw[a] >> 16) : (raw[a] & 0xFFFFu));
-            if (WINDOW) x = x * (hh_ ? wn[WINDOW ? a : 0].y : wn[WINDOW ? a : 0].x);
-            zk[a] = live ? x : 0.0f;
-            z[a] = make_float2(0.f, 0.f);
-        }
+        float lo = fac * (float)(short)(raw[a] & 0xFFFFu);
+        float hi = fac * (float)(short)(raw[a] >> 16);
+        if (WINDOW) { lo = lo * wn[WINDOW ? a : 0].x; hi = hi * wn[WINDOW ? a : 0].y; }
+        z[a] = live ? make_float2(lo, hi) : make_float2(0.f, 0.f);
     }
     // the PREVIOUS step's power row leaves now (16 B per lane): issued ahead of the prefetch, its stores have a whole
     // transform to retire before the top of the next iteration waits for vmcnt(0)
@@ -652,35 +663,12 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         for (int a = 0; a < AMAX; ++a) raw[a] = (128 * a + b < NPACK) ? d32[(STEP / 2) * (j + 1) + 128 * a] : 0u;
     }
 
-    if (S1MFMA) {
-        constexpr int NPAIR = NA / 2;
-        typedef float f32x16 __attribute__((ext_vector_type(16)));
-        f32x16 acc;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
-        if (hh_) { acc[12] = z[0].x; acc[13] = z[0].y; }      // output 0 = ((z0 + z1) + z2) + ... : its chain starts from z0
-#pragma unroll
-        for (int a = 1; a < AMAX; ++a)                      // lane (i, h): A[i][k = h] = coefA, B[k = h][j = i] = Re / Im of z_a of column b
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(coefA[a], zk[a], acc, 0, 0, 0);
-        // D[row][col = lane & 31], row = (v & 3) + 8 (v >> 2) + 4 hh: v = 4 p + chain, pair c = 1 + p + 4 hh
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int c = 1 + p + 4 * hh_;
-            if (c <= NPAIR) {
-                const float P = acc[4 * p], Q = acc[4 * p + 1], R = acc[4 * p + 2], S = acc[4 * p + 3];
-                const float2 yc = make_float2(z[0].x + (P - Q), z[0].y + (R + S));
-                const float2 yn = make_float2(z[0].x + (P + Q), z[0].y + (S - R));
-                s_y[c][b] = cmul_f(yc, twm[2 * p]);
-                s_y[NA - c][b] = cmul_f(yn, twm[2 * p + 1]);
-            }
-        }
-        if (hh_) s_y[0][b] = make_float2(acc[12], acc[13]);
-    } else {
-        // stage 1 (wave-uniform split of the conjugate pairs of outputs between waves 0-1 and waves 2-3)
-        if (tid < 128) spectra_stage1_regs<0, NA, AMAX>(z, s_y, tb, tw1, b);
-        else spectra_stage1_regs<1, NA, AMAX>(z, s_y, tb, tw1, b);
-    }
+    // stage 1 (wave-uniform split of the outputs between waves 0-1 and waves 2-3)
+    if (tid < 128) spectra_stage1_regs<0, NA, AMAX>(z, s_y, tw1, b);
+    else spectra_stage1_regs<1, NA, AMAX>(z, s_y, tw1, b);
+    PSTAMP(1);
     lds_barrier();
+    PSTAMP(2);
 
     // stage 2, pass A: DIT stages len = 2,4,8 (see the first version)
     {
@@ -711,6 +699,7 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();                 // (see above: pass B reads what lanes of this wave wrote)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PSTAMP(3);
     // pass B: stages len = 16,32,64
     if (tid < NGRP) {
         const int r = tid & 7;
@@ -732,20 +721,22 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
 #pragma unroll
         for (int q = 0; q < 8; ++q) *reinterpret_cast<float2 *>(sy_bytes + aB[q]) = e[q];
     }
+    PSTAMP(4);
     lds_barrier();
+    PSTAMP(5);
 
     // last stage (len = 128) fused with the unpack: see the header of this kernel
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
         if (iskip[i]) continue;
-        float2 u1 = *reinterpret_cast<const float2 *>(sy_bytes + au1[i]), v1 = *reinterpret_cast<const float2 *>(sy_bytes + av1[i]);
-        float2 u2 = *reinterpret_cast<const float2 *>(sy_bytes + au2[i]), v2 = *reinterpret_cast<const float2 *>(sy_bytes + av2[i]);
+        float2 u1 = *reinterpret_cast<const float2 *>(sy_bytes + au1[i]), v1 = *reinterpret_cast<const float2 *>(sy_bytes + (au1[i] ^ 64u) + 512);
+        float2 u2 = *reinterpret_cast<const float2 *>(sy_bytes + au2[i]), v2 = *reinterpret_cast<const float2 *>(sy_bytes + (au2[i] ^ 64u) + 512);
         bfly(u1, v1, *reinterpret_cast<const float2 *>(w128_bytes + aw1[i]));
         bfly(u2, v2, *reinterpret_cast<const float2 *>(w128_bytes + aw2[i]));
         if (izero[i]) {                                     // Z[0] and Z[NZ/2] pair with themselves
             s_pw[0] = unpack_power(u1, u1, w3[i][0]);
-            if (NA * 64 < nbins) s_pw[NA * 64] = unpack_power(v1, v1, tb.w3840[NA * 64]);
-            if (NZ < nbins) s_pw[NZ] = unpack_power(u1, u1, tb.w3840[NZ]);
+            if (NA * 64 < nbins) s_pw[NA * 64] = unpack_power(v1, v1, s_w128[64]);
+            if (NZ < nbins) s_pw[NZ] = unpack_power(u1, u1, s_w128[65]);
             continue;
         }
         if (sparse) {
@@ -770,7 +761,9 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         }
     }
     for (int k = NZ + 1 + tid; k < nbins; k += 256) s_pw[k] = 0.0f;          // padding beyond the Nyquist bin
+    PSTAMP(6);
     lds_barrier();
+    PSTAMP(7);
     }   // next symbol step: s_y is rewritten after this barrier, s_pw only after four more
     if (jend > j0) {
         CWSLG_GLOBAL v4f *out4 = reinterpret_cast<CWSLG_GLOBAL v4f *>(as_global_rw(w->spectra) + (size_t)(jend - 1) * nbins);

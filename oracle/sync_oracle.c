@@ -8,19 +8,33 @@
 #define NB   128               /* radix-2 part of both transforms */
 
 /*
- * Transform of record ("spec v2"), shared by FT8 (2*NZ = 3840, NA = 15) and FT4 (2*NZ = 2304, NA = 9):
+ * Transform of record ("spec v3", round 4), shared by FT8 (2*NZ = 3840, NA = 15) and FT4 (2*NZ = 2304, NA = 9):
  *   pack     z[m] = x[2m] + i x[2m+1]  (m < NZ; FT8: zero for m >= 960), m = 128 a + b
- *   stage 1  for each column b an NA-point DFT over a, evaluated in conjugate pairs (c, NA-c):
+ *   stage 1  for each column b an NA-point DFT over a, then y_c *= WN[b c] for c >= 1 (cmul below).
+ *            NA = 9: evaluated in conjugate pairs (c, NA-c):
  *              P = sum_a zr_a wr, Q = sum_a zi_a wi, R = sum_a zr_a wi, S = sum_a zi_a wr   (a = 1.., fmaf chains from 0)
  *              y_c = (z0r + (P - Q), z0i + (R + S)),  y_{NA-c} = (z0r + (P + Q), z0i + (S - R)),  w = WA[(a c) mod NA]
  *              y_0 = z_0 + z_1 + ... (sequential)
- *            then y_c *= WN[b c] for c >= 1 (cmul below)
- *   stage 2  NA radix-2 DIT FFTs of 128 points (input bit-reversed): t = v*w, (u, v) <- (u + t, u - t)
- *   stage 3  real-input unpack with W2N[k], pw = fmaf(xr, xr, xi*xi)
+ *            NA = 15 (spec v3): Good-Thomas 3 x 5 on the EIGHT live inputs a = 0..7 (a column with seven takes z_7 = 0):
+ *              a = (5 n1 + 3 n2) mod 15, c = (10 k1 + 6 k2) mod 15, so W15^(a c) = W3^(n1 k1) W5^(n2 k2).
+ *              five-point step, per n1, over the live n2 in ascending order (n1 = 0: n2 = 0,1,2 = a 0,3,6; n1 = 1: n2 = 0,4 = a 5,2;
+ *              n1 = 2: n2 = 2,3,4 = a 1,4,7):  Y[n1][0] = sequential sum;  for k2 = 1, 2, over the inputs with n2 != 0, w = W5^(n2 k2):
+ *                P = zr wr, Q = zi wi, R = zr wi, S = zi wr for the first of them (plain products), fmaf chains for the others;
+ *                Y[n1][k2] = d + (P - Q, R + S),  Y[n1][5 - k2] = d + (P + Q, S - R),  d = the n2 = 0 input (absent for n1 = 2: no addition)
+ *              three-point step, per k2:  X[k1 = 0] = (Y0 + Y1) + Y2;  t = Y1 + Y2, d = Y1 - Y2, m = fmaf(t, -0.5, Y0) per component,
+ *                X[k1 = 1] = (fmaf(-s3, d.i, m.r), fmaf(s3, d.r, m.i)),  X[k1 = 2] = (fmaf(s3, d.i, m.r), fmaf(-s3, d.r, m.i)),  s3 = float(-sin(2 pi / 3))
+ *   stage 2  NA radix-2 DIT FFTs of 128 points (input bit-reversed); butterfly (u, v, w) -> (a, d), three fmaf-class operations per component:
+ *              a.r = fmaf(v.r, w.r, fmaf(-v.i, w.i, u.r)),  a.i = fmaf(v.r, w.i, fmaf(v.i, w.r, u.i)),  d = fmaf(2, u, -a)
+ *            (in the first three stages, len = 2, 4, 8, the butterflies with w = (1, 0) and w = (0, -1) -- exact table entries -- are plain
+ *            additions: a = u + v, d = u - v; resp. a = u + (v.i, -v.r), d = u - (v.i, -v.r); from len = 16 on every butterfly takes the fmaf form)
+ *   stage 3  real-input unpack with WH[k] = 0.5 * W2N[k] (exact scaling):  A = Z[k], B = conj Z[N - k]:
+ *              s = A + B, o = A - B, t = cmul(o, WH[k]),  xr = fmaf(s.r, 0.5, t.i), xi = fmaf(s.i, 0.5, -t.r),  pw = fmaf(xr, xr, xi*xi)
  *   cmul     (vr + i vi)(wr + i wi) = ( fmaf(vr, wr, -(vi*wi)),  fmaf(vr, wi, vi*wr) )
  * Twiddle tables: float(cos), float(-sin) of the double angle, EXCEPT that the cardinal points are exact
- * (W^0 = (1, 0), W128^32 = (0, -1)) and WA is conjugate-symmetric bit for bit (WA[NA-k] = conj(WA[k])).
+ * (W^0 = (1, 0), W128^32 = (0, -1)) and WA / W5 are conjugate-symmetric bit for bit (WA[NA-k] = conj(WA[k])).
  * fmaf is the correctly-rounded fused multiply-add (C99); everything else is plain float + - *.
+ * (Spec v2, rounds 2-3: the NA = 9 form of stage 1 for both modes, t = cmul(v, w) and (u + t, u - t) butterflies, halving before the unpack
+ * product.  v3 is the same transform with about 17 % fewer operations; both agree with a double-precision FFT to the same 2e-6.)
  */
 typedef struct {
     int na, nz, npack;
@@ -30,6 +44,7 @@ typedef struct {
 } fft_plan;
 
 static float w128r[NB / 2], w128i[NB / 2]; /* exp(-2 pi i k/128)  */
+static float w5r[5], w5i[5], w3s;          /* exp(-2 pi i k/5) (conjugate-symmetric), -sin(2 pi/3) */
 static unsigned char rev7[NB];
 static fft_plan plan8, plan4;
 static int tables_ready = 0;
@@ -46,6 +61,7 @@ static void make_plan(fft_plan *P, int na, int npack)
     for (int k = 0; k < P->nz; ++k) { P->wnr[k] = (float)cos(2.0 * pi * k / P->nz); P->wni[k] = (float)(-sin(2.0 * pi * k / P->nz)); }
     for (int k = 0; k <= P->nz; ++k) { P->w2r[k] = (float)cos(pi * k / P->nz); P->w2i[k] = (float)(-sin(pi * k / P->nz)); }
     P->wnr[0] = 1.0f; P->wni[0] = 0.0f; P->w2r[0] = 1.0f; P->w2i[0] = 0.0f;
+    for (int k = 0; k <= P->nz; ++k) { P->w2r[k] = 0.5f * P->w2r[k]; P->w2i[k] = 0.5f * P->w2i[k]; }      /* WH = 0.5 * W2N, exact */
 }
 
 static void make_tables(void)
@@ -53,6 +69,10 @@ static void make_tables(void)
     const double pi = 3.14159265358979323846;
     for (int k = 0; k < NB / 2; ++k) { w128r[k] = (float)cos(2.0 * pi * k / 128.0); w128i[k] = (float)(-sin(2.0 * pi * k / 128.0)); }
     w128r[0] = 1.0f; w128i[0] = 0.0f; w128r[32] = 0.0f; w128i[32] = -1.0f;
+    for (int k = 0; k <= 2; ++k) { w5r[k] = (float)cos(2.0 * pi * k / 5.0); w5i[k] = (float)(-sin(2.0 * pi * k / 5.0)); }
+    w5r[0] = 1.0f; w5i[0] = 0.0f;
+    for (int k = 3; k < 5; ++k) { w5r[k] = w5r[5 - k]; w5i[k] = -w5i[5 - k]; }
+    w3s = (float)(-sin(2.0 * pi / 3.0));
     for (int b = 0; b < NB; ++b) {
         int r = 0;
         for (int t = 0; t < 7; ++t) if (b & (1 << t)) r |= 1 << (6 - t);
@@ -65,6 +85,46 @@ static void make_tables(void)
 
 #define CMUL(vr, vi, wr, wi, tr, ti) do { (tr) = fmaf((vr), (wr), -((vi) * (wi))); (ti) = fmaf((vr), (wi), (vi) * (wr)); } while (0)
 
+/* spec v3 stage 1 for NA = 15: the 15-point DFT of z_0..z_7 (z_8.. = 0) by the prime-factor algorithm; out[c], c = 0..14 */
+static void dft15_pfa8(const float *zr, const float *zi, float *outr, float *outi)
+{
+    static const int cnt[3] = {3, 2, 3};
+    static const int n2s[3][3] = {{0, 1, 2}, {0, 4, 0}, {2, 3, 4}};           /* live n2 per n1, ascending            */
+    static const int as_[3][3] = {{0, 3, 6}, {5, 2, 0}, {1, 4, 7}};           /* a = (5 n1 + 3 n2) mod 15 of each one  */
+    float Yr[3][5], Yi[3][5];
+    for (int n1 = 0; n1 < 3; ++n1) {
+        const int m = cnt[n1], dc = (n2s[n1][0] == 0);
+        float sr = zr[as_[n1][0]], si = zi[as_[n1][0]];
+        for (int i = 1; i < m; ++i) { sr = sr + zr[as_[n1][i]]; si = si + zi[as_[n1][i]]; }
+        Yr[n1][0] = sr; Yi[n1][0] = si;
+        for (int k2 = 1; k2 <= 2; ++k2) {
+            float Ps = 0.0f, Qs = 0.0f, Rs = 0.0f, Ss = 0.0f;
+            for (int i = dc; i < m; ++i) {
+                const float xr = zr[as_[n1][i]], xi = zi[as_[n1][i]];
+                const float wr = w5r[(n2s[n1][i] * k2) % 5], wi = w5i[(n2s[n1][i] * k2) % 5];
+                if (i == dc) { Ps = xr * wr; Qs = xi * wi; Rs = xr * wi; Ss = xi * wr; }
+                else { Ps = fmaf(xr, wr, Ps); Qs = fmaf(xi, wi, Qs); Rs = fmaf(xr, wi, Rs); Ss = fmaf(xi, wr, Ss); }
+            }
+            if (dc) {
+                const float dr = zr[as_[n1][0]], di = zi[as_[n1][0]];
+                Yr[n1][k2] = dr + (Ps - Qs);     Yi[n1][k2] = di + (Rs + Ss);
+                Yr[n1][5 - k2] = dr + (Ps + Qs); Yi[n1][5 - k2] = di + (Ss - Rs);
+            } else {
+                Yr[n1][k2] = Ps - Qs;     Yi[n1][k2] = Rs + Ss;
+                Yr[n1][5 - k2] = Ps + Qs; Yi[n1][5 - k2] = Ss - Rs;
+            }
+        }
+    }
+    for (int k2 = 0; k2 < 5; ++k2) {
+        const float y0r = Yr[0][k2], y0i = Yi[0][k2], y1r = Yr[1][k2], y1i = Yi[1][k2], y2r = Yr[2][k2], y2i = Yi[2][k2];
+        outr[(6 * k2) % 15] = (y0r + y1r) + y2r;  outi[(6 * k2) % 15] = (y0i + y1i) + y2i;
+        const float tr = y1r + y2r, ti = y1i + y2i, dr = y1r - y2r, di = y1i - y2i;
+        const float mr = fmaf(tr, -0.5f, y0r), mi = fmaf(ti, -0.5f, y0i);
+        outr[(10 + 6 * k2) % 15] = fmaf(-w3s, di, mr);  outi[(10 + 6 * k2) % 15] = fmaf(w3s, dr, mi);
+        outr[(20 + 6 * k2) % 15] = fmaf(w3s, di, mr);   outi[(20 + 6 * k2) % 15] = fmaf(-w3s, dr, mi);
+    }
+}
+
 /* x[0 .. 2*npack) real (implicitly zero padded to 2*NZ); pw[k] = |X[k]|^2 for k in [0, nbins), nbins <= NZ + 1 */
 static void spectrum_packed(const fft_plan *P, const float *x, float *pw, int nbins)
 {
@@ -73,6 +133,18 @@ static void spectrum_packed(const fft_plan *P, const float *x, float *pw, int nb
     for (int b = 0; b < NB; ++b) {
         int amax = 0;
         while (amax < na && NB * amax + b < P->npack) ++amax;              /* inputs a < amax are live */
+        if (na == 15) {
+            float zr[8], zi[8], cr[15], ci[15];
+            for (int a = 0; a < 8; ++a) { zr[a] = (a < amax) ? x[2 * (NB * a + b)] : 0.0f; zi[a] = (a < amax) ? x[2 * (NB * a + b) + 1] : 0.0f; }
+            dft15_pfa8(zr, zi, cr, ci);
+            yr[0][rev7[b]] = cr[0]; yi[0][rev7[b]] = ci[0];                   /* c = 0: WN^0 = 1, no multiply */
+            for (int c = 1; c < 15; ++c) {
+                float qr, qi;
+                CMUL(cr[c], ci[c], P->wnr[b * c], P->wni[b * c], qr, qi);
+                yr[c][rev7[b]] = qr; yi[c][rev7[b]] = qi;
+            }
+            continue;
+        }
         const float z0r = x[2 * b], z0i = x[2 * b + 1];
         float s0r = z0r, s0i = z0i;
         for (int a = 1; a < amax; ++a) { s0r = s0r + x[2 * (NB * a + b)]; s0i = s0i + x[2 * (NB * a + b) + 1]; }
@@ -99,10 +171,20 @@ static void spectrum_packed(const fft_plan *P, const float *x, float *pw, int nb
             for (int base = 0; base < NB; base += len) {
                 for (int k = 0; k < half; ++k) {
                     const float ur = yr[c][base + k], ui = yi[c][base + k];
-                    float tr, ti;
-                    CMUL(yr[c][base + k + half], yi[c][base + k + half], w128r[k * step], w128i[k * step], tr, ti);
-                    yr[c][base + k] = ur + tr;        yi[c][base + k] = ui + ti;
-                    yr[c][base + k + half] = ur - tr; yi[c][base + k + half] = ui - ti;
+                    const float vr = yr[c][base + k + half], vi = yi[c][base + k + half];
+                    const int kw = k * step;
+                    if (len <= 8 && kw == 0) {                        /* w = (1, 0)  */
+                        yr[c][base + k] = ur + vr;        yi[c][base + k] = ui + vi;
+                        yr[c][base + k + half] = ur - vr; yi[c][base + k + half] = ui - vi;
+                    } else if (len <= 8 && kw == NB / 4) {            /* w = (0, -1): t = (v.i, -v.r) */
+                        yr[c][base + k] = ur + vi;        yi[c][base + k] = ui - vr;
+                        yr[c][base + k + half] = ur - vi; yi[c][base + k + half] = ui + vr;
+                    } else {
+                        const float wr = w128r[kw], wi = w128i[kw];
+                        const float ar = fmaf(vr, wr, fmaf(-vi, wi, ur)), ai = fmaf(vr, wi, fmaf(vi, wr, ui));
+                        yr[c][base + k] = ar;                    yi[c][base + k] = ai;
+                        yr[c][base + k + half] = fmaf(2.0f, ur, -ar); yi[c][base + k + half] = fmaf(2.0f, ui, -ai);
+                    }
                 }
             }
         }
@@ -111,12 +193,12 @@ static void spectrum_packed(const fft_plan *P, const float *x, float *pw, int nb
         const int k2 = (nz - k) % nz, kk = k % nz;
         const float ar = yr[kk % na][kk / na], ai = yi[kk % na][kk / na];
         const float br = yr[k2 % na][k2 / na], bi = -yi[k2 % na][k2 / na];  /* conj(Z[N-k]) */
-        const float er = (ar + br) * 0.5f, ei = (ai + bi) * 0.5f;
-        const float orr = (ar - br) * 0.5f, oi = (ai - bi) * 0.5f;
+        const float sr = ar + br, si = ai + bi;
+        const float orr = ar - br, oi = ai - bi;
         float tr, ti;
-        CMUL(orr, oi, P->w2r[k], P->w2i[k], tr, ti);
-        const float xr = er + ti;            /* E + (-i) T */
-        const float xi = ei - tr;
+        CMUL(orr, oi, P->w2r[k], P->w2i[k], tr, ti);                        /* WH = 0.5 W2N */
+        const float xr = fmaf(sr, 0.5f, ti);   /* E + (-i) T */
+        const float xi = fmaf(si, 0.5f, -tr);
         pw[k] = fmaf(xr, xr, xi * xi);
     }
 }
