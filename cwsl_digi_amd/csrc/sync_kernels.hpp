@@ -622,12 +622,13 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
 #pragma unroll
         for (int q = 0; q < 8; ++q) aB[q] = 8u * (unsigned)((tid_ < NGRP ? c : 0) * SY_PITCH + sy_col(64 * blk + r + 8 * q));
     }
-    if (tid_ >= 64 && tid_ < 128) s_w128[tid_ - 64] = tb.w128[tid_ - 64];
     // the two self-paired bins' twiddles go through LDS: fetched inside the loop (round 3) they were a global load on wave 0's path in EVERY
     // transform, whose vmcnt wait also drained the prefetched window -- ~550 cycles that the other three waves then spent at the barrier
     // (s_memtime stamps, scripts/gpu_stamps_spectra.py)
-    if (tid_ == 128) s_w128[64] = tb.w3840[NA * 64];
-    if (tid_ == 129) s_w128[65] = tb.w3840[NZ];
+    if (tid_ >= 64 && tid_ < 130) {
+        const float2 *src = (tid_ < 128) ? tb.w128 + (tid_ - 64) : tb.w3840 + (tid_ == 128 ? NA * 64 : NZ);
+        s_w128[tid_ - 64] = *src;
+    }
     // every loop-invariant load (twiddles, window) is waited for HERE, with the builtin the compiler's wait-count pass
     // understands: otherwise it keeps conservative vmcnt waits for them inside the loop (the first iteration could still
     // need them), and from the second iteration on those waits drain the prefetch in the middle of stage 1
@@ -735,8 +736,9 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         bfly(u2, v2, *reinterpret_cast<const float2 *>(w128_bytes + aw2[i]));
         if (izero[i]) {                                     // Z[0] and Z[NZ/2] pair with themselves
             s_pw[0] = unpack_power(u1, u1, w3[i][0]);
-            if (NA * 64 < nbins) s_pw[NA * 64] = unpack_power(v1, v1, s_w128[64]);
-            if (NZ < nbins) s_pw[NZ] = unpack_power(u1, u1, s_w128[65]);
+            // (the FT4 instantiation keeps its nine window pairs in registers and has none to spare for the LDS form: it fetches the two twiddles)
+            if (NA * 64 < nbins) s_pw[NA * 64] = unpack_power(v1, v1, WINDOW ? tb.w3840[NA * 64] : s_w128[64]);
+            if (NZ < nbins) s_pw[NZ] = unpack_power(u1, u1, WINDOW ? tb.w3840[NZ] : s_w128[65]);
             continue;
         }
         if (sparse) {
