@@ -46,14 +46,16 @@ HBM_PEAK_GBS = 8000.0                     # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_SAMPLE_DEMOD = 8.0 + 4.0 / 16   # demod kernel: 8 B IQ read + 0.25 B float audio write
 BYTES_PER_SAMPLE_PATH = 8.625             # + finalise: 0.25 B read + 0.125 B int16 write
 VALU_PEAK_TFLOPS = 157.3                  # MI355X_MICROARCH.md: FP32 vector peak (spec), an FMA counted as 2
-# FT8 sync stage, floating-point operations of the "spec v2" arithmetic (oracle/sync_oracle.c; an FMA = 2), per 3840-point symbol transform:
+# FT8 sync stage, floating-point operations of the "spec v3" arithmetic (oracle/sync_oracle.c; an FMA = 2), per 3840-point symbol transform:
 #   scale by 1/300                                  3 840
-#   stage 1: 128 columns x (output 0: 14; 7 conjugate pairs x (4 chains x 7 FMA = 56, combine 8, two twiddle products 12))  = 128 x 546 = 69 888
-#   stage 2: 15 rows x 7 radix-2 stages x 64 butterflies x 10                                                               = 67 200
-#   real-input unpack + |X|^2 of the stored bins:   20 per bin
+#   stage 1 (prime-factor 3 x 5 on the 8 live inputs): 128 columns x (five-point sums 122 + five three-point DFTs 100 + 14 twiddle products 84) = 128 x 306 = 39 168
+#   stage 2: 15 rows x 64 butterflies x (len 2, 4: 4 + 4; len 8: half plain 4, half three-fmaf 12; len 16..128: 4 x 12)                        = 61 440
+#   real-input unpack + |X|^2 of the stored bins:   17 per bin
+# (spec v2, rounds 2-3: 3 840 + 69 888 + 67 200 + 20 per bin = 160 768 at 992 bins; v3: 121 312 -- a quarter fewer operations for the same transform,
+# so the stage's TFLOP/s figure FALLS while its time does: compare times across rounds, not fractions of the FP32 peak)
 # and per searched bin of the Costas stage: 7-tone sums 6 x 378 adds, 125 lags x (42 adds + 30 for the two sync ratios) = 11 268
 def sync_flops_per_slot(nbins, n_search_bins):
-    per_transform = 3840 + 69888 + 67200 + 20 * nbins
+    per_transform = 3840 + 39168 + 61440 + 17 * nbins
     return 372 * per_transform + n_search_bins * 11268, per_transform
 
 

@@ -103,7 +103,7 @@ __device__ __forceinline__ float2 cmul_u(float2 a, float2 b)          // un-fuse
     const float ac = a.x * b.x, bd = a.y * b.y, ad = a.x * b.y, bc = a.y * b.x;
     return make_float2(ac - bd, ad + bc);
 }
-// the transform's complex product (spec v2): one rounding fewer per component, same bits as the oracle's CMUL
+// the transform's complex product (twiddles behind stage 1, unpack): one rounding fewer per component, same bits as the oracle's CMUL
 __device__ __forceinline__ float2 cmul_f(float2 v, float2 w)
 {
     return make_float2(__builtin_fmaf(v.x, w.x, -(v.y * w.y)), __builtin_fmaf(v.x, w.y, v.y * w.x));
@@ -112,12 +112,13 @@ __device__ __forceinline__ float2 cmul_f(float2 v, float2 w)
 // ---------------------------------------------------------------------------------------------
 // Symbol spectra.  grid (NHSYM, n_channels), 256 threads.
 //
-// The transform is DEFINED (oracle/sync_oracle.c, "spec v2") as: pack z[m] = x[2m] + i x[2m+1] (m < NPACK, zero
-// above), NZ = NA x 128: NA-point DFTs over a (m = 128a + b) evaluated in conjugate pairs with fmaf chains ->
-// twiddle W_NZ^(bc) -> NA radix-2 DIT FFTs of 128 points (bit-reversed input) -> real-input unpack with W_2NZ^k.
+// The transform is DEFINED (oracle/sync_oracle.c, "spec v3") as: pack z[m] = x[2m] + i x[2m+1] (m < NPACK, zero
+// above), NZ = NA x 128: NA-point DFTs over a (m = 128a + b) -- FT8: prime-factor 3 x 5 on the eight live inputs, FT4: conjugate
+// pairs with fmaf chains -> twiddle W_NZ^(bc) -> NA radix-2 DIT FFTs of 128 points (bit-reversed input, three-fmaf butterflies) ->
+// real-input unpack with 0.5 W_2NZ^k.
 // Any schedule that evaluates the same operations gives the same bits; here each lane does 8-point groups (three
-// radix-2 stages) in registers per LDS pass, and products by the exact table entries W^0 = (1,0) and
-// W128^32 = (0,-1) are not multiplied out (identical up to the sign of zeros, which |X|^2 cannot see).
+// radix-2 stages) in registers per LDS pass.  In the first three stages the butterflies with the exact table entries W^0 = (1,0) and
+// W128^32 = (0,-1) are plain additions BY DEFINITION of the spec (from len = 16 on every butterfly takes the fmaf form, whatever its twiddle).
 // LDS image of the NA x 128 work array: row pitch 144 complex (consecutive rows start 32 banks apart: the two rows of a
 // 32-lane ds_read_b64 group fall into different halves of the 64 banks) and, after pass A, logical column i stored at
 // i ^ ((i >> 3) & 15) (a 16-lane ds_write_b64 group -- one row, 16 eight-point groups -- hits 16 distinct bank pairs).
@@ -161,7 +162,7 @@ __device__ __forceinline__ void stage1_load_tw(const float2 *__restrict__ wn, in
     }
 }
 
-// W_NA^k = (cos, -sin)(2 pi k / NA), k <= NA / 2, as COMPILE-TIME constants (NA = 15: FT8, NA = 9: FT4): the values of spec v2's table --
+// W_NA^k = (cos, -sin)(2 pi k / NA), k <= NA / 2, as COMPILE-TIME constants (NA = 15: FT8, NA = 9: FT4): the values of the oracle's table --
 // float(cos), float(-sin) of the double angle, W^0 exact -- written out as hexadecimal floats; sync_ensure_shared recomputes the table at
 // start-up and refuses to run if a single bit differs.  Round 4: they used to arrive as kernel arguments, i.e. in SCALAR registers,
 // and on gfx950 a one-lane-wide FP32 operation with a scalar-register source issues at HALF rate (4.2 against 2.35 cycles per wave64
@@ -514,14 +515,14 @@ constexpr int SPEC_JPER = CWSLG_SPEC_JPER;   // symbol steps per workgroup (FT8:
 // (Rounds 2-3 carried a matrix-core form of spec v2's stage 1 -- its fmaf chains as v_mfma_f32_32x32x2_f32 steps -- as a lab variant: measured
 // slower twice, 1.56 against 1.29 ms per 512 slots and 6.3 against 5.2 ms per 4096; it went with spec v2's stage 1.)
 #if defined(CWSLG_STAMP) && defined(CWSLG_STAMP_SPEC)
-// diagnostic build only (scripts/gpu_stamps_spectra.py): s_memtime of waves 0 and 2 at the phase seams of the workgroup's THIRD transform
+// diagnostic build only (scripts/gpu_stamps_spectra.py): s_memtime of every wave at the phase seams of the workgroup's THIRD transform
 #define PSTAMP(slot)                                                                                                               \
     do {                                                                                                                           \
         const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                                                  \
-        if (j == j0 + 2 && (tid_ & 127) == 0 && wg_ < 32768) {                                                                     \
+        if (j == j0 + 2 && (tid_ & 63) == 0 && wg_ < 16384) {                                                                     \
             unsigned long long t_;                                                                                                 \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                             \
-            g_stamps[16 * wg_ + 8 * (tid_ >> 7) + (slot)] = t_;                                                                    \
+            g_stamps[32 * wg_ + 8 * (tid_ >> 6) + (slot)] = t_;                                                                    \
         }                                                                                                                          \
     } while (0)
 #else
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     static_assert(NGRP <= 256, "geometry");
     __shared__ __attribute__((aligned(16))) float s_pw[NIN + 32];     // one power row: nbins <= NIN + 32 (FT8: the widest search stores 1952)
     __shared__ float2 s_y[NA][SY_PITCH];
-    __shared__ float2 s_w128[66];                          // W_128^k, k < 64; [64], [65]: the unpack twiddles of bins NA * 64 and NZ (izero lane)
+    __shared__ float2 s_w128[64];
     const SyncWork *w = works + blockIdx.y;
     const int j0 = blockIdx.x * SPEC_JPER;
     const int jend = min(j0 + SPEC_JPER, nsteps);
@@ -568,67 +569,67 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     Stage1Tw<NA> tw1;
     if (tid_ < 128) stage1_load_tw<0, NA>(tb.w1920, b_, tw1);
     else stage1_load_tw<1, NA>(tb.w1920, b_, tw1);
-    // the unpack twiddles W_2NZ^K of this thread's items (bins K1, K2 of each; the two upper bins of an item are rare for
-    // FT8's default range and fetched on demand)
-    float2 w3[IPT][2];
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-        const int it = tid_ + 256 * i;
-        const int r = it >> 6, q = it & 63;
-        const int K1 = NA * q + r;
-        const int K2 = (r == 0) ? NA * ((64 - q) & 63) : NA * (63 - q) + NA - r;
-        const bool live = it < NITEM && !(r == 0 && q > 32);
-        w3[i][0] = (live && K1 < nbins) ? tb.w3840[K1] : make_float2(0.f, 0.f);
-        w3[i][1] = (live && K2 < nbins) ? tb.w3840[K2] : make_float2(0.f, 0.f);
-    }
-    // "sparse upper half": the stored row ends at most 32 bins above NA * 64 (FT8's default search: 992 against 960).  Then bins K1, K2
-    // of every item are inside the row (no tests, no exec masking), and the few bins above NA * 64 -- K3 of the columns q <= 2, K4 of
-    // q >= 62 -- are the job of ONE wave after the item loop, one (row pair, column) slot per lane, instead of two more unpacks in
-    // every item of every wave that serve two or three lanes each (round-3 ISA count: ~80 of a wave's ~690 VALU instructions per
-    // transform).  Same butterflies, same unpack on the same operands: the same bits.
+    // "sparse upper half" (FT8's default search: the stored row ends at most 32 bins above NA * 64 = 960).  The last stage works on ITEMS: a
+    // thread takes the butterfly pair P1 = (row r, column q), P2 = (row NA - r, column 63 - q) and unpacks the bins K1 = NA q + r and
+    // K2 = NA (63 - q) + NA - r from their results.  512 item slots (8 rows x 64 columns, two per thread), of which row 0 -- which pairs with
+    // itself -- fills only columns 0..32.  Round 4: the 31 idle lanes of row 0 (wave 0, columns 33..63) take the 31 bins 961..991 ABOVE 960
+    // (kind 2: K = NA (q + 64) + r pairs v1 with u2; kind 3: K = NA (127 - q) + NA - r pairs v2 with u1), and lane 0 takes the two self-paired
+    // bins 0 and 960 (kind 1) -- by operand SELECTS inside the same instruction stream, so that every wave runs exactly two items.  Round 3
+    // gave the upper bins to one wave as a section of its own behind the item loop and the self-paired bins to a divergent branch of wave 0:
+    // s_memtime stamps (scripts/gpu_stamps_spectra.py) showed those two waves 230 and 320 cycles behind the other two at the barrier of
+    // every transform.  Same butterflies, same unpack on the same operands: the same bits.
     const bool sparse = nbins >= NA * 64 && nbins <= NA * 64 + 32 && NH == 7;          // wave-uniform (kernel argument)
-    const int ul_ = tid_ & 63, ur_ = ul_ & 7, usel_ = ul_ >> 3;
-    const bool uk3_ = usel_ < 3;
-    const int uq_ = uk3_ ? usel_ : 63 - (usel_ - 3);
-    const int ur2_ = (ur_ == 0) ? 0 : NA - ur_, uk2_ = (ur_ == 0) ? ((64 - uq_) & 63) : 63 - uq_;
-    const int uK_ = uk3_ ? NA * (uq_ + 64) + ur_ : NA * (uk2_ + 64) + ur2_;
-    const bool ulive_ = sparse && (tid_ >> 6) == 3 && usel_ < 5 && !(ur_ == 0 && (uq_ == 0 || !uk3_)) && uK_ < nbins;
-    const float2 w3u = ulive_ ? tb.w3840[uK_] : make_float2(0.f, 0.f);
+    constexpr unsigned PW_DUMMY = 4u * (NIN + 31);         // byte offset of a float of s_pw that no stored row reaches in sparse mode
     // LDS byte offsets of the last stage's operands and of pass B's eight points, computed ONCE (from the real thread index): the
-    // opaque copy below keeps everything else out of registers, but these 24 are worth theirs -- recomputed per transform they were
+    // opaque copy below keeps everything else out of registers, but these are worth theirs -- recomputed per transform they were
     // ~90 of a wave's ~610 VALU instructions (swizzle, row pitch products, shifts).
-    unsigned au1[IPT], au2[IPT], aw1[IPT], aw2[IPT], ap1[IPT], ap2[IPT];
+    float2 w3[IPT][2];
+    unsigned au1[IPT], au2[IPT], aw1[IPT], aw2[IPT], ap1[IPT], ap2[IPT];   // ap1 of item 0 carries the kind in bits 16-17 (sparse mode)
     bool iskip[IPT], izero[IPT];
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
         const int it = tid_ + 256 * i;
-        const int r = it >> 6, q = it & 63;
+        int r = it >> 6, q = it & 63, kind = 0;
+        bool skip = it >= NITEM || (r == 0 && q > 32);
+        int Kup = 0;
+        if (sparse && i == 0 && r == 0 && q > 32) {        // wave 0, lanes 33..63: the bin Kup = 928 + q above NA * 64
+            Kup = NA * 64 - 32 + q;
+            const int d = Kup - NA * 64, a = d / NA, rem = d % NA;
+            if (rem <= NH) { kind = 2; r = rem; q = a; }
+            else { kind = 3; r = NA - rem; q = 63 - a; }
+            skip = Kup >= nbins;
+        }
         const int r2 = (r == 0) ? 0 : NA - r;
         const int k2 = (r == 0) ? ((64 - q) & 63) : 63 - q;
-        iskip[i] = it >= NITEM || (r == 0 && q > 32);
-        izero[i] = r == 0 && q == 0;
-        const int rr = iskip[i] ? 0 : r, rr2 = iskip[i] ? 0 : r2;
+        izero[i] = r == 0 && q == 0 && kind == 0;
+        if (sparse && izero[i]) kind = 1;
+        iskip[i] = skip;
+        const int rr = skip ? 0 : r, rr2 = skip ? 0 : r2;
         // the partner column k + 64 is not kept: sy_col(k + 64) = 64 + (sy_col(k) ^ 8) for k < 64, and a row starts at a multiple of 128 bytes,
         // so its byte address is (address of column k ^ 64) + 512 -- one XOR at the point of use, the 512 rides in the instruction's offset field
         static_assert((SY_PITCH * 8) % 128 == 0, "row pitch");
         au1[i] = 8u * (unsigned)(rr * SY_PITCH + sy_col(q));
         au2[i] = 8u * (unsigned)(rr2 * SY_PITCH + sy_col(k2));
         aw1[i] = 8u * (unsigned)q; aw2[i] = 8u * (unsigned)k2;
-        ap1[i] = 4u * (unsigned)(NA * q + r); ap2[i] = 4u * (unsigned)(NA * k2 + r2);
+        int K1 = NA * q + r, K2 = NA * k2 + r2;            // the bins of a plain item
+        unsigned p1 = 4u * (unsigned)K1, p2 = 4u * (unsigned)K2;
+        if (kind == 1) { K2 = NA * 64; p2 = (K2 < nbins) ? 4u * (unsigned)K2 : PW_DUMMY; }        // bins 0 and NA * 64, each paired with itself
+        if (kind >= 2) { K1 = Kup; p1 = 4u * (unsigned)Kup; K2 = nbins; p2 = PW_DUMMY; }          // one bin; the second unpack lands in the dummy
+        ap1[i] = p1 | ((unsigned)kind << 16); ap2[i] = p2;
+        w3[i][0] = (!skip && K1 < nbins) ? tb.w3840[K1] : make_float2(0.f, 0.f);
+        w3[i][1] = (!skip && K2 < nbins) ? tb.w3840[K2] : make_float2(0.f, 0.f);
     }
+    const bool wave0_ = __builtin_amdgcn_readfirstlane(tid_ >> 6) == 0;
     unsigned aB[8];
     {
         const int c = tid_ >> 4, g = tid_ & 15, blk = g >> 3, r = g & 7;
 #pragma unroll
         for (int q = 0; q < 8; ++q) aB[q] = 8u * (unsigned)((tid_ < NGRP ? c : 0) * SY_PITCH + sy_col(64 * blk + r + 8 * q));
     }
-    // the two self-paired bins' twiddles go through LDS: fetched inside the loop (round 3) they were a global load on wave 0's path in EVERY
-    // transform, whose vmcnt wait also drained the prefetched window -- ~550 cycles that the other three waves then spent at the barrier
-    // (s_memtime stamps, scripts/gpu_stamps_spectra.py)
-    if (tid_ >= 64 && tid_ < 130) {
-        const float2 *src = (tid_ < 128) ? tb.w128 + (tid_ - 64) : tb.w3840 + (tid_ == 128 ? NA * 64 : NZ);
-        s_w128[tid_ - 64] = *src;
-    }
+    // (the twiddles of the two self-paired bins 0 and NA * 64 are per-lane registers like every other item's -- w3[0][] of lane 0: fetched inside
+    // the loop, as in round 3, they were a global load on wave 0's path in EVERY transform whose vmcnt wait also drained the prefetched window:
+    // ~550 cycles that the other three waves then spent at the barrier; s_memtime stamps, scripts/gpu_stamps_spectra.py)
+    if (tid_ >= 64 && tid_ < 128) s_w128[tid_ - 64] = tb.w128[tid_ - 64];
     // every loop-invariant load (twiddles, window) is waited for HERE, with the builtin the compiler's wait-count pass
     // understands: otherwise it keeps conservative vmcnt waits for them inside the loop (the first iteration could still
     // need them), and from the second iteration on those waits drain the prefetch in the middle of stage 1
@@ -657,7 +658,10 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     // transform to retire before the top of the next iteration waits for vmcnt(0)
     if (j > j0) {
         CWSLG_GLOBAL v4f *out4 = reinterpret_cast<CWSLG_GLOBAL v4f *>(as_global_rw(w->spectra) + (size_t)(j - 1) * nbins);
-        for (int k4 = tid; 4 * k4 < nbins; k4 += 256) out4[k4] = *reinterpret_cast<const v4f *>(s_pw + 4 * k4);
+        // by waves 2-3 only when stage 1 is the prime-factor form: their half of it is 32 instructions shorter than waves 0-1's (stamps: they
+        // waited ~430 cycles at the barrier behind stage 1)
+        if (NA == 15) { if (tid >= 128) for (int k4 = tid - 128; 4 * k4 < nbins; k4 += 128) out4[k4] = *reinterpret_cast<const v4f *>(s_pw + 4 * k4); }
+        else for (int k4 = tid; 4 * k4 < nbins; k4 += 256) out4[k4] = *reinterpret_cast<const v4f *>(s_pw + 4 * k4);
     }
     if (j + 1 < jend) {                                   // wave-uniform: the next step's window, in flight during this transform
 #pragma unroll
@@ -734,16 +738,24 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         float2 u2 = *reinterpret_cast<const float2 *>(sy_bytes + au2[i]), v2 = *reinterpret_cast<const float2 *>(sy_bytes + (au2[i] ^ 64u) + 512);
         bfly(u1, v1, *reinterpret_cast<const float2 *>(w128_bytes + aw1[i]));
         bfly(u2, v2, *reinterpret_cast<const float2 *>(w128_bytes + aw2[i]));
-        if (izero[i]) {                                     // Z[0] and Z[NZ/2] pair with themselves
-            s_pw[0] = unpack_power(u1, u1, w3[i][0]);
-            // (the FT4 instantiation keeps its nine window pairs in registers and has none to spare for the LDS form: it fetches the two twiddles)
-            if (NA * 64 < nbins) s_pw[NA * 64] = unpack_power(v1, v1, WINDOW ? tb.w3840[NA * 64] : s_w128[64]);
-            if (NZ < nbins) s_pw[NZ] = unpack_power(u1, u1, WINDOW ? tb.w3840[NZ] : s_w128[65]);
+        if (sparse) {
+            float2 A1 = u1, B1 = v2, A2 = u2;
+            unsigned p1 = ap1[i];
+            if (i == 0 && wave0_) {                        // wave-uniform: row 0's lanes -- plain items, the self-paired pair, the bins above NA * 64
+                const unsigned kind = p1 >> 16;
+                p1 &= 0xFFFFu;
+                A1 = (kind == 2) ? v1 : (kind == 3) ? v2 : u1;
+                B1 = (kind == 0) ? v2 : (kind == 2) ? u2 : u1;
+                A2 = (kind == 1) ? v1 : u2;
+            }
+            *reinterpret_cast<float *>(pw_bytes + p1) = unpack_power(A1, B1, w3[i][0]);
+            *reinterpret_cast<float *>(pw_bytes + ap2[i]) = unpack_power(A2, v1, w3[i][1]);
             continue;
         }
-        if (sparse) {
-            *reinterpret_cast<float *>(pw_bytes + ap1[i]) = unpack_power(u1, v2, w3[i][0]);
-            *reinterpret_cast<float *>(pw_bytes + ap2[i]) = unpack_power(u2, v1, w3[i][1]);
+        if (izero[i]) {                                     // Z[0] and Z[NZ/2] pair with themselves
+            s_pw[0] = unpack_power(u1, u1, w3[i][0]);
+            if (NA * 64 < nbins) s_pw[NA * 64] = unpack_power(v1, v1, tb.w3840[NA * 64]);
+            if (NZ < nbins) s_pw[NZ] = unpack_power(u1, u1, tb.w3840[NZ]);
             continue;
         }
         const int K1 = (int)(ap1[i] >> 2), K2 = (int)(ap2[i] >> 2);
@@ -752,15 +764,6 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         if (K2 < nbins) s_pw[K2] = unpack_power(u2, v1, w3[i][1]);
         if (K3 < nbins) s_pw[K3] = unpack_power(v1, u2, tb.w3840[K3]);
         if (K4 < nbins) s_pw[K4] = unpack_power(v2, u1, tb.w3840[K4]);
-    }
-    if (sparse && (tid >> 6) == 3) {                        // wave-uniform: the bins above NA * 64, one slot per lane
-        if (ulive_) {
-            float2 u1 = s_y[ur_][sy_col(uq_)], v1 = s_y[ur_][sy_col(uq_ + 64)];
-            float2 u2 = s_y[ur2_][sy_col(uk2_)], v2 = s_y[ur2_][sy_col(uk2_ + 64)];
-            bfly(u1, v1, s_w128[uq_]);
-            bfly(u2, v2, s_w128[uk2_]);
-            s_pw[uK_] = uk3_ ? unpack_power(v1, u2, w3u) : unpack_power(v2, u1, w3u);
-        }
     }
     for (int k = NZ + 1 + tid; k < nbins; k += 256) s_pw[k] = 0.0f;          // padding beyond the Nyquist bin
     PSTAMP(6);

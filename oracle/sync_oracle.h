@@ -17,9 +17,9 @@
  *                 (4 Hz, 0.04 s), sorted by sync, first maxcand kept.
  *
  * Because no external implementation can arbitrate, the ARITHMETIC is fully specified here (float32 operations
- * in a fixed order; the transform -- "spec v2" at the top of sync_oracle.c -- is a fixed factorisation
- * 3840 -> real-pack 1920 = 15 x 128 [FT4: 2304 -> 1152 = 9 x 128], NA-point DFTs in conjugate pairs with
- * correctly-rounded fmaf chains, radix-2 DIT butterflies whose complex product is (fmaf, fmaf), host twiddles
+ * in a fixed order; the transform -- "spec v3" at the top of sync_oracle.c -- is a fixed factorisation
+ * 3840 -> real-pack 1920 = 15 x 128 [FT4: 2304 -> 1152 = 9 x 128], NA-point DFTs (FT8: prime-factor 3 x 5 on the eight
+ * live inputs; FT4: conjugate pairs with correctly-rounded fmaf chains), radix-2 DIT butterflies of three fmaf per component, host twiddles
  * from double cos/sin with exact cardinal points; everything after the spectra is un-fused + - * /)
  * so that the GPU kernels reproduce it BIT FOR BIT and "bit-identical candidate
  * lists" is a testable statement.  Ordering of the final list: descending sync, ties by ascending bin, then lag.

@@ -1,5 +1,5 @@
 """Diagnostic: where a transform of symbol_spectra_v2_kernel spends its time (s_memtime stamps of a -DCWSLG_STAMP -DCWSLG_STAMP_SPEC lab build;
-waves 0 and 2 of every workgroup, its third transform)."""
+every wave of every workgroup, its third transform)."""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,7 @@ import cwsl_digi_amd as P
 ctx = P.Context(0)
 ctx.set_exact(False)
 ctx.enable_sync(True, 1.5, 200, 200, 3000)
-S, N, BLK = 1024, 2880000, 2048
+S, N, BLK = 512, 2880000, 2048
 rb = N // BLK + 3
 for s in range(S):
     rx = ctx.receiver_open(192000, BLK, 0, ring_blocks=rb)
@@ -25,9 +25,9 @@ buf = np.zeros(8 * n, np.uint64)
 rc = ctx.L.cwslg_debug_read_stamps(buf.ctypes.data_as(C.c_void_p), C.c_size_t(8 * n))
 assert rc == 0
 nwg = 31 * S
-st = buf.reshape(n // 2, 2, 8).astype(np.int64)[:min(nwg, 32768)]
+st = buf.reshape(n // 4, 4, 8).astype(np.int64)[:min(nwg, 16384)]
 names = ["convert + issue prefetch + stage 1", "barrier 1", "pass A", "pass B", "barrier 2", "last stage + unpack", "barrier 3"]
-for wv, label in ((0, "wave 0 (stage-1 pairs 1-3 + output 0)"), (1, "wave 2 (stage-1 pairs 4-7)")):
+for wv, label in ((0, "wave 0 (stage 1: k2 = 0, 1, 4)"), (1, "wave 1 (same)"), (2, "wave 2 (stage 1: k2 = 2, 3)"), (3, "wave 3 (same; + the bins above 960)")):
     s_ = st[:, wv, :]
     d = np.diff(s_, axis=1)
     ok = (d > 0).all(axis=1) & (d < 10 ** 6).all(axis=1)
