@@ -236,7 +236,7 @@ __device__ __forceinline__ void stage1_pfa15(const float2 (&z)[8], float2 (*s_y)
         const float2 x1 = make_float2(__builtin_fmaf(-W3_S, d.y, m.x), __builtin_fmaf(W3_S, d.x, m.y));
         const float2 x2 = make_float2(__builtin_fmaf(W3_S, d.y, m.x), __builtin_fmaf(-W3_S, d.x, m.y));
         const int c0 = pfa15_c(0, k2), c1 = pfa15_c(1, k2), c2 = pfa15_c(2, k2);
-        if (c0 == 0) s_y[0][b] = x0;                       // W_NZ^0 = 1: no multiply
+        if (c0 == 0) s_y[0][b] = make_float2(x0.x * (1.0f / 300.0f), x0.y * (1.0f / 300.0f));       // WN'^0 = (fac, 0): plain products
         else s_y[c0][b] = cmul_f(x0, tw[n++]);
         s_y[c1][b] = cmul_f(x1, tw[n++]);
         s_y[c2][b] = cmul_f(x2, tw[n++]);
@@ -339,8 +339,8 @@ __global__ __launch_bounds__(256) void symbol_spectra_kernel(const SyncWork *__r
         const unsigned v[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float lo = fac * (float)(short)(v[k] & 0xFFFFu);
-            float hi = fac * (float)(short)(v[k] >> 16);
+            float lo = (float)(short)(v[k] & 0xFFFFu), hi = (float)(short)(v[k] >> 16);
+            if (NA != 15) { lo = fac * lo; hi = fac * hi; }            // FT8 (spec v3): the scale rides in stage 1's twiddle
             if (WINDOW) { lo = lo * tb.win[8 * t + 2 * k]; hi = hi * tb.win[8 * t + 2 * k + 1]; }
             s_x[8 * t + 2 * k] = lo;
             s_x[8 * t + 2 * k + 1] = hi;
@@ -649,8 +649,8 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) {
         const bool live = 128 * a + b < NPACK;
-        float lo = fac * (float)(short)(raw[a] & 0xFFFFu);
-        float hi = fac * (float)(short)(raw[a] >> 16);
+        float lo = (float)(short)(raw[a] & 0xFFFFu), hi = (float)(short)(raw[a] >> 16);
+        if (NA != 15) { lo = fac * lo; hi = fac * hi; }                // FT8 (spec v3): the scale rides in stage 1's twiddle
         if (WINDOW) { lo = lo * wn[WINDOW ? a : 0].x; hi = hi * wn[WINDOW ? a : 0].y; }
         z[a] = live ? make_float2(lo, hi) : make_float2(0.f, 0.f);
     }

@@ -9,6 +9,8 @@
 
 /*
  * Transform of record ("spec v3", round 4), shared by FT8 (2*NZ = 3840, NA = 15) and FT4 (2*NZ = 2304, NA = 9):
+ *   input    FT8: x = the int16 samples as floats, the 1/300 of sync8 rides in stage 1's twiddle (WN' = fl(fac * WN), output 0 takes a plain
+ *            multiplication by fac); FT4: x = (fac * d) * window
  *   pack     z[m] = x[2m] + i x[2m+1]  (m < NZ; FT8: zero for m >= 960), m = 128 a + b
  *   stage 1  for each column b an NA-point DFT over a, then y_c *= WN[b c] for c >= 1 (cmul below).
  *            NA = 9: evaluated in conjugate pairs (c, NA-c):
@@ -62,6 +64,10 @@ static void make_plan(fft_plan *P, int na, int npack)
     for (int k = 0; k <= P->nz; ++k) { P->w2r[k] = (float)cos(pi * k / P->nz); P->w2i[k] = (float)(-sin(pi * k / P->nz)); }
     P->wnr[0] = 1.0f; P->wni[0] = 0.0f; P->w2r[0] = 1.0f; P->w2i[0] = 0.0f;
     for (int k = 0; k <= P->nz; ++k) { P->w2r[k] = 0.5f * P->w2r[k]; P->w2i[k] = 0.5f * P->w2i[k]; }      /* WH = 0.5 * W2N, exact */
+    if (na == 15) {                                      /* FT8: the input scale 1/300 folded into the twiddle behind stage 1 */
+        const float fac = 1.0f / 300.0f;
+        for (int k = 0; k < P->nz; ++k) { P->wnr[k] = fac * P->wnr[k]; P->wni[k] = fac * P->wni[k]; }
+    }
 }
 
 static void make_tables(void)
@@ -137,7 +143,7 @@ static void spectrum_packed(const fft_plan *P, const float *x, float *pw, int nb
             float zr[8], zi[8], cr[15], ci[15];
             for (int a = 0; a < 8; ++a) { zr[a] = (a < amax) ? x[2 * (NB * a + b)] : 0.0f; zi[a] = (a < amax) ? x[2 * (NB * a + b) + 1] : 0.0f; }
             dft15_pfa8(zr, zi, cr, ci);
-            yr[0][rev7[b]] = cr[0]; yi[0][rev7[b]] = ci[0];                   /* c = 0: WN^0 = 1, no multiply */
+            yr[0][rev7[b]] = cr[0] * P->wnr[0]; yi[0][rev7[b]] = ci[0] * P->wnr[0];     /* c = 0: WN'^0 = (fac, 0): plain products */
             for (int c = 1; c < 15; ++c) {
                 float qr, qi;
                 CMUL(cr[c], ci[c], P->wnr[b * c], P->wni[b * c], qr, qi);
@@ -208,10 +214,9 @@ int orc_ft8_spectra(const int16_t *frame, float *s_out, int nbins)
     if (!tables_ready) make_tables();
     if (nbins < 1 || nbins > FT8_NH1 + 1) return -1;
     float x[FT8_NSPS];
-    const float fac = 1.0f / 300.0f;
     for (int j = 0; j < FT8_NHSYM; ++j) {
         const int16_t *d = frame + (size_t)FT8_NSTEP * j;
-        for (int n = 0; n < FT8_NSPS; ++n) x[n] = fac * (float)d[n];
+        for (int n = 0; n < FT8_NSPS; ++n) x[n] = (float)d[n];          /* the scale fac rides in stage 1's twiddle (spec v3) */
         spectrum_packed(&plan8, x, s_out + (size_t)j * nbins, nbins);
     }
     return 0;
