@@ -5,12 +5,12 @@
 // container.  These kernels implement the published FT8 candidate search (WSJT-X 2.6.x lib/ft8/sync8.f90,
 // ft8_params.f90: NSPS=1920, NFFT1=3840, NSTEP=480, NHSYM=372, JZ=62, icos7 = 3,1,4,0,6,5,2) with an
 // arithmetic specification shared with the repository's own CPU restatement (oracle/sync_oracle.c):
-// every float operation is un-fused and in a fixed order, the FFT factorisation and twiddle tables are
-// fixed, so the candidate lists are BIT-IDENTICAL to that restatement (tests/test_gpu_sync.py).
+// every float operation is in a fixed order (fused only where the restatement says fmaf), the FFT factorisation and
+// twiddle tables are fixed ("spec v3", round 4), so the candidate lists are BIT-IDENTICAL to that restatement (tests/test_gpu_sync.py).
 //
 // Launches per slot boundary, all FT8 channels of the group batched in each:
 //   symbol_spectra_v2_kernel one workgroup per (12 symbol steps, channel): 1920 int16 -> packed 1920-point complex FFT
-//                         (15 x 128: 15-point DFTs + radix-2 DIT butterflies in LDS) -> |X|^2 rows
+//                         (15 x 128: prime-factor 15-point DFTs on the 8 live inputs + radix-2 DIT butterflies in LDS) -> |X|^2 rows
 //   ft8_sync_chan_kernel  one workgroup per channel: walks the 32-bin bands of the search range with a sliding LDS window (the next
 //                         band's lines in flight under the search), lane = two adjacent time lags, Costas correlation for 125 lags
 //                         with the LDS traffic of a bin as one hand-scheduled stream (sync2d_asm.inc), wavefront arg-max for the +-10
