@@ -52,9 +52,12 @@ __device__ __forceinline__ float2 lcmul(float2 v, float2 w)           // spec B'
 }
 
 // ---------------------------------------------------------------------------------------------
-// spec B stage 1.  grid (NB / 64, transforms, channels), FFTB_S1_NT threads (8 waves: with the 64 KB tile of NA = 125 two workgroups
-// fit a CU, and the scalar twiddle loads need the 4 waves per SIMD to hide their latency).
-constexpr int FFTB_S1_NT = 512;
+// spec B stage 1.  grid (NB / 64, transforms, channels), FFTB_S1_NT threads: three waves, each three groups of five outputs for NA = 45 (eight waves left
+// one of them two of the nine groups and the other seven one: same-box A/B on configs[4], long-sync stage 5.05-5.08 against 5.12 ms; five waves 5.18).
+#ifndef CWSLG_FFTB_S1_NT
+#define CWSLG_FFTB_S1_NT 192
+#endif
+constexpr int FFTB_S1_NT = CWSLG_FFTB_S1_NT;   // -D overrides are for A/B builds only
 template <int NA, int NB>
 __global__ __launch_bounds__(FFTB_S1_NT, 4) void fftb_stage1_kernel(const LongWork *__restrict__ works, FftbTables tb, const float2 *__restrict__ wfull,
                                                           int which_in, int which_out)
