@@ -505,13 +505,17 @@ __device__ __forceinline__ void spectra_stage1_regs(const float2 (&z)[AMAX], flo
     }
 }
 
-#ifndef CWSLG_SPEC_JPER
-#define CWSLG_SPEC_JPER 12
-#endif
 #ifndef CWSLG_SPEC_WAVES
 #define CWSLG_SPEC_WAVES 4
 #endif
-constexpr int SPEC_JPER = CWSLG_SPEC_JPER;   // symbol steps per workgroup (FT8: 372 = 31 x 12); -D overrides are for A/B builds only
+// Symbol steps per workgroup of symbol_spectra_v2_kernel (a kernel argument).  A workgroup's prologue -- twiddles, 24 LDS addresses, the first window's
+// memory latency -- is paid once per `jper` transforms: same-box at 4096 slots 4.31 ms with 12 steps (31 workgroups per channel), 4.20 with 31, 4.18 with 62;
+// few channels need the short form to fill the chip (four workgroups per CU).
+inline int spectra_jper(int nsteps, size_t channels)
+{
+    for (int jper : {62, 31}) if (channels * (size_t)((nsteps + jper - 1) / jper) >= 3072) return jper;
+    return 12;
+}
 // (Rounds 2-3 carried a matrix-core form of spec v2's stage 1 -- its fmaf chains as v_mfma_f32_32x32x2_f32 steps -- as a lab variant: measured
 // slower twice, 1.56 against 1.29 ms per 512 slots and 6.3 against 5.2 ms per 4096; it went with spec v2's stage 1.)
 #if defined(CWSLG_STAMP) && defined(CWSLG_STAMP_SPEC)
@@ -529,7 +533,7 @@ constexpr int SPEC_JPER = CWSLG_SPEC_JPER;   // symbol steps per workgroup (FT8:
 #define PSTAMP(slot) do { } while (0)
 #endif
 template <int NA, int NIN, int STEP, bool WINDOW>
-__global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kernel(const SyncWork *__restrict__ works, SyncTables tb, int nbins, int nsteps)
+__global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kernel(const SyncWork *__restrict__ works, SyncTables tb, int nbins, int nsteps, int jper)
 {
     constexpr int NZ = NA * 128;
     constexpr int NPACK = NIN / 2;
@@ -542,15 +546,15 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     __shared__ float2 s_y[NA][SY_PITCH];
     __shared__ float2 s_w128[64];
     const SyncWork *w = works + blockIdx.y;
-    const int j0 = blockIdx.x * SPEC_JPER;
-    const int jend = min(j0 + SPEC_JPER, nsteps);
+    const int j0 = blockIdx.x * jper;
+    const int jend = min(j0 + jper, nsteps);
     const int tid_ = threadIdx.x;
     const int b_ = tid_ & 127;
     const float fac = 1.0f / 300.0f;
     // Barriers are lds_barrier() (s_waitcnt lgkmcnt(0) + s_barrier): __syncthreads() would also wait for vmcnt(0), i.e. for
     // the prefetched window, at the first barrier behind its issue.
     // this lane's packed inputs z[a] = x[2m] + i x[2m+1], m = 128 a + b_: one aligned 4-byte load each.  The workgroup walks
-    // SPEC_JPER consecutive symbol steps and always has the NEXT step's eight loads in flight while it transforms the
+    // jper consecutive symbol steps and always has the NEXT step's eight loads in flight while it transforms the
     // current one: the first version's workgroups all sat through a full memory latency before any arithmetic
     // (6 resident workgroups per CU, lifetime = latency + arithmetic: VALU 65 % busy); now only the first step of a
     // workgroup does.
