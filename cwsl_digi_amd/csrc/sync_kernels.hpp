@@ -162,24 +162,14 @@ __device__ __forceinline__ void stage1_load_tw(const float2 *__restrict__ wn, in
     }
 }
 
-// W_NA^k = (cos, -sin)(2 pi k / NA), k <= NA / 2, as COMPILE-TIME constants (NA = 15: FT8, NA = 9: FT4): the values of the oracle's table --
-// float(cos), float(-sin) of the double angle, W^0 exact -- written out as hexadecimal floats; sync_ensure_shared recomputes the table at
-// start-up and refuses to run if a single bit differs.  Round 4: they used to arrive as kernel arguments, i.e. in SCALAR registers,
-// and on gfx950 a one-lane-wide FP32 operation with a scalar-register source issues at HALF rate (4.2 against 2.35 cycles per wave64
-// instruction and SIMD; literal and inline constants run at full rate: scripts/micro/pk_issue.hip, profiles/r4_pk_issue.txt) -- 160 of the
-// ~500 arithmetic instructions of a transform.  As literals they are folded into the instruction word.
+// W_9^k = (cos, -sin)(2 pi k / 9), k <= 4, as COMPILE-TIME constants (FT4's stage 1; FT8's prime-factor stage 1 has W_5 and sin 2 pi / 3 below): the
+// values of the oracle's table -- float(cos), float(-sin) of the double angle, W^0 exact -- written out as hexadecimal floats; sync_ensure_shared
+// recomputes them at start-up and refuses to run if a single bit differs.  Round 4: they used to arrive as kernel arguments, i.e. in SCALAR registers,
+// and on gfx950 a one-lane-wide FP32 operation with a scalar-register source issues at HALF rate (4.2 against 2.35 cycles per wave64 instruction and
+// SIMD; literal and inline constants run at full rate: scripts/micro/pk_issue.hip, profiles/r4_pk_issue_operands.txt).  As literals they are folded
+// into the instruction word.  (It did not shorten the launch: the scalar-source port is shared by the SIMD's waves and a third of a mixed stream stays under it.)
 template <int NA> __host__ __device__ constexpr float small_wr(int k);
 template <int NA> __host__ __device__ constexpr float small_wi(int k);
-template <> __host__ __device__ constexpr float small_wr<15>(int k)
-{
-    return k == 0 ? 1.0f : k == 1 ? 0x1.d3bc3ap-1f : k == 2 ? 0x1.56984ap-1f : k == 3 ? 0x1.3c6ef4p-2f : k == 4 ? -0x1.ac260ap-4f
-         : k == 5 ? -0x1.0p-1f : k == 6 ? -0x1.9e377ap-1f : -0x1.f4cfc4p-1f;
-}
-template <> __host__ __device__ constexpr float small_wi<15>(int k)
-{
-    return k == 0 ? 0.0f : k == 1 ? -0x1.a07f92p-2f : k == 2 ? -0x1.7c7d7ap-1f : k == 3 ? -0x1.e6f0e2p-1f : k == 4 ? -0x1.fd31fap-1f
-         : k == 5 ? -0x1.bb67aep-1f : k == 6 ? -0x1.2cf23p-1f : -0x1.a9cd9ap-3f;
-}
 template <> __host__ __device__ constexpr float small_wr<9>(int k)
 {
     return k == 0 ? 1.0f : k == 1 ? 0x1.8836fap-1f : k == 2 ? 0x1.63a1a8p-3f : k == 3 ? -0x1.0p-1f : -0x1.e11f64p-1f;
@@ -470,8 +460,7 @@ __device__ __forceinline__ void spectra_stage1_regs(const float2 (&z)[AMAX], flo
     if constexpr (NA == 15) {                            // spec v3: prime-factor 3 x 5 on the eight live inputs
         static_assert(AMAX == 8, "FT8: 960 packed inputs = 8 rows of 128");
         stage1_pfa15<HALF>(z, s_y, twp.v, b);
-        return;
-    }
+    } else {                                             // FT4 (NA = 9): conjugate pairs of fmaf chains
     constexpr int NPAIR = NA / 2, SPLIT = NPAIR / 2;
     constexpr int C0 = HALF ? SPLIT + 1 : 1, C1 = HALF ? NPAIR : SPLIT;
     const float2 *tw = twp.v;
@@ -502,6 +491,7 @@ __device__ __forceinline__ void spectra_stage1_regs(const float2 (&z)[AMAX], flo
         const float2 yn = make_float2(z[0].x + (P + Q), z[0].y + (S - R));
         s_y[c][b] = cmul_f(yc, tw[2 * (c - C0)]);
         s_y[NA - c][b] = cmul_f(yn, tw[2 * (c - C0) + 1]);
+    }
     }
 }
 
