@@ -12,7 +12,7 @@
 // two real sequences share one complex M-point transform, which is "spec B" (N = NA x NB; WSPR 45 x 1024, FST4W 125 x 256):
 //   fftb_stage1_kernel   dense NA-point DFTs down the columns as four ascending fmaf chains per output + twiddle W_N^(b c);
 //                        a 64-column tile of the input is staged in LDS once and shared by the four waves (outputs c = wave mod 4)
-//   fftb_stage2_kernel   one workgroup per row: NB-point radix-2 DIT in LDS
+//   fftb_stage2_kernel   NB / 16 threads per row, sixteen points per thread: NB-point radix-2 DIT, four levels per pass in registers
 // Output convention: Z[c + NA d] = y[c][d], kept as y (row-major [NA][NB]); consumers do the index arithmetic.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -25,7 +25,7 @@ constexpr int WSPR_IQ_LEN = 46336;          // 358*128 + 512: the spectra read p
 constexpr int F4W_NMAX = 1440000, F4W_NSPS = 8200, F4W_M = 32000, F4W_R = 45, F4W_MAXCAND = 100, F4W_NNW = 65600;
 
 struct FftbTables {                          // device pointers
-    const float2 *wa, *wn, *wb;              // NA | N | NB/2
+    const float2 *wa, *wn, *wb;              // NA | [NA][NB]: wn[c][b] = W_N^(b c) | NB/2
     const float2 *wfull;                     // [NA][NA]: wfull[c][a] = wa[(a c) mod NA], the stage-1 matrix row by row
 };
 
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(FFTB_S1_NT, 4) void fftb_stage1_kernel(const LongWo
         }
 #pragma unroll
         for (int j = 0; j < CB; ++j)
-            gst2(yout + (size_t)(c0 + j) * NB + b, lcmul(make_float2(PS[j].x - RQ[j].y, RQ[j].x + PS[j].y), tb.wn[b * (c0 + j)]));
+            gst2(yout + (size_t)(c0 + j) * NB + b, lcmul(make_float2(PS[j].x - RQ[j].y, RQ[j].x + PS[j].y), tb.wn[(size_t)(c0 + j) * NB + b]));
     }
 }
 
@@ -173,51 +173,112 @@ __global__ __launch_bounds__(64 * ((NA + 31) / 32)) void fftb_stage1_mfma_kernel
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         const int cr = c0 + (v & 3) + 8 * (v >> 2) + 4 * h;
-        if (cr < NA) gst2(yout + (size_t)cr * NB + b, lcmul(make_float2(P[v] - Q[v], R[v] + S[v]), tb.wn[b * cr]));
+        if (cr < NA) gst2(yout + (size_t)cr * NB + b, lcmul(make_float2(P[v] - Q[v], R[v] + S[v]), tb.wn[(size_t)cr * NB + b]));
     }
 }
 
-// spec B stage 2.  grid (NA, transforms, channels), 256 threads.  In place on y (row c).
-// Round 4: TWO radix-2 levels per pass -- a thread holds the four points e0 = base + k, e1 = e0 + h, e2 = e0 + 2h, e3 = e2 + h of levels
-// len = 2h and 2 len, does the two butterflies of the first level, (e0, e1) and (e2, e3) with W^(k NB/len), then the two of the second,
-// (e0, e2) with W^(k NB/(2 len)) and (e1, e3) with W^((k + h) NB/(2 len)), in registers: every butterfly is the restatement's (t = v w by lcmul,
-// u + t, u - t) on the same operands, so the row is bit-identical to ten (eight) single-level passes -- with half the LDS traffic and half
-// the barriers (round 3: one level per pass, 0.61-0.64 ms per 128 frames for either transform size).
+// spec B stage 2: the NB-point radix-2 DIT of every row, in place on y.  grid (ceil(NA / rows per workgroup), transforms, channels), 256 threads.
+// Round 4, second form: SIXTEEN points per thread, i.e. four radix-2 levels per pass in registers -- NB / 16 threads per row (one wave for NB = 1024,
+// a quarter wave for NB = 256), 4 / 16 rows per workgroup, and no workgroup barrier behind the twiddle table's: a row never leaves its wave.
+//   pass 1  levels 2..16 on positions 16 t .. 16 t + 15 of the bit-reversed order.  Position p holds input brev(p), so thread t's sixteen inputs are
+//           row[brev(t) + (NB / 16) m], m = 0..15 (register brev4(m)): read straight from memory (for each m the wave's reads permute one contiguous
+//           run) -- no bit-reversing scatter into LDS (which put all 64 lanes of a store on one bank pair).  Twiddles W^(k NB / len): wave-uniform reads.
+//   pass 2  levels 32..256 on positions 256 blk + r + 16 q, q = 0..15 (thread = (blk, r)); level 32 * 2^s pairs q with q + 2^s, twiddle index
+//           (r + 16 (q mod 2^s)) NB / len.  NB = 256 ends here: stored from registers.
+//   pass 3  (NB = 1024) levels 512, 1024 on positions g + 256 q, q = 0..3, g = t + 64 i: stored from registers.
+// The LDS image of a row is padded by one element per sixteen (position p at p + p / 16): every pass reads and writes with consecutive lanes on
+// consecutive elements or on a stride of 17.  Every butterfly is the restatement's (t = v w by lcmul, u + t, u - t) on the same operands:
+// bit-identical rows.  (First form of round 4: two levels per pass, four points per thread, one row per workgroup, five barrier-separated passes
+// behind a bit-reversing scatter: 0.55 ms per launch of either size against 0.25 ms for its bytes.)
+__device__ __forceinline__ void fftb_bf(float2 &u, float2 &v, float2 tw)
+{
+    const float2 tt = lcmul(v, tw);
+    const float2 u0 = u;
+    u = make_float2(u0.x + tt.x, u0.y + tt.y);
+    v = make_float2(u0.x - tt.x, u0.y - tt.y);
+}
 template <int NA, int NB>
 __global__ __launch_bounds__(256) void fftb_stage2_kernel(const LongWork *__restrict__ works, FftbTables tb, int which)
 {
-    constexpr int LOGB = (NB == 1024) ? 10 : (NB == 512 ? 9 : (NB == 256 ? 8 : 7));
-    static_assert((1 << LOGB) == NB && LOGB % 2 == 0, "NB = 4^n");
-    __shared__ float2 s_r[NB];
+    constexpr int LOGB = (NB == 1024) ? 10 : 8;
+    static_assert(NB == 1024 || NB == 256, "NB = 256 or 1024");
+    constexpr int TPR = NB / 16;                         // threads per row
+    constexpr int RPW = 256 / TPR;                       // rows per workgroup
+    constexpr int PITCH = NB + NB / 16;
+    __shared__ float2 s_r[RPW][PITCH];
     __shared__ float2 s_w[NB / 2];
     const LongWork *w = works + blockIdx.z;
-    CWSLG_GLOBAL v2f *row = reinterpret_cast<CWSLG_GLOBAL v2f *>(as_global_rw(which == 0 ? w->y : w->aux + NA * NB)) + ((size_t)blockIdx.y * NA + blockIdx.x) * NB;
+    const int tid = threadIdx.x, t = tid % TPR;
+    const int c = (int)blockIdx.x * RPW + tid / TPR;     // this thread's row
+    const bool live = c < NA;
+    CWSLG_GLOBAL v2f *row = reinterpret_cast<CWSLG_GLOBAL v2f *>(as_global_rw(which == 0 ? w->y : w->aux + NA * NB)) + ((size_t)blockIdx.y * NA + (live ? c : 0)) * NB;
     const CWSLG_GLOBAL v2f *wb = reinterpret_cast<const CWSLG_GLOBAL v2f *>(as_global(tb.wb));
-    const int tid = threadIdx.x;
-    for (int k = tid; k < NB / 2; k += 256) { const v2f t = wb[k]; s_w[k] = make_float2(t.x, t.y); }
-    for (int b = tid; b < NB; b += 256) { const v2f t = row[b]; s_r[__brev((unsigned)b) >> (32 - LOGB)] = make_float2(t.x, t.y); }
-    __syncthreads();
-    auto bf = [](float2 &u, float2 &v, float2 tw) {
-        const float2 tt = lcmul(v, tw);
-        const float2 u0 = u;
-        u = make_float2(u0.x + tt.x, u0.y + tt.y);
-        v = make_float2(u0.x - tt.x, u0.y - tt.y);
-    };
-    for (int len = 2; len <= NB / 2; len <<= 2) {            // levels len and 2 len
-        const int h = len >> 1, step1 = NB / len, step2 = step1 >> 1;
-        for (int q = tid; q < NB / 4; q += 256) {
-            const int k = q & (h - 1), base = (q - k) * 4;
-            float2 e0 = s_r[base + k], e1 = s_r[base + k + h], e2 = s_r[base + k + len], e3 = s_r[base + k + len + h];
-            const float2 w1 = s_w[k * step1];
-            bf(e0, e1, w1);
-            bf(e2, e3, w1);
-            bf(e0, e2, s_w[k * step2]);
-            bf(e1, e3, s_w[(k + h) * step2]);
-            s_r[base + k] = e0; s_r[base + k + h] = e1; s_r[base + k + len] = e2; s_r[base + k + len + h] = e3;
+    float2 *sr = s_r[tid / TPR];
+    auto pad = [](int p) { return p + (p >> 4); };
+    float2 e[16];
+    {   // pass 1: this thread's sixteen inputs, issued before the twiddle table's loads are waited for
+        const int bt = (int)(__brev((unsigned)t) >> (32 - (LOGB - 4)));
+        v2f x[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) x[m] = live ? row[bt + TPR * m] : v2f{0.f, 0.f};
+        for (int k = tid; k < NB / 2; k += 256) { const v2f q = wb[k]; s_w[k] = make_float2(q.x, q.y); }
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const int j = ((m & 1) << 3) | ((m & 2) << 1) | ((m & 4) >> 1) | ((m & 8) >> 3);
+            e[j] = make_float2(x[m].x, x[m].y);
         }
-        __syncthreads();
     }
-    for (int b = tid; b < NB; b += 256) row[b] = v2f{s_r[b].x, s_r[b].y};
+    __syncthreads();                                     // the twiddle table
+#pragma unroll
+    for (int len = 2; len <= 16; len <<= 1) {
+        const int h = len >> 1;
+#pragma unroll
+        for (int base = 0; base < 16; base += len)
+#pragma unroll
+            for (int k = 0; k < h; ++k) fftb_bf(e[base + k], e[base + k + h], s_w[k * (NB / len)]);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sr[pad(16 * t + j)] = e[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                     // a row lives in ONE wave: its LDS operations execute in program order
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {   // pass 2
+        const int blk = t >> 4, r = t & 15;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) e[q] = sr[pad(256 * blk + r + 16 * q)];
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const int len = 32 << s_;
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (!(q & (1 << s_))) fftb_bf(e[q], e[q | (1 << s_)], s_w[(r + 16 * (q & ((1 << s_) - 1))) * (NB / len)]);
+        }
+        if (NB == 256) {
+            if (live)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) row[r + 16 * q] = v2f{e[q].x, e[q].y};
+            return;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sr[pad(256 * blk + r + 16 * q)] = e[q];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // pass 3 (NB = 1024): levels 512 and 1024
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = t + 64 * i;
+        float2 f0 = sr[pad(g)], f1 = sr[pad(g + 256)], f2 = sr[pad(g + 512)], f3 = sr[pad(g + 768)];
+        const float2 w1 = s_w[g * (NB / 512)];
+        fftb_bf(f0, f1, w1);
+        fftb_bf(f2, f3, w1);
+        fftb_bf(f0, f2, s_w[g]);
+        fftb_bf(f1, f3, s_w[g + 256]);
+        if (live) {
+            row[g] = v2f{f0.x, f0.y}; row[g + 256] = v2f{f1.x, f1.y}; row[g + 512] = v2f{f2.x, f2.y}; row[g + 768] = v2f{f3.x, f3.y};
+        }
+    }
 }
 
 // Z[k] of transform t out of the row-major stage-2 output
