@@ -140,18 +140,38 @@ __global__ __launch_bounds__(64 * ((NA + 31) / 32)) void fftb_stage1_mfma_kernel
                                                                                int which_in, int which_out)
 {
     __shared__ float2 s_wa[NA];
+    __shared__ float2 s_zt[NA + 1][32];                    // the tile's inputs: every wave of the workgroup multiplies the SAME 32 columns
     const LongWork *w = works + blockIdx.z;
     const int t = blockIdx.y, b0 = blockIdx.x * 32;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const float2 *zin = (which_in == 0 ? w->z : w->aux) + (size_t)t * (NA * NB);
     float2 *yout = (which_out == 0 ? w->y : w->aux + NA * NB) + (size_t)t * (NA * NB);
+    // Round 4: the tile goes through LDS once (16-byte loads, all issued before the first LDS write).  Each wave used to read its operand of every
+    // step from memory inside the matrix-instruction loop -- the same 32 KB by every wave of the workgroup, one load latency per two steps:
+    // 1.07 ms per 128 frames against 0.70 ms of matrix-pipe time.
+    {
+        const CWSLG_GLOBAL v4f *zg4 = reinterpret_cast<const CWSLG_GLOBAL v4f *>(as_global(reinterpret_cast<const v2f *>(zin)) + b0);
+        constexpr int NT = 64 * ((NA + 31) / 32);
+        constexpr int NQ = (NA + 1) * 16, PER = (NQ + NT - 1) / NT;      // 16-byte pieces of the tile (two columns each); row NA is the zero row of the odd last step
+        v4f tmp[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = tid + NT * q, a = e >> 4, p = e & 15;
+            tmp[q] = v4f{0.f, 0.f, 0.f, 0.f};
+            if (a < NA) tmp[q] = zg4[(size_t)(NB / 2) * a + p];
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int e = tid + NT * q, a = e >> 4, p = e & 15;
+            if (a <= NA) *reinterpret_cast<v4f *>(&s_zt[a][2 * p]) = tmp[q];
+        }
+    }
     for (int k = tid; k < NA; k += blockDim.x) s_wa[k] = tb.wa[k];
     __syncthreads();
     const int i = lane & 31, h = lane >> 5;
     const int c0 = 32 * wv;
     const int c = (c0 + i < NA) ? c0 + i : 0;              // rows past NA - 1 compute row 0 and are not stored
     const int b = b0 + i;
-    const CWSLG_GLOBAL v2f *zg = as_global(reinterpret_cast<const v2f *>(zin)) + b;
     lf32x16 P, Q, R, S;
 #pragma unroll
     for (int v = 0; v < 16; ++v) { P[v] = 0.f; Q[v] = 0.f; R[v] = 0.f; S[v] = 0.f; }
@@ -159,8 +179,7 @@ __global__ __launch_bounds__(64 * ((NA + 31) / 32)) void fftb_stage1_mfma_kernel
     const int step = (2 * c) % NA;
 #pragma unroll 2
     for (int a = 0; a < NA; a += 2) {
-        v2f z = {0.f, 0.f};
-        if (a + h < NA) z = zg[(size_t)NB * (a + h)];       // lane (i, h): B[k = h][j = i] = z[a + h][b0 + i]
+        const float2 z = s_zt[a + h][i];                    // lane (i, h): B[k = h][j = i] = z[a + h][b0 + i]  (row NA holds zeros)
         const float2 tw = s_wa[idx];                        //              A[i][k = h]     = W[c0 + i][a + h]
         idx += step;
         if (idx >= NA) idx -= NA;
