@@ -29,7 +29,7 @@ constexpr int F4C_CPT = 4;                      // DFT-567 outputs per lane
 constexpr int F4C_PLANE = 1012;                 // 4032 / 4 + pad
 
 struct Ft4Tables {                              // device pointers (built once per context, sync_host.inc)
-    const float2 *w567, *wn2, *w2n, *w64, *w63, *w4032, *csync, *ctwk;
+    const float2 *w567, *wn2, *w2n, *w64, *w63, *w4032, *csync, *ctwk;   // wn2, w4032: [c][b] = W_N^(b c), b < 64 (the other tables: W^k)
     const float *win;
 };
 
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void ft4_dft567_kernel(const Ft4Work *__restri
 #pragma unroll
     for (int i = 0; i < F4C_CPT; ++i) {
         const int c = cbase + i;
-        if (c < F4C_NA) w->y[c * 64 + rev6(b)] = cmul_f(make_float2(yr[i], yi[i]), tb.wn2[b * c]);
+        if (c < F4C_NA) w->y[c * 64 + rev6(b)] = cmul_f(make_float2(yr[i], yi[i]), tb.wn2[c * 64 + b]);
     }
 }
 #endif  // CWSLG_LAB
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void ft4_dft567_mfma_kernel(const Ft4Work *__r
 #pragma unroll
     for (int v = 0; v < 16; ++v) {
         const int cr = c0 + (v & 3) + 8 * (v >> 2) + 4 * h;
-        if (cr < F4C_NA) gst2(w->y + cr * 64 + rev6(b), cmul_f(make_float2(yr[v], yi[v]), tb.wn2[b * cr]));
+        if (cr < F4C_NA) gst2(w->y + cr * 64 + rev6(b), cmul_f(make_float2(yr[v], yi[v]), tb.wn2[cr * 64 + b]));
     }
 }
 
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void ft4_refine_kernel(const Ft4Work *__restri
                 yr = __builtin_fmaf(z.x, t.x, yr); yr = __builtin_fmaf(z.y, t.y, yr);
                 yi = __builtin_fmaf(z.y, t.x, yi); yi = __builtin_fmaf(-z.x, t.y, yi);
             }
-            s_y[c][rev6(b)] = cmulc_f(make_float2(yr, yi), tb.w4032[b * c]);
+            s_y[c][rev6(b)] = cmulc_f(make_float2(yr, yi), tb.w4032[c * 64 + b]);
         }
     }
     wave_sync_lds();                                 // rows c = wv, wv+4, ... were written by this wave only
