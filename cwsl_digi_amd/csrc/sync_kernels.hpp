@@ -509,11 +509,11 @@ inline int spectra_jper(int nsteps, size_t channels)
 // (Rounds 2-3 carried a matrix-core form of spec v2's stage 1 -- its fmaf chains as v_mfma_f32_32x32x2_f32 steps -- as a lab variant: measured
 // slower twice, 1.56 against 1.29 ms per 512 slots and 6.3 against 5.2 ms per 4096; it went with spec v2's stage 1.)
 #if defined(CWSLG_STAMP) && defined(CWSLG_STAMP_SPEC)
-// diagnostic build only (scripts/gpu_stamps_spectra.py): s_memtime of every wave at the phase seams of the workgroup's THIRD transform
+// diagnostic build only (scripts/gpu_stamps_spectra.py): s_memtime of every wave at the phase seams of the workgroup's MIDDLE transform
 #define PSTAMP(slot)                                                                                                               \
     do {                                                                                                                           \
         const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                                                  \
-        if (j == j0 + 2 && (tid_ & 63) == 0 && wg_ < 16384) {                                                                     \
+        if (j == j0 + (jper >> 1) && (tid_ & 63) == 0 && wg_ < 16384) {                                                                     \
             unsigned long long t_;                                                                                                 \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                             \
             g_stamps[32 * wg_ + 8 * (tid_ >> 6) + (slot)] = t_;                                                                    \

@@ -1,5 +1,5 @@
 """Diagnostic: where a transform of symbol_spectra_v2_kernel spends its time (s_memtime stamps of a -DCWSLG_STAMP -DCWSLG_STAMP_SPEC lab build;
-every wave of every workgroup, its third transform)."""
+every wave of every workgroup, its middle transform)."""
 import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
