@@ -61,6 +61,21 @@ def test_sync_parameter_sweep(ctx, oracle, maxcand, syncmin, lo, hi):
     assert len(got) <= maxcand
 
 
+@pytest.mark.parametrize("hi", [2900, 2960, 2962, 3037, 3062, 3100, 5900])
+def test_spectra_rows_at_every_form_of_the_last_stage(ctx, oracle, hi):
+    """The spectra kernel's last stage has three forms by the stored row length: rows below 960 bins (plain items), 960..992 (the bins above 960
+    packed into row 0's idle lanes, the self-paired bins on lane 0 -- FT8's default search), and wider rows (four bins per item): every stored bin of
+    every symbol step is the restatement's, bit for bit, at row lengths on both sides of each switch."""
+    specs = [(600.0 + 310 * k, 0.2 + 0.13 * k, 2500.0 - 200 * k) for k in range(8)]
+    ch, fr = _run(ctx, oracle, 20000, specs, 17, 200, 1.5, 200, hi)
+    s_gpu = ctx.sync_debug(ch, "spectra")
+    s_ref = oracle.ft8_spectra(fr, s_gpu.shape[1])
+    assert s_gpu.shape[0] == 372 and np.array_equal(s_gpu.view(np.uint32), s_ref.view(np.uint32)), s_gpu.shape
+    ref = oracle.ft8_sync(fr, 200, hi, 1.5, 200)
+    got = ctx.fetch_candidates(ch, 200)
+    assert [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in got] == [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in ref]
+
+
 def test_sync_short_frame_zero_tail(ctx, oracle):
     """A slot that ended early: the zero tail gives all-zero symbol windows (0/0 defined as 0 in both)."""
     specs = [(1200.0, 0.5, 3000.0)]
