@@ -390,13 +390,14 @@ def main():
         per_slot, per_transform = sync_flops_per_slot(nbins, nsearch)
         ms = st_["sync_ms"] / st_["sync_launches"]
         tfl = per_slot * S / (ms * 1e-3) / 1e12
-        fabric, src = None, None
+        fabric, src, spec_insts = None, None, None
         tp = os.path.join(ROOT, "profiles", "traffic_per_launch.json")
         if os.path.isfile(tp):
             try:
                 for tj in json.load(open(tp)).get("sync_runs", []):
                     if tj.get("slots") == S:
                         fabric, src = tj.get("fabric_bytes_per_boundary"), "replayed: " + tj.get("source", "")
+                        spec_insts = (tj.get("valu_insts_per_launch") or {}).get("symbol_spectra_v2_kernel")
             except Exception:
                 pass
         # each kernel against the resource it leans on: the spectra kernel is FP32 work (VALU-bound); the Costas search re-reads its band image
@@ -409,7 +410,13 @@ def main():
         per_kernel = None
         if sp_ms > 0 and se_ms > 0:
             per_kernel = {"spectra": {"avg_ms": sp_ms, "bound": "valu", "achieved_tflops": 372 * per_transform * S / (sp_ms * 1e-3) / 1e12,
-                                      "frac": 372 * per_transform * S / (sp_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS},
+                                      "frac": 372 * per_transform * S / (sp_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
+                                      # the bound that moves with the arithmetic spec: the kernel's VALU instructions (SQ_INSTS_VALU of the committed PMC
+                                      # summary, replayed) at the 2.35 cycles a SIMD needs per one-lane FP32 instruction with two or more resident waves
+                                      # (profiles/r4_pk_issue_operands.txt), at the chip's 2.4 GHz peak clock -- the kernel runs near 2.0 GHz, so this fraction is a floor
+                                      "valu_insts_per_launch": spec_insts,
+                                      "issue_bound_ms_at_2p4_ghz": None if not spec_insts else spec_insts / (n_cu * 4) * 2.35 / 2.4e9 * 1e3,
+                                      "issue_frac_floor": None if not spec_insts else spec_insts / (n_cu * 4) * 2.35 / 2.4e9 * 1e3 / sp_ms},
                           "search": {"avg_ms": se_ms, "bound": "lds", "lds_read_bytes": lds_bytes, "achieved_tbs": lds_bytes / (se_ms * 1e-3) / 1e12,
                                      "peak_tbs": lds_peak_tbs, "frac": lds_bytes / (se_ms * 1e-3) / 1e12 / lds_peak_tbs}}
         return {"bound": "valu", "kernels": kernels, "nbins_stored": nbins, "bins_searched": nsearch, "per_kernel": per_kernel,
