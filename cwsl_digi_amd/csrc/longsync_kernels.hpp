@@ -140,7 +140,7 @@ __global__ __launch_bounds__(64 * ((NA + 31) / 32)) void fftb_stage1_mfma_kernel
                                                                                int which_in, int which_out)
 {
     __shared__ float2 s_wa[NA];
-    __shared__ float2 s_zt[NA + 1][32];                    // the tile's inputs: every wave of the workgroup multiplies the SAME 32 columns
+    __shared__ __attribute__((aligned(16))) float2 s_zt[NA + 1][32];                    // the tile's inputs: every wave of the workgroup multiplies the SAME 32 columns
     const LongWork *w = works + blockIdx.z;
     const int t = blockIdx.y, b0 = blockIdx.x * 32;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
