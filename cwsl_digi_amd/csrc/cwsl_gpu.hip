@@ -14,6 +14,7 @@
 #include <atomic>
 #include <cctype>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -205,6 +206,7 @@ struct WorkBuf {
 struct TimedSpan {
     hipEvent_t a, b;
     int kind;                          // 0 demod, 1 finalize, 2 sync stage (whole), 3 / 4 its FT8 spectra / search + selection kernels
+    unsigned gen;                      // cwslg_reset_stats generation it was started in: a span of an older generation is not accounted
 };
 
 } // namespace cwslg
@@ -247,6 +249,13 @@ struct cwslg_ctx {
     hipEvent_t fetch_ev = nullptr;
     bool fetch_ev_valid = false;
     unsigned fetch_rr = 0;
+    // Frames are handed out whole (Instance.cpp:238-245 copies the frame into the ItemToDecode it pushes, DecoderPool.hpp:174-210): a fetch
+    // registers here under `mu` before it releases it; the next boundary -- the only writer of d_i16 / d_factor -- waits, under `mu`, until
+    // every registered copy has finished before it queues its finalise.  A fetch therefore returns the frame of the start_epoch it reports,
+    // never the next slot's samples under it, and the shared fetch_ev is never re-recorded under a waiter.
+    std::mutex fetch_mu;
+    std::condition_variable fetch_cv;
+    int fetch_inflight = 0;            // guarded by fetch_mu (incremented with mu held, decremented without)
     std::shared_mutex life_mu;         // shared: a fetch's copy is in flight; exclusive: a close frees device buffers (order: mu, then life_mu)
     BatchStage batch[kBatchStages];
     std::atomic<unsigned> batch_next{0};
@@ -255,6 +264,7 @@ struct cwslg_ctx {
     // one workgroup's life (demod_exact3_kernel's `clk`), read back by drain_spans
     unsigned long long *clk_h = nullptr, *clk_dev = nullptr;
     unsigned clk_head = 0, clk_tail = 0;
+    unsigned stat_gen = 0;             // bumped by cwslg_reset_stats: work timed before a reset is not folded into the figures read after it
     double clk_sum_mhz = 0.0;
     int occ_cache[3][5] = {};          // launch_demod: resident demod_exact3 workgroups per CU by (D, tile form); per context = per device
     // launch descriptors
@@ -393,7 +403,7 @@ void span_begin(cwslg_ctx *c, int kind, hipEvent_t *a, hipEvent_t *b)
     *a = p.first;
     *b = p.second;
     hipEventRecord(*a, c->stream);
-    c->spans.push_back({*a, *b, kind});
+    c->spans.push_back({*a, *b, kind, c->stat_gen});
 }
 void span_end(cwslg_ctx *c, hipEvent_t b)
 {
@@ -409,7 +419,7 @@ void span_begin_on(cwslg_ctx *c, int kind, hipStream_t st, hipEvent_t *a, hipEve
     else { hipEventCreate(&p.first); hipEventCreate(&p.second); }
     *a = p.first; *b = p.second;
     hipEventRecord(*a, st);
-    c->spans.push_back({*a, *b, kind});
+    c->spans.push_back({*a, *b, kind, c->stat_gen});
 }
 // every stream of the context that can hold device work (host-visible results must wait for all of them)
 hipError_t sync_streams(cwslg_ctx *c)
@@ -431,7 +441,7 @@ void drain_spans(cwslg_ctx *c)
     for (const TimedSpan &s : c->spans) {
         if (hipEventQuery(s.b) != hipSuccess) { later.push_back(s); continue; }
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+        if (s.gen == c->stat_gen && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
             if (s.kind == 0) c->stats.demod_ms += ms;
             else if (s.kind == 1) c->stats.finalize_ms += ms;
             else if (s.kind == 3) c->stats.sync_spectra_ms += ms;
@@ -441,9 +451,12 @@ void drain_spans(cwslg_ctx *c)
         c->ev_pool.push_back({s.a, s.b});
     }
     c->spans.swap(later);
-    if (!c->spans.empty()) return;         // (the clock slots below belong to launches that may still run)
+    // clock slots, oldest first: a slot whose end stamps have landed belongs to a finished launch whatever else is queued (a real-time host
+    // never reaches an empty span list); one without them is either still running -- stop there -- or, with nothing queued any more, a
+    // launch whose stamping workgroup had no work: skip it
     for (; c->clk_tail != c->clk_head; ++c->clk_tail) {
-        const unsigned long long *q = c->clk_h + 4 * (c->clk_tail % kClkSlots);
+        const volatile unsigned long long *q = c->clk_h + 4 * (c->clk_tail % kClkSlots);
+        if (!(q[2] && q[3]) && !c->spans.empty()) break;
         if (q[0] && q[1] && q[2] > q[0] && q[3] > q[1] + 300) {        // >= 3 us of the 100 MHz counter (a tile workgroup of the fast kernel lives ~6 us)
             c->clk_sum_mhz += 100.0 * (double)(q[2] - q[0]) / (double)(q[3] - q[1]);
             c->stats.demod_clock_launches++;
@@ -954,6 +967,18 @@ int reserve_ring(cwslg_ctx *c, Receiver &rx, uint32_t n)
     return CWSLG_OK;
 }
 
+// One in-flight cwslg_fetch_frame copy (see cwslg_ctx::fetch_inflight).
+struct FetchTicket {
+    cwslg_ctx *c = nullptr;
+    void take(cwslg_ctx *ctx) { std::lock_guard<std::mutex> g(ctx->fetch_mu); ++ctx->fetch_inflight; c = ctx; }
+    ~FetchTicket()
+    {
+        if (!c) return;
+        { std::lock_guard<std::mutex> g(c->fetch_mu); --c->fetch_inflight; }
+        c->fetch_cv.notify_all();
+    }
+};
+
 int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s, uint64_t *n_emitted = nullptr)
 {
     if (n_emitted) *n_emitted = 0;
@@ -1003,6 +1028,11 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s,
     if (c->cand_pending && (c->sync_variant & 32)) {     // the previous boundary's sync chain (side stream) reads the int16 frames
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->cand_done, 0));
         c->cand_pending = false;
+    }
+    {   // the finalise below rewrites d_i16 / d_factor: let the copies of the previous generation finish first (each is one frame's D2H copy;
+        // new fetches wait for `mu`, which this thread holds)
+        std::unique_lock<std::mutex> lk(c->fetch_mu);
+        c->fetch_cv.wait(lk, [&] { return c->fetch_inflight == 0; });
     }
     WorkBuf *w = acquire_workbuf(c, fin.size() * sizeof(FinWork));
     if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
@@ -1379,6 +1409,9 @@ static int push_iq_piece(cwslg_ctx *c, int rx_id, const float *iq, uint32_t n)
         if (rx_id >= (int)c->rxs.size() || !c->rxs[rx_id].open || c->rxs[rx_id].d_ring != d_ring)
             return fail(c, CWSLG_ERR_ARG, "receiver closed during a push");
         Receiver &rx = c->rxs[rx_id];
+        // the write position was read in step 1: another push on this receiver (a cwslg_push_iq_many batch, or a second thread -- the contract
+        // is one pusher per receiver, Receiver.hpp:167) has moved it since, so the staged block would land on top of that push's samples
+        if (rx.total != total0) return fail(c, CWSLG_ERR_ARG, "receiver %d was pushed from two threads at once; nothing accounted", rx_id);
         // ring history that a queued demod launch still reads must not be overwritten under it
         const int cs = rx_id % kCopyStreams;
         hipStream_t cstr = c->copy_on_main ? c->stream : c->copy_stream[cs];
@@ -1996,6 +2029,7 @@ int cwslg_fetch_frame(cwslg_ctx *c, int ch_id, int16_t *dst, size_t cap, uint64_
     const float *fac_src = nullptr;
     size_t flen = 0;
     std::shared_lock<std::shared_mutex> life;
+    FetchTicket ticket;                                              // released (after `life`) when the copy is done or the call fails
     {
         std::lock_guard<std::mutex> g(c->mu);
         if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
@@ -2014,6 +2048,7 @@ int cwslg_fetch_frame(cwslg_ctx *c, int ch_id, int16_t *dst, size_t cap, uint64_
         }
         fs = c->fetch_stream[c->fetch_rr++ % kFetchStreams];
         src = ch.d_i16; fac_src = ch.d_factor; flen = ch.frame_len;
+        ticket.take(c);
         life = std::shared_lock<std::shared_mutex>(c->life_mu);      // the buffers stay allocated until the copy below is done
     }
     // no context lock from here on: pushes, launches and other fetches proceed
@@ -2191,6 +2226,8 @@ int cwslg_reset_stats(cwslg_ctx *c)
     c->stats = cwslg_stats{};
     c->stats.rccl_world = (uint64_t)c->rccl_world;
     c->clk_sum_mhz = 0.0;
+    c->clk_tail = c->clk_head;         // launches timed before the reset: neither their clock stamps ...
+    c->stat_gen++;                     // ... nor their event spans count afterwards
     c->push_calls_a.store(0); c->push_host_ns_a.store(0);
     return CWSLG_OK;
 }

@@ -98,7 +98,12 @@ int cwslg_receiver_open(cwslg_ctx *ctx, uint32_t fs, uint32_t iq_len, int32_t lo
 int cwslg_receiver_close(cwslg_ctx *ctx, int rx_id);
 /* Replaces the memcpy into the ring slot + inc_write_index (Receiver.hpp:247-249) AND the N per-Instance
  * pop_no_wait()/Iterate() loops (Instance.cpp:265-276): called ONCE per block per receiver.  The host block
- * is only read during the call.  n_complex must be a multiple of 2*fs/6000 (SSBD::GetInSize). */
+ * is only read during the call.  n_complex must be a multiple of 2*fs/6000 (SSBD::GetInSize).
+ * One call is one H2D copy and two context-mutex acquisitions: right for the reference's topology (a few receivers, many channels each).
+ * A host that feeds THOUSANDS of private streams in real time must use cwslg_push_iq_many below (measured, profiles/r4_realtime.json: 4096
+ * streams through this call fall behind -- 13.1 s of wall time for 5.2 s of signal; through the batched call 0 drops at 6.3 GB/s on a
+ * quarter of a host core).  A receiver has one pusher at a time (Receiver.hpp:167); a second concurrent push of the same receiver,
+ * by either call, is refused with CWSLG_ERR_ARG and nothing is accounted. */
 int cwslg_push_iq(cwslg_ctx *ctx, int rx_id, const float *iq_interleaved, uint32_t n_complex);
 /* One block of n_complex samples for EACH of n_rx receivers in one call -- the batched form of the per-block memcpy + inc_write_index of
  * Receiver::readIQ (Receiver.hpp:242-249) for a host that serves thousands of streams (the north star's 4096 private 192 kHz streams are
@@ -219,7 +224,12 @@ int cwslg_rccl_init(cwslg_ctx *ctx, const void *id, int rank, int world);
 /* ---- results: replaces decoderPool->push(ItemToDecode(audio_i16, ...)) (Instance.cpp:244-245) ----
  * Copies the last finalised frame of the channel: frame_len = 12000*(period+5) int16 samples with the
  * reference's zero tail; *n_valid = samples actually demodulated in the slot; *start_epoch = the frame's
- * startEpochTime.  Returns CWSLG_ERR_NO_FRAME until a frame has been finalised. */
+ * startEpochTime.  Returns CWSLG_ERR_NO_FRAME until a frame has been finalised.
+ * Lifetime: the frame stays fetchable until the channel's NEXT emitting boundary replaces it.  The copy is atomic against that boundary
+ * (the reference copies the frame into the ItemToDecode it pushes, Instance.cpp:238-245, DecoderPool.hpp:174-210): a fetch that started
+ * before the boundary returns the old frame whole with the old start_epoch -- the boundary waits for it -- and one that starts after it
+ * returns the new frame with the new start_epoch; samples of one slot are never delivered under the epoch of another.  A consumer more
+ * than one slot late therefore sees only the newest frame (the reference's pool would drop the stale item by age, DecoderPool.hpp:358-374). */
 int cwslg_fetch_frame(cwslg_ctx *ctx, int ch_id, int16_t *dst, size_t cap,
                       uint64_t *start_epoch, size_t *n_valid, float *factor);
 /* The last finalised frame as the reference's .wav (WaveFile.hpp:19-35,87-135: 46-byte RIFF/WAVE/fmt(18-byte

@@ -159,3 +159,74 @@ def test_longest_modes_allocate_and_frame(ctx, oracle, mode):
     assert not fr["i16"][nv:].any()                # the reference's zero tail
     d = np.abs(fr["i16"][:nv].astype(np.int32) - r["i16"][:nv].astype(np.int32))
     assert d.max() <= 1
+
+
+def test_fetch_is_atomic_against_the_next_boundary(ctx, oracle):
+    """A frame is handed out whole: the reference copies it into the ItemToDecode it pushes (Instance.cpp:238-245, DecoderPool.hpp:174-210),
+    so a consumer that is late never sees samples of slot N + 1 under the start epoch of slot N.  Here a clock thread pushes a short slot
+    of distinct content and fires the boundary, back to back, on 64 channels, while three consumer threads fetch in a loop; every frame
+    that comes back must be -- bit for bit (the default mode is the bit-identical one) -- the oracle's frame of the start_epoch it was
+    returned with.  (Round 4's library queued the D2H copy with the context mutex released and nothing kept the next boundary's
+    finalize_kernel from rewriting the buffer under it.)"""
+    n_ch, n_epochs, n_blk = 64, 24, 6
+    n_live = n_blk * BLK // 16 + 64                        # samples past this index are the frame's zero tail
+    rx = ctx.receiver_open(FS, BLK, 0)
+    freqs = [-88000 + 2750 * k for k in range(n_ch)]
+    chans = [ctx.channel_open(rx, f, "FT8") for f in freqs]
+    segs = {e: oracle.synth_iq(5000 + e, n_blk * BLK, FS, tones_hz=[freqs[(7 * e) % n_ch] + 700.0 + 13.0 * e, freqs[(3 * e + 1) % n_ch] + 1500.0], amp=1.5e4)
+            for e in range(1, n_epochs + 1)}
+    want = {}                                              # (channel index, start epoch) -> the live part of the int16 frame
+    for k, f in enumerate(freqs):
+        oc = oracle.Channel("FT8", FS, BLK, f)
+        assert oc.boundary(1) is None                      # the first, partial slot is discarded (Instance.cpp:224-227)
+        for e in range(1, n_epochs + 1):
+            oc.push_many(segs[e])
+            r = oc.boundary(e + 1)
+            assert r["t_start"] == e
+            assert not r["i16"][n_live:].any()
+            want[(k, e)] = r["i16"][:n_live].astype(np.int32)
+        oc.close()
+    for k in range(n_ch):                                  # the frames really differ from epoch to epoch, by far more than the fast mode's +-1 LSB
+        for e in range(1, n_epochs):
+            assert np.abs(want[(k, e)] - want[(k, e + 1)]).max() > 100
+    lsb = 0 if ctx.mode == "exact" else 1                  # exact (default) mode: the reference's bits; fast mode: rounding ties may differ
+    errors, seen = [], set()
+    stop = threading.Event()
+
+    def clock():
+        try:
+            ctx.slot_boundary("FT8", 1)
+            for e in range(1, n_epochs + 1):
+                ctx.push_iq(rx, segs[e])
+                ctx.slot_boundary("FT8", e + 1)
+        except Exception as ex:       # pragma: no cover
+            errors.append(ex)
+        finally:
+            stop.set()
+
+    def consumer(first):
+        try:
+            k = first
+            while True:
+                done = stop.is_set()                       # one more round after the clock has finished
+                for _ in range(n_ch):
+                    fr = ctx.fetch_frame(chans[k])
+                    if fr is not None:
+                        e = int(fr["t_start"])
+                        if np.abs(fr["i16"][:n_live].astype(np.int32) - want[(k, e)]).max() > lsb or fr["i16"][n_live:].any():
+                            errors.append(AssertionError(f"channel {k}: frame returned with start epoch {e} is not that slot's frame"))
+                            return
+                        seen.add((k, e))
+                    k = (k + 1) % n_ch
+                if done:
+                    return
+        except Exception as ex:       # pragma: no cover
+            errors.append(ex)
+
+    th = [threading.Thread(target=clock)] + [threading.Thread(target=consumer, args=(17 * j,)) for j in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+    assert {e for _, e in seen} >= {n_epochs} and len({e for _, e in seen}) >= 3     # the consumers overlapped several generations
