@@ -436,7 +436,30 @@ def main():
                 "finalize_avg_ms": st_["finalize_ms"] / max(1, st_["finalize_launches"]),
                 "sync_avg_ms": st_["sync_ms"] / max(1, st_["sync_launches"]),
                 "whole_path_frac": BYTES_PER_SAMPLE_PATH * spl * args.steps / dt_ / 1e9 / HBM_PEAK_GBS}
-        if exact:
+        if exact and "exact5" in kname:
+            # demod_exact5_kernel (round 5): per tile (one 16-sample block of 32 streams = the work of 32 outputs) 16 K = 1 matrix instructions -- the
+            # 32 768 un-fused products fl(y * h) -- and 603 one-lane FP32 instructions (15 x 32 ordered additions, mix 48, sum * phase and workspace 64 + 3,
+            # phasor 7, ...).  The f32 MFMA occupies the SIMD's FP32 lanes: its 64 cycles and the VALU's time ADD (scripts/micro/mfma_k1.hip,
+            # profiles/r5_mfma_k1.txt: gapN / both_* rows), so the bound is a one-pipe sum, priced at the clock measured inside the timed launches.
+            roof["demod_head"] = {"kernel": "demod_exact4_kernel<512,512>", "launches": st_.get("demod_head_launches", 0),
+                                  "avg_ms": st_.get("demod_head_ms", 0.0) / max(1, st_.get("demod_head_launches", 0)),
+                                  "what": "the first 32 outputs after a demodulator's creation (no 32-block history yet); not in avg_launch_ms"}
+            clk_mhz = float(st_.get("demod_clock_mhz", 0.0))
+            tiles = spl / 16.0 / 32.0 / (n_cu * 4.0)                                   # per SIMD and launch (the streams' 32-block warm-up not counted: it is overhead)
+            mfma_cyc, valu_insts = 16 * 64, 603
+            vp = {"bound": "fp32 lanes: K = 1 MFMA products + un-fused one-lane sums (one pipe: the times add, profiles/r5_mfma_k1.txt)",
+                  "mfma_per_tile": 16, "cycles_per_mfma": 64, "valu_insts_per_tile": valu_insts, "cycles_per_valu_inst": 2,
+                  "clock_mhz": clk_mhz or None, "clock_source": f"in-kernel s_memtime / s_memrealtime over {int(st_.get('demod_clock_launches', 0))} timed launches",
+                  "bound_ms": None, "frac": None}
+            if clk_mhz > 0 and avg_ms > 0:
+                vp["bound_ms"] = tiles * (mfma_cyc + 2 * valu_insts) / (clk_mhz * 1e3)
+                vp["frac"] = vp["bound_ms"] / avg_ms
+                # what two waves per SIMD retire of exactly this instruction mix with every operand in registers (both_sc, profiles/r5_mfma_k1.txt)
+                vp["measured_issue_floor"] = {"cycles_per_tile": 2326, "source": "profiles/r5_mfma_k1.txt (both_sc, two waves per SIMD)", "waves_per_simd": 2,
+                                              "bound_ms": tiles * 2326 / (clk_mhz * 1e3)}
+                vp["measured_issue_floor"]["frac"] = vp["measured_issue_floor"]["bound_ms"] / avg_ms
+            roof["valu_pipe"] = vp
+        elif exact:
             # What bounds the exact kernel is not HBM but its un-fused arithmetic on the FP32 pipe: per pair of adjacent outputs
             # 33 steps x (16 taps x (multiply, add) x (Re, Im) + 4 for sum * phase) packed operations, each occupying its SIMD's vector pipe for 4
             # cycles (MI355X_MICROARCH.md: one wave's VALU instruction issues every 4 cycles; SQ_ACTIVE_INST_VALU = 1 quad-cycle per instruction in

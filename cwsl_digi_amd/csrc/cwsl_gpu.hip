@@ -72,6 +72,7 @@ constexpr int kWorkBufs = 8;
 constexpr unsigned kOrderEvent = hipEventDisableTiming | hipEventDisableSystemFence;
 constexpr int kCopyStreams = 4;
 constexpr int kFetchStreams = 4;
+constexpr unsigned kExact5SegCap = 1408;   // outputs per stream of demod_exact5_kernel at most (launch_exact5)
 constexpr unsigned kClkSlots = 1024;      // timed exact-mode demod launches between two drains of the spans
 
 // Host-push staging of one receiver.  The reference has one thread per Receiver (Receiver.hpp:167); each of them gets its own
@@ -205,7 +206,7 @@ struct WorkBuf {
 
 struct TimedSpan {
     hipEvent_t a, b;
-    int kind;                          // 0 demod, 1 finalize, 2 sync stage (whole), 3 / 4 its FT8 spectra / search + selection kernels
+    int kind;                          // 0 demod, 1 finalize, 2 sync stage (whole), 3 / 4 its FT8 spectra / search + selection kernels, 5 demod head launch
     unsigned gen;                      // cwslg_reset_stats generation it was started in: a span of an older generation is not accounted
 };
 
@@ -264,6 +265,8 @@ struct cwslg_ctx {
     // one workgroup's life (demod_exact3_kernel's `clk`), read back by drain_spans
     unsigned long long *clk_h = nullptr, *clk_dev = nullptr;
     unsigned clk_head = 0, clk_tail = 0;
+    unsigned exact5_seg_cap = kExact5SegCap;
+    bool use_exact5 = true;            // 192 kHz exact mode: demod_exact5_kernel (lab build: CWSLG_DEMOD_VARIANT=27 keeps demod_exact4_kernel for A/B)
     unsigned stat_gen = 0;             // bumped by cwslg_reset_stats: work timed before a reset is not folded into the figures read after it
     double clk_sum_mhz = 0.0;
     int occ_cache[3][5] = {};          // launch_demod: resident demod_exact3 workgroups per CU by (D, tile form); per context = per device
@@ -446,6 +449,7 @@ void drain_spans(cwslg_ctx *c)
             else if (s.kind == 1) c->stats.finalize_ms += ms;
             else if (s.kind == 3) c->stats.sync_spectra_ms += ms;
             else if (s.kind == 4) c->stats.sync_search_ms += ms;
+            else if (s.kind == 5) c->stats.demod_head_ms += ms;
             else c->stats.sync_ms += ms;
         }
         c->ev_pool.push_back({s.a, s.b});
@@ -573,10 +577,70 @@ int restore_open_tuning(cwslg_ctx *c, Channel &ch, const Receiver &rx)
     return CWSLG_OK;
 }
 
-template <int D>
-int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_blocks, uint32_t fs, bool tile_major)
+// demod_exact5_kernel (192 kHz, exact mode): one wave per (channel, chunk of 32 streams x seg_len outputs).  seg_len trades the 32-block warm-up
+// of every stream (32 / seg_len of extra work) against waves to fill the chip with: at least two rounds of resident waves where the work allows.
+int launch_exact5(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_blocks, uint32_t fs, bool chunk_major)
 {
     if (works.empty()) return CWSLG_OK;
+    uint64_t total_blocks = 0;
+    for (const ChanWork &w : works) total_blocks += w.n_blocks;
+    const uint64_t waves_min = (uint64_t)c->cu_count * 8 * 2;
+    unsigned seg = (unsigned)std::min<uint64_t>(c->exact5_seg_cap, (total_blocks + 32 * waves_min - 1) / (32 * waves_min));
+    seg = std::max(4u, (seg + 3) / 4 * 4);
+    const int chunks = (int)((max_blocks + 32 * seg - 1) / (32 * seg));
+    WorkBuf *w = acquire_workbuf(c, works.size() * sizeof(ChanWork));
+    if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
+    std::memcpy(w->h, works.data(), works.size() * sizeof(ChanWork));
+    HIPCHK(c, upload_workbuf(c, w, works.size() * sizeof(ChanWork)));
+    const long long items = (long long)chunks * (long long)works.size();
+    hipEvent_t ea, eb;
+    span_begin(c, 0, &ea, &eb);
+    c->demod_kernel_name = "demod_exact5_kernel";
+    unsigned long long *clk = nullptr;
+    if (c->timing && c->clk_dev && c->clk_head - c->clk_tail < kClkSlots) {
+        const unsigned slot = c->clk_head++ % kClkSlots;
+        std::memset(c->clk_h + 4 * slot, 0, 4 * sizeof(unsigned long long));
+        clk = c->clk_dev + 4 * slot;
+    }
+    hipLaunchKernelGGL(demod_exact5_kernel, dim3((unsigned)((items + kExact5Waves - 1) / kExact5Waves)), dim3(64 * kExact5Waves), 0, c->stream,
+                       (const ChanWork *)w->d, (const float *)c->d_taps[fs], chunk_major ? -chunks : chunks, (int)works.size(), (int)seg, clk);
+    span_end(c, eb);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(w->done, c->stream));
+    w->in_flight = true;
+    c->stats.demod_launches++;
+    return CWSLG_OK;
+}
+
+template <int D>
+int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_blocks, uint32_t fs, bool tile_major, bool no_split = false)
+{
+    if (works.empty()) return CWSLG_OK;
+    if (D == 16 && c->exact && c->use_exact5 && !no_split) {
+        // 192 kHz, exact mode: demod_exact5_kernel takes every output whose 32-block history exists (q_first >= 32); the first 32 outputs of a
+        // fresh demodulator -- and any work that does not meet its alignment rules -- go through demod_exact4_kernel
+        std::vector<ChanWork> head, rest;
+        unsigned max_head = 0, max_rest = 0;
+        for (const ChanWork &w0 : works) {
+            ChanWork w = w0;
+            const bool aligned = w.q_first % 4 == 0 && w.n_blocks % 4 == 0 && w.lo_mod % 64 == 0 && w.ring_cap % 64 == 0 && (uint64_t)w.ring_cap * 8 < (1ull << 32);
+            unsigned n_head = !aligned ? w.n_blocks : (w.q_first < 32 ? (unsigned)std::min<long long>(w.n_blocks, 32 - w.q_first) : 0u);
+            if (n_head) {
+                ChanWork h = w;
+                h.n_blocks = n_head;
+                head.push_back(h);
+                max_head = std::max(max_head, n_head);
+                w.out += n_head;
+                w.n_blocks -= n_head;
+                w.lo_mod = (unsigned)(((uint64_t)w.lo_mod + (uint64_t)n_head * D) % w.ring_cap);
+                w.q_first += n_head;
+            }
+            if (w.n_blocks) { rest.push_back(w); max_rest = std::max(max_rest, w.n_blocks); }
+        }
+        int rc = launch_demod<D>(c, head, max_head, fs, tile_major, true);
+        if (rc) return rc;
+        return launch_exact5(c, rest, max_rest, fs, tile_major);
+    }
     // the descriptors, then (64-byte aligned) the eight per-XCD work counters of demod_exact3_kernel, zero at launch
     const size_t ctr_off = (works.size() * sizeof(ChanWork) + 63) & ~size_t(63);
     WorkBuf *w = acquire_workbuf(c, ctr_off + 64);
@@ -601,7 +665,7 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     const long long total = (long long)tiles_n * (long long)works.size();
     const long long per_xcd = (total + 7) / 8;
     hipEvent_t ea, eb;
-    span_begin(c, 0, &ea, &eb);
+    span_begin(c, no_split ? 5 : 0, &ea, &eb);
     bool launched = false;
 #if CWSLG_LAB
     launched = true;
@@ -685,7 +749,7 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
             const int run_len = (int)std::min<long long>(8, std::max<long long>(1, per_xcd / slots));  // items per draw
             const long long wgs = 8 * std::min(slots, (per_xcd + run_len - 1) / run_len);
             unsigned long long *clk = nullptr;
-            if (c->timing && c->clk_dev && c->clk_head - c->clk_tail < kClkSlots) {
+            if (c->timing && c->clk_dev && !no_split && c->clk_head - c->clk_tail < kClkSlots) {     // (a head launch is not what the clock figure is about)
                 const unsigned slot = c->clk_head++ % kClkSlots;
                 std::memset(c->clk_h + 4 * slot, 0, 4 * sizeof(unsigned long long));
                 clk = c->clk_dev + 4 * slot;
@@ -726,7 +790,7 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(w->done, c->stream));
     w->in_flight = true;
-    c->stats.demod_launches++;
+    if (no_split) c->stats.demod_head_launches++; else c->stats.demod_launches++;
     return CWSLG_OK;
 }
 
@@ -1140,6 +1204,8 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
     // lab build only: the switches that select a measured alternative.  The product library reads no environment variable that
     // changes a kernel or the order of its arithmetic.
     if (const char *v = std::getenv("CWSLG_DEMOD_VARIANT")) c->demod_variant = std::atoi(v);
+    if (c->demod_variant != 0) c->use_exact5 = false;          // every measured alternative is an alternative to round 4's launch shape (27: exact4 itself, for A/B)
+    if (const char *v = std::getenv("CWSLG_EXACT5_SEG")) c->exact5_seg_cap = (unsigned)std::max(4, std::atoi(v));
     if (const char *v = std::getenv("CWSLG_UPLOAD")) c->upload_by_dma = std::strcmp(v, "dma") == 0;
     if (const char *v = std::getenv("CWSLG_FT4_DFT")) c->ft4_dft_valu = std::strcmp(v, "valu") == 0;
     if (const char *v = std::getenv("CWSLG_ITEM_ORDER")) c->order_override = std::atoi(v);

@@ -2260,6 +2260,95 @@ __global__ __launch_bounds__(NT, 4) void demod_exact4_kernel(const ChanWork *__r
 }
 
 // ---------------------------------------------------------------------------------------------
+// demod_exact5_kernel (192 kHz; round 5): the reference's arithmetic with LANE = STREAM -- a wave serves 32 consecutive segments of seg_len
+// outputs of ONE channel, time runs along the lane, and everything a stream needs between two tiles (its 16 samples, the 32 x 2 running sums,
+// the workspace chain, its mixer phase) stays in registers.  The un-fused products fl(y * h) (SSBD.hpp:167-168) of a block against all 32 tap
+// blocks are ONE K = 1 matrix instruction per sample (v_mfma_f32_32x32x1_2b_f32, C = 0: bit-identical to v_mul_f32, scripts/micro/mfma_k1.hip);
+// the ordered sums, sum * phase and the workspace accumulation are plain v_add_f32 / v_mul_f32 in the reference's order.  Why this shape, what
+// the matrix instruction does and does not buy (it shares the FP32 lanes with the VALU: no second pipe), the register map and the zero-sign
+// argument: scripts/gen_exact5_asm.py and DESIGN.md 4.1d; profiles/r5_mfma_k1.txt.  The wave's whole life is one generated assembly statement
+// (exact5_asm.inc), executed on the CPU against the oracle before it ever reached a GPU (tests/test_exact5_stream.py, tests/wave_emulator.py).
+//   Work item = (channel, chunk of 32 x seg_len outputs); one wave per item, four waves per workgroup, no barrier anywhere (a wave's LDS
+//   rows are its own: the 32 x 128 bytes of a tile are loaded coalesced -- eight lanes per 128-byte line -- and read back lane = stream).
+//   A stream starts 32 blocks before its first output (the workspace needs an output's 32 blocks); the host therefore hands this kernel only
+//   work whose 32-block history exists: q_first >= 32 (the first 32 outputs of a fresh demodulator go through demod_exact4_kernel).
+//   Requires q_first, n_blocks, seg_len multiples of 4, lo_mod a multiple of 64 samples and the ring shorter than 4 GiB (host-checked).
+#include "exact5_asm.inc"
+constexpr int kExact5Waves = 4;
+__global__ __launch_bounds__(64 * kExact5Waves, 2) void demod_exact5_kernel(const ChanWork *__restrict__ works, const float *__restrict__ taps, int chunks_x,
+                                                                              int n_ch, int seg_len, unsigned long long *__restrict__ clk)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_rows[kExact5Waves * 2 * EXACT5_ASM_BUF_BYTES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int item = (int)blockIdx.x * kExact5Waves + wv;
+    const int n_items = (chunks_x < 0 ? -chunks_x : chunks_x) * n_ch;
+    if (item >= n_items) return;
+    int ch, chunk;
+    item_to_ch_tile(item, chunks_x, n_ch, ch, chunk);
+    ch = (int)uni((unsigned)ch); chunk = (int)uni((unsigned)chunk);
+    const CWSLG_CONST ChanWork *cw = as_const(works + ch);
+    const unsigned n_blocks = cw->n_blocks, cap = cw->ring_cap, lo_mod = cw->lo_mod;
+    const long long q_first = cw->q_first;
+    const long long first_seg = (long long)chunk * 32;
+    if (first_seg * seg_len >= (long long)n_blocks) return;                           // a chunk past this channel's pending blocks
+    const unsigned most = (unsigned)min((long long)seg_len, (long long)n_blocks - first_seg * seg_len);   // outputs of the wave's first (fullest) stream
+    // ring byte offset of the first sample of stream s (its 32-block warm-up included): lo_mod + 16 (first output - 32), modulo the ring
+    auto stream_pos = [&](int s) -> unsigned {
+        long long rel = ((first_seg + s) * (long long)seg_len - 32) * 16 + (long long)lo_mod;
+        rel %= (long long)cap;
+        if (rel < 0) rel += cap;
+        return (unsigned)rel * 8u;
+    };
+    const int j = lane & 31;
+    unsigned off0 = stream_pos(0 + (lane >> 3)) + (unsigned)(lane & 7) * 16u, off1 = stream_pos(8 + (lane >> 3)) + (unsigned)(lane & 7) * 16u;
+    unsigned off2 = stream_pos(16 + (lane >> 3)) + (unsigned)(lane & 7) * 16u, off3 = stream_pos(24 + (lane >> 3)) + (unsigned)(lane & 7) * 16u;
+    const unsigned pc16 = (unsigned)(lane & 7) * 16u, capl = cap * 8u + pc16;
+    const unsigned lds0 = (unsigned)(size_t)(s_rows + wv * 2 * EXACT5_ASM_BUF_BYTES);
+    const unsigned ldsr = lds0 + (unsigned)j * EXACT5_ASM_ROW_BYTES, ldsw = lds0 + (unsigned)(lane >> 3) * EXACT5_ASM_ROW_BYTES + pc16;
+    const long long my_first = (first_seg + j) * (long long)seg_len;
+    int rem = (int)max(0ll, min((long long)seg_len, (long long)n_blocks - my_first));
+    const long long q_start = q_first + my_first - 32;
+    const unsigned ckoff = rem > 0 ? (unsigned)(q_start / kCk) * 8u : 0u;                // an idle stream: any entry of the table
+    unsigned outoff = (unsigned)my_first * 4u;
+    // the matrix instruction's row i (operand lane i & 31) lands in the half (i >> 2) & 1, register (i & 3) + 4 (i >> 3): give row i tap block
+    // n = register + 16 half, so that a lane of the lower half holds tap blocks 0..15 in register order and the upper half 16..31
+    const unsigned tapoff = (unsigned)((j & 3) + 4 * (j >> 3) + 16 * ((j >> 2) & 1)) * 64u;
+    const float sign = __uint_as_float(uni(__float_as_uint(cw->sign)));
+    const float nsign = -sign;
+    const float incre = __uint_as_float(uni(__float_as_uint(cw->inc.x))), incim = __uint_as_float(uni(__float_as_uint(cw->inc.y)));
+    const float2 *ring = uni_ptr(cw->ring), *ckpt = uni_ptr(cw->ckpt), *tone = uni_ptr(cw->tone);
+    float *out = uni_ptr(cw->out);
+    unsigned *peak_word = uni_ptr(cw->peak);
+    const float *taps_u = uni_ptr(taps);
+    int warm = EXACT5_ASM_WARM_STORES, iters = EXACT5_ASM_WARM_ITERS + (int)((most + 3) / 4);
+    const unsigned long long hmask = 0xFFFFFFFF00000000ull;
+    unsigned long long esave;
+    float peak;
+    const bool stamp = clk != nullptr && blockIdx.x == 0 && wv == 0;
+    if (stamp && lane == 0) {
+        unsigned long long t_, r_;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");
+        as_global_rw(clk)[0] = t_;
+        as_global_rw(clk)[1] = r_;
+    }
+    asm volatile(EXACT5_PROLOGUE_ASM EXACT5_LOOP_ASM EXACT5_EPILOGUE_ASM
+                 : [off0] "+v"(off0), [off1] "+v"(off1), [off2] "+v"(off2), [off3] "+v"(off3), [rem] "+v"(rem), [outoff] "+v"(outoff), [peak] "=&v"(peak),
+                   [esave] "=&s"(esave), [warm] "+s"(warm), [iters] "+s"(iters)
+                 : [capl] "v"(capl), [pc16] "v"(pc16), [ldsr] "v"(ldsr), [ldsw] "v"(ldsw), [ckoff] "v"(ckoff), [tapoff] "v"(tapoff),
+                   [ring] "s"(ring), [taps] "s"(taps_u), [tone] "s"(tone), [ckpt] "s"(ckpt), [out] "s"(out),
+                   [incre] "s"(incre), [incim] "s"(incim), [sign] "s"(sign), [nsign] "s"(nsign), [hmask] "s"(hmask)
+                 : EXACT5_ASM_CLOBBERS);
+    const float mx = wave_max_dpp(peak);
+    if (lane == 0) publish_peak(peak_word, mx);
+    if (stamp && lane == 0) {
+        unsigned long long t_, r_;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");
+        as_global_rw(clk)[2] = t_;
+        as_global_rw(clk)[3] = r_;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // demod_transition_kernel: the (at most 32) outputs after a phase-continuous retune, in ProcessBlock's own order (SSBD.hpp:160-183)
 // whatever the context's mode -- they are a handful per retune.  grid = works, 64 threads: thread = output.
 template <int D>

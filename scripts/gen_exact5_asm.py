@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""Generates cwsl_digi_amd/csrc/exact5_asm.inc: the whole life of one wave of demod_exact5_kernel (192 kHz, round 5) as ONE assembly statement.
+
+Why a new shape.  demod_exact4_kernel pays for the reference's arithmetic at 1.76 GHz: lane = output, so every block row of the tile image is
+re-read from LDS by 17 lanes (1.15 MB per 512 outputs) and the chip sits at its package power limit.  Round 5's micro-benchmark
+(scripts/micro/mfma_k1.hip, profiles/r5_mfma_k1.txt) measured the same arithmetic with every operand in registers at 980-1110 ns per 1024 sums
+and 2.38 GHz, against exact4's 1570 ns.  Here therefore LANE = STREAM and time runs along the lane:
+
+  * a wave serves 32 consecutive segments ("streams") of ONE channel's pending blocks: lane j and lane 32 + j both belong to stream j; a lane of
+    the lower half carries Re, of the upper half Im, of the mixed sample y = in * tone (SSBD.hpp:167) and the tap blocks n = 0..15 / 16..31;
+  * per block ("tile": 16 samples of each stream): y[m] = in.re * c1[m] + in.im * c2[m] (c = (tone.re, -tone.im) in the lower half, (tone.im,
+    tone.re) in the upper: the un-fused complex product's Re and Im), then for m = 0..15 ONE v_mfma_f32_32x32x1_2b_f32 with A = lane i -> h[m +
+    16 n(i)], B = y[m], C = 0: the 2048 products fl(y * h) of all 32 tap blocks, Re and Im (K = 1: one rounding per product, bit-identical to
+    v_mul_f32 -- measured on 2^32 pairs), landing in the lane of their stream; S = P_0, S = fl(S + P_m) in the reference's order (:168);
+  * T_r = S.re_r * k1 + S.im_r * k2 -- the component of sum * phase (:170) that Iterate() will read of the output this term belongs to (Re for
+    even outputs, Im for odd ones: :131-134), the block's phase kept and advanced in the lane (phase *= phase_inc, :174);
+  * the 32-term accumulation of an output (:170, oldest block first) runs down a 17-register shift chain: W[r + 1] = W[r] + T_r (tap block r of the
+    lower half, 16 + r of the upper); once per tile the lower half's finished partial (n = 0..15) crosses to the upper half (v_permlane32_swap)
+    where it collects n = 16..31, and the upper half's W[16] is the finished output;
+  * the wave streams its 32 x 128 bytes per tile through LDS only to transpose them (coalesced 16-byte loads -> one row per stream, read back
+    lane = stream); nothing is re-read: 12 KB of LDS traffic per 1024 sums where exact4 moves 72 KB.
+A stream starts 32 blocks before its first output (the workspace warm-up: an output needs its 32 blocks); the host hands over only work whose
+32-block history exists (the first 32 outputs after a demodulator's creation go through demod_exact4_kernel).
+
+Zeros.  The MFMA computes fmaf(a, b, +0): an exact-zero product arrives as +0 where v_mul_f32 gives -0.  That cannot change an output: the
+reference's running sum starts as (+0 + p_0) and is therefore never -0, so adding either zero leaves it unchanged; where a whole sum is zero its
+term T is a zero of either sign, and the workspace slot it is added to -- which itself starts as +0 + T_0 -- is never -0 either.
+
+    python scripts/gen_exact5_asm.py > cwsl_digi_amd/csrc/exact5_asm.inc
+
+tests/test_exact5_stream.py runs this text on a 64-lane emulator (tests/wave_emulator.py) against the oracle's demodulator and compares bits; it also
+re-derives every wait the text needs (MFMA results, LDS and memory loads) and fails on a read that is not covered."""
+import re
+import sys
+
+# ---- register map (all fixed; the statement's operands are extra registers chosen by the compiler) ----
+S, DA, DB, H, Y, IN, C1, C2, W = 0, 32, 64, 96, 112, 128, 144, 160, 176
+NPIM, P, STG, OB, PEAK, T = 193, 194, 196, 212, 216, 217           # P = (re, im) at 194/195; temporaries T..T+7
+VTOP = 225
+import os
+LOADER_IN_GAP = os.environ.get("X5_LOADER_IN_GAP", "1") == "1"
+RING_NT = " nt" if os.environ.get("X5_RING_NT", "1") == "1" else ""    # the ring is read once: non-temporal (same-box A/B: 2.5-2.8 % of the launch)
+STG2 = 240                                                         # the second staging set, at the top of the file (the operands sit between VTOP and it)
+ROW = 144                                                          # LDS row pitch: 16 samples + 16 bytes (conflict-free 16-byte reads, lane = row)
+BUF = 32 * ROW                                                     # one tile of one wave: 4608 bytes; two buffers
+MFMA_WAIT = 18                                                     # issue slots between a 16-pass f32 MFMA and a VALU access to its result
+WARM_ITERS = 8                                                     # 32 warm-up tiles
+
+
+def mfma(dst, m):
+    return f"v_mfma_f32_32x32x1_2b_f32 v[{dst}:{dst + 31}], v{H + m}, v{Y + m}, 0"
+
+
+def adds(src):
+    return [f"v_add_f32 v{S + k}, v{S + k}, v{src + k}" for k in range(32)]
+
+
+def mix(m):
+    mm, t = m & 7, T + 2 * (m & 1)
+    return [f"v_mul_f32 v{t}, v{IN + 2 * mm}, v{C1 + m}", f"v_mul_f32 v{t + 1}, v{IN + 2 * mm + 1}, v{C2 + m}", f"v_add_f32 v{Y + m}, v{t}, v{t + 1}"]
+
+
+def lds_read(buf, half):
+    return [f"ds_read_b128 v[{IN + 4 * k}:{IN + 4 * k + 3}], %[ldsr] offset:{buf * BUF + 64 * half + 16 * k}" for k in range(4)]
+
+
+def stg(tile):
+    return STG2 if tile & 1 else STG                                # tile t's rows travel through staging set t & 1 into LDS buffer t & 1
+
+
+def lds_write(tile):
+    return [f"ds_write_b128 %[ldsw], v[{stg(tile) + 4 * i}:{stg(tile) + 4 * i + 3}] offset:{(tile & 1) * BUF + 8 * ROW * i}" for i in range(4)]
+
+
+def ring_loads(tile):
+    return [f"global_load_dwordx4 v[{stg(tile) + 4 * i}:{stg(tile) + 4 * i + 3}], %[off{i}], %[ring] offset:{128 * (tile & 3)}{RING_NT}" for i in range(4)]
+
+
+def advance_offsets():
+    out = []
+    for i in range(4):                                             # the next 512 bytes of each stream; the ring's end is a multiple of 512 bytes away from its start
+        out += [f"v_add_u32 %[off{i}], 0x200, %[off{i}]", f"v_cmp_eq_u32 vcc, %[off{i}], %[capl]", f"v_cndmask_b32 %[off{i}], %[off{i}], %[pc16], vcc"]
+    return out
+
+
+def t_and_w(u):
+    """sum * phase, the component the output will read, and the workspace chain (descending r: every add reads the slot's previous occupant)."""
+    out = []
+    for r in range(15, -1, -1):
+        re_type = (u + r) & 1                                       # output b = q + 31 - n is even: Re(sum * phase) = S.re p.re - S.im p.im
+        k1, k2 = (P, NPIM) if re_type else (P + 1, P)               # odd: Im = S.re p.im + S.im p.re
+        t = T + 3 * (r & 1)
+        out += [f"v_mul_f32 v{t}, v{S + r}, v{k1}", f"v_mul_f32 v{t + 1}, v{S + 16 + r}, v{k2}", f"v_add_f32 v{t + 2}, v{t}, v{t + 1}",
+                f"v_add_f32 v{W + r + 1}, v{W + r}, v{t + 2}"]
+    # the lower half's partial (tap blocks 0..15 done) becomes the upper half's W[0]; the lower half starts a fresh slot (+0)
+    out += [f"v_mov_b32 v{W}, 0"]
+    return out
+
+
+def swap_and_out(u):
+    g = ["v_mov_b32 v{d}, v{s}", "v_mul_f32 v{d}, %[nsign], v{s}", "v_mul_f32 v{d}, -1.0, v{s}", "v_mul_f32 v{d}, %[sign], v{s}"][u]   # Iterate(): +Re, -Im sign, -Re, +Im sign
+    return [f"v_permlane32_swap_b32 v{W}, v{W + 16}", g.format(d=OB + u, s=W + 16)]
+
+
+def phase_step():
+    t = T
+    return [f"v_mul_f32 v{t}, %[incre], v{P}", f"v_mul_f32 v{t + 1}, %[incim], v{P + 1}", f"v_mul_f32 v{t + 2}, %[incim], v{P}", f"v_mul_f32 v{t + 3}, %[incre], v{P + 1}",
+            f"v_sub_f32 v{P}, v{t}, v{t + 1}", f"v_add_f32 v{P + 1}, v{t + 2}, v{t + 3}", f"v_mul_f32 v{NPIM}, -1.0, v{P + 1}"]
+
+
+def tile(u):
+    """Memory pipeline: TWO tiles of a stream are in flight (one tile per wave was 8 MB in flight chip-wide: at ~2.8 us of loaded HBM latency that
+    is the 2.9 TB/s the first form of this kernel ran at, whatever its arithmetic did).  At tile t: wait for tile t + 1's rows (the older of the
+    two outstanding sets: vmcnt(4)), move them to LDS buffer (t + 1) & 1, and request tile t + 3 into the staging set that this freed."""
+    buf = u & 1
+    L = ["s_waitcnt lgkmcnt(0)"]                                    # samples 0..7 of this tile (read at the end of the previous one)
+    for m in range(8):
+        L += mix(m)
+    L += lds_read(buf, 1)                                           # samples 8..15 into the same registers
+    loader = ["s_waitcnt vmcnt(4)"]                                 # the NEXT tile's rows have arrived from the ring ...
+    loader += lds_write(u + 1)                                      # ... transposed through LDS ...
+    if u == 0:
+        loader += store_block()                                     # the previous iteration's four outputs (behind the older loads, ahead of the new ones: see vmcnt)
+    if u == 1:
+        loader += advance_offsets()
+    loader += ring_loads(u + 3)                                     # ... and the third tile from here is requested
+    if not LOADER_IN_GAP:
+        L += loader
+    where = {}
+    second_half_mixed = False
+    for m in range(16):
+        dst = S if m == 0 else (DA if m & 1 else DB)
+        L.append(mfma(dst, m))
+        where[m] = dst
+        if m == 1 and LOADER_IN_GAP:                                # MFMA 1's products are 18 issue slots away: the memory pipeline's instructions wait here
+            L += loader
+        if m >= 2:
+            L += adds(where[m - 1])
+        if m == 5:                                                  # samples 8..15 have long landed: mix them before MFMA 8 needs y[8]
+            L += ["s_waitcnt lgkmcnt(0)"]
+            for mm in range(8, 16):
+                L += mix(mm)
+            L += lds_read(buf ^ 1, 0)                               # the next tile's samples 0..7
+    L += adds(where[15])
+    L += t_and_w(u)
+    L += phase_step()                                               # (two instructions at least between W[0]'s write and the swap that reads it)
+    L += swap_and_out(u)
+    return L
+
+
+def prologue():
+    L = ["s_nop 4"]                                                 # operands fresh from v_readfirstlane are read as addresses below (5 wait states)
+    L += [f"global_load_dwordx4 v[{H + 4 * k}:{H + 4 * k + 3}], %[tapoff], %[taps] offset:{16 * k}" for k in range(4)]
+    L += [f"global_load_dwordx2 v[{P}:{P + 1}], %[ckoff], %[ckpt]"]
+    L += ["s_load_dwordx16 s[64:79], %[tone], 0x0", "s_load_dwordx16 s[80:95], %[tone], 0x40"]
+    L += ring_loads(0) + ring_loads(1)
+    L += [f"v_mov_b32 v{W + k}, 0" for k in range(17)] + [f"v_mov_b32 v{OB + k}, 0" for k in range(4)] + [f"v_mov_b32 v{PEAK}, 0"]
+    L += ["s_waitcnt vmcnt(0) lgkmcnt(0)"]
+    L += ["s_mov_b64 vcc, %[hmask]"]
+    for m in range(16):                                             # c1 = (tone.re | tone.im), c2 = (-tone.im | tone.re) by half
+        L += [f"v_mov_b32 v{T}, s{64 + 2 * m}", f"v_mov_b32 v{T + 1}, s{65 + 2 * m}", f"v_cndmask_b32 v{C1 + m}, v{T}, v{T + 1}, vcc",
+              f"v_xor_b32 v{T + 2}, 0x80000000, v{T + 1}", f"v_cndmask_b32 v{C2 + m}, v{T + 2}, v{T}, vcc"]
+    L += [f"v_mul_f32 v{NPIM}, -1.0, v{P + 1}"]
+    L += lds_write(0)
+    L += ring_loads(2)
+    L += lds_read(0, 0)
+    return L
+
+
+def store_block():
+    return ["s_cmp_gt_u32 %[warm], 0", "s_cbranch_scc1 L5_WARM_%=",
+            "v_cmp_lt_i32 vcc, 0, %[rem]", "s_and_b64 vcc, vcc, %[hmask]", "s_and_saveexec_b64 %[esave], vcc",
+            f"global_store_dwordx4 %[outoff], v[{OB}:{OB + 3}], %[out]"] + \
+           [f"v_max_f32 v{PEAK}, v{PEAK}, |v{OB + k}|" for k in range(4)] + \
+           ["s_mov_b64 exec, %[esave]", "v_add_u32 %[outoff], 16, %[outoff]", "v_add_u32 %[rem], -4, %[rem]", "s_branch L5_NEXT_%=",
+            "L5_WARM_%=:", "s_sub_u32 %[warm], %[warm], 1", "L5_NEXT_%=:"]
+
+
+def regs_of(tok):
+    tok = tok.strip().strip("|")
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def split_ops(l):
+    op, _, rest = l.partition(" ")
+    rest = re.sub(r"\s+offset:\d+", "", rest)
+    return op, ([t.strip() for t in re.split(r",\s*(?![^\[]*\])", rest)] if rest else [])
+
+
+def slots(L):
+    """Issue slots of the SHORTEST path through L: what lies between a forward branch and its target may be skipped and counts nothing."""
+    n, skip_to = 0, None
+    for l in L:
+        if skip_to is not None:
+            if l == skip_to + ":":
+                skip_to = None
+            continue
+        if l.endswith(":"):
+            continue
+        n += int(l.split()[1]) + 1 if l.startswith("s_nop") else 1
+        if l.startswith(("s_cbranch", "s_branch")):
+            skip_to = l.split()[1]
+    return n
+
+
+def fix_hazards(L):
+    """hipcc pads nothing inside an asm string.  Rules applied (the f32 MFMAs are 16-pass, not XDL): an MFMA's result may be touched by the VALU
+    MFMA_WAIT issue slots after the MFMA at the earliest -- or once two later MFMAs have issued (they complete in order); a VALU result is an MFMA
+    operand two slots later at the earliest; v_permlane32_swap reads a VALU result two slots later at the earliest."""
+    out, pend, wrote, n_mfma = [], [], {}, 0
+    for l in L:
+        op, toks = split_ops(l)
+        used = set().union(*[regs_of(t) for t in toks]) if toks else set()
+        need = 0
+        if op.startswith(("v_", "ds_write", "global_store")):
+            for (regs, pos, idx) in pend:
+                if regs & used and n_mfma - idx < (1 if op.startswith("v_mfma") else 2):
+                    need = max(need, MFMA_WAIT - (slots(out) - pos))
+        if op.startswith("v_mfma") or op.startswith("v_permlane"):
+            for t in (toks[1:3] if op.startswith("v_mfma") else toks[0:2]):
+                for r in regs_of(t):
+                    if r in wrote:
+                        need = max(need, 2 - (slots(out) - wrote[r]))
+        if need > 0:
+            out.append(f"s_nop {need - 1}")
+        if op.startswith("v_mfma"):
+            n_mfma += 1
+            pend = [(r, p, i) for (r, p, i) in pend if n_mfma - i < 3]
+            pend.append((regs_of(toks[0]), slots(out) + 1, n_mfma))
+        elif op.startswith("v_") and toks and not op.startswith("v_cmp"):
+            for r in regs_of(toks[0]):
+                wrote[r] = slots(out) + 1
+        out.append(l)
+    return out
+
+
+def program():
+    pro = fix_hazards(prologue())
+    body = []
+    for u in range(4):
+        body += tile(u)
+    body = fix_hazards(body + [mfma(S, 0)])[:-1]                    # (the loop wraps: the hazards of the first MFMA against the body's end hold as well)
+    loop = ["L5_LOOP_%=:"] + body + ["s_sub_u32 %[iters], %[iters], 1", "s_cmp_lg_u32 %[iters], 0", "s_cbranch_scc1 L5_LOOP_%="]
+    epi = [l.replace("L5_", "L5E_") for l in store_block()] + ["s_waitcnt vmcnt(0) lgkmcnt(0)", f"v_mov_b32 %[peak], v{PEAK}"]
+    return pro, loop, epi
+
+
+def main():
+    pro, loop, epi = program()
+    w = sys.stdout.write
+    w("// GENERATED by scripts/gen_exact5_asm.py -- do not edit.  See that script and demod_exact5_kernel (demod_kernels.hpp).\n")
+    w(f"#define EXACT5_ASM_ROW_BYTES {ROW}\n#define EXACT5_ASM_BUF_BYTES {BUF}\n#define EXACT5_ASM_WARM_ITERS {WARM_ITERS}\n#define EXACT5_ASM_WARM_STORES {WARM_ITERS + 1}\n#define EXACT5_ASM_VTOP {VTOP}\n")
+    w("#define EXACT5_ASM_CLOBBERS " + ", ".join(f'"v{i}"' for i in list(range(VTOP)) + list(range(STG2, STG2 + 16))) + ", " + ", ".join(f'"s{i}"' for i in range(64, 96)) + ', "vcc", "scc", "memory"\n')
+    for name, lines in (("EXACT5_PROLOGUE_ASM", pro), ("EXACT5_LOOP_ASM", loop), ("EXACT5_EPILOGUE_ASM", epi)):
+        w(f"#define {name} \\\n")
+        for l in lines:
+            w(f'    "{l}\\n\\t" \\\n')
+        w('    ""\n\n')
+
+
+if __name__ == "__main__":
+    main()

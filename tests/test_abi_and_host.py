@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in cwsl_gpu.h but not exported"
     assert sorted(api.ABI_SYMBOLS) == names, set(api.ABI_SYMBOLS) ^ set(names)
-    assert L.cwslg_abi_version() == 4
+    assert L.cwslg_abi_version() == 5
 
 
 def test_fails_loudly_without_gpu():
@@ -109,7 +109,7 @@ def test_product_library_has_one_kernel_per_job_and_no_lab_switches():
     B.build()
     prod, lab = open(B.LIB, "rb").read(), open(B.LAB_LIB, "rb").read()
     for switch in (b"CWSLG_DEMOD_VARIANT", b"CWSLG_SYNC_VARIANT", b"CWSLG_LONG_VARIANT", b"CWSLG_FT4_DFT", b"CWSLG_ITEM_ORDER",
-                   b"CWSLG_UPLOAD", b"CWSLG_COPY_ON_MAIN", b"CWSLG_PERSIST_WGS_PER_CU"):
+                   b"CWSLG_UPLOAD", b"CWSLG_COPY_ON_MAIN", b"CWSLG_PERSIST_WGS_PER_CU", b"CWSLG_EXACT5_SEG"):
         assert switch not in prod, switch
         assert switch in lab, switch
     kp, kl = _kernel_names(B.LIB), _kernel_names(B.LAB_LIB)
@@ -124,9 +124,10 @@ def test_product_library_has_one_kernel_per_job_and_no_lab_switches():
     # (tile by decimation: 256 outputs at 192 kHz, 512 at 96 kHz, 768 at 48 kHz -- the same amount of IQ per workgroup)
     assert len(demod) == 3 and sum(t in k for k in demod for t in ("ILi16ELi256ELi256ELi0E", "ILi8ELi512ELi256ELi0E", "ILi4ELi768ELi256ELi0E")) == 3, demod
     exact = sorted(k for k in kp if "demod_exact" in k)
-    # exact mode: the two-stream form at 192 kHz (eight waves per tile image), round 3's one-stream form at 96 / 48 kHz
-    assert len(exact) == 3 and sum("demod_exact4_kernelILi512ELi512E" in k for k in exact) == 1, exact
+    # exact mode at 192 kHz: the stream form (round 5: lane = stream, K = 1 matrix products) for every output whose 32-block history exists, the
+    # two-stream tile form for the first 32 outputs of a demodulator; round 3's one-stream form at 96 / 48 kHz
+    assert len(exact) == 4 and sum("demod_exact4_kernelILi512ELi512E" in k for k in exact) == 1 and sum("demod_exact5_kernel" in k for k in exact) == 1, exact
     assert sum("demod_exact3_kernelILi8ELi512ELi256E" in k or "demod_exact3_kernelILi4ELi512ELi256E" in k for k in exact) == 2, exact
     # FT8: Costas search + candidate selection in one launch per boundary, or (few channels) one workgroup per band + the selection
     assert any("ft8_sync_chan_kernel" in k for k in kp) and any("ft8_sync2d_v3_kernel" in k for k in kp)
-    assert len(kp) <= 37, sorted(kp)                   # round 4: + scatter_blocks_kernel (cwslg_push_iq_many)
+    assert len(kp) <= 38, sorted(kp)                   # round 4: + scatter_blocks_kernel (cwslg_push_iq_many); round 5: + demod_exact5_kernel

@@ -1,0 +1,127 @@
+"""CPU: the generated program of demod_exact5_kernel (scripts/gen_exact5_asm.py: one wave's whole life -- prologue, tile loop with its branches, epilogue)
+run on the 64-lane emulator (tests/wave_emulator.py) against the oracle's demodulator (oracle/cwsl_oracle.c, pinned bit for bit to the compiled
+SSBD.hpp): the 32 streams of a wave write exactly the reference's float32 audio, the ragged last lanes write nothing, the ring wrap inside a
+stream is followed, the peak is the maximum of what was written.  The emulator also re-derives every wait the text needs (memory / LDS loads in
+flight, MFMA results, operands of the matrix instruction and of the lane swap) and fails on an uncovered access."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from wave_emulator import Wave
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F, U = np.float32, np.uint32
+FS, D = 192000, 16
+
+
+def _gen():
+    return subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_exact5_asm.py")], check=True, capture_output=True, text=True).stdout
+
+
+def _lines(text, macro):
+    body = text.split("#define %s \\\n" % macro, 1)[1].split('    ""\n', 1)[0]
+    return re.findall(r'"([^"\\]*)\\n\\t"', body)
+
+
+def _define(text, name):
+    return int(re.search(r"#define %s (\d+)" % name, text).group(1))
+
+
+def _cmul(a, b):
+    return (F(F(a[0] * b[0]) - F(a[1] * b[1])), F(F(a[0] * b[1]) + F(a[1] * b[0])))
+
+
+def _tap_block_of_row(i):
+    return (i & 3) + 4 * (i >> 3) + 16 * ((i >> 2) & 1)
+
+
+def _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, ring_shift_blocks):
+    text = _gen()
+    row, buf, warm = _define(text, "EXACT5_ASM_ROW_BYTES"), _define(text, "EXACT5_ASM_BUF_BYTES"), _define(text, "EXACT5_ASM_WARM_ITERS")
+    q_first = 32                                              # the demodulator's first 32 outputs are not this kernel's (no 32-block history)
+    total_blocks = q_first + n_blocks
+    n_samp = total_blocks * D
+    iq = oracle.synth_iq(seed, n_samp, FS, tones_hz=[f_hz + 700.0, f_hz + 2250.5], amp=1.7e4)
+    dm = oracle.Demod(FS, f_hz, usb=usb)
+    ref = dm.run(iq)
+    taps, tone, inc = dm.taps.astype(F), dm.tone, dm.phase_inc
+    # ---- global memory image ----
+    cap = ((n_samp + 64 * 37) // 64) * 64                     # ring capacity in samples, a multiple of 64
+    shift = ring_shift_blocks * D                             # logical sample i lives at ring[(i + shift) % cap]
+    ring = (np.arange(2 * cap, dtype=np.float32) * 0 + 7.0e8)  # junk everywhere the stream must not read
+    ring = ring.reshape(cap, 2)
+    pos = (np.arange(n_samp) + shift) % cap
+    ring[pos, 0], ring[pos, 1] = iq.real, iq.imag
+    n_ck = total_blocks // 4 + 2
+    ck = np.zeros((n_ck, 2), F)
+    p = (F(1), F(0))
+    for q in range(4 * n_ck):
+        if q % 4 == 0:
+            ck[q // 4] = p
+        p = _cmul(p, (F(inc.real), F(inc.imag)))
+    tone_ri = np.stack([tone.real, tone.imag], 1).astype(F)
+    out = np.full(n_blocks + 64, 3.0e8, F)
+    parts, base = {}, {}
+    cur = 256
+    for name, arr in (("ring", ring), ("taps", taps), ("tone", tone_ri), ("ckpt", ck), ("out", out)):
+        base[name] = cur
+        parts[name] = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+        cur += (len(parts[name]) + 255) // 256 * 256
+    mem = np.zeros(cur, np.uint8)
+    for name in parts:
+        mem[base[name]:base[name] + len(parts[name])] = parts[name]
+    # ---- operands of the statement, as the kernel's C++ prologue computes them ----
+    lane = np.arange(64)
+    j = lane & 31
+    def stream_pos_bytes(s):                                   # ring byte offset of the first sample of stream s (its 32-block warm-up included)
+        qs = q_first + s * seg_len - 32
+        return (((qs * D + shift) % cap) * 8).astype(np.int64)
+    n_out = np.clip(n_blocks - j * seg_len, 0, seg_len)
+    ops = {}
+    for i in range(4):
+        ops["off%d" % i] = ("v", (stream_pos_bytes(8 * i + (lane >> 3)) + (lane & 7) * 16).astype(U))
+    ops["capl"] = ("v", (cap * 8 + (lane & 7) * 16).astype(U))
+    ops["pc16"] = ("v", ((lane & 7) * 16).astype(U))
+    ops["ldsr"] = ("v", (j * row).astype(U))
+    ops["ldsw"] = ("v", ((lane >> 3) * row + (lane & 7) * 16).astype(U))
+    ops["ckoff"] = ("v", (((q_first + j * seg_len - 32) // 4) * 8).astype(U))
+    ops["tapoff"] = ("v", np.array([64 * _tap_block_of_row(int(i)) for i in j], U))
+    ops["rem"] = ("v", n_out.astype(U))
+    ops["outoff"] = ("v", (j * seg_len * 4).astype(U))
+    ops["peak"] = ("v", np.zeros(64, U))
+    sign = F(1.0 if usb else -1.0)
+    for name in ("ring", "taps", "tone", "ckpt", "out"):
+        ops[name] = ("s64", base[name])
+    ops.update(incre=("s", int(np.array(inc.real, F).view(U))), incim=("s", int(np.array(inc.imag, F).view(U))),
+               sign=("s", int(np.array(sign, F).view(U))), nsign=("s", int(np.array(-sign, F).view(U))),
+               hmask=("s64", 0xFFFFFFFF00000000), esave=("s64", 0), warm=("s", _define(text, "EXACT5_ASM_WARM_STORES")), iters=("s", warm + int(n_out.max() + 3) // 4))
+    w = Wave(mem, 2 * buf, ops)
+    w.run(_lines(text, "EXACT5_PROLOGUE_ASM") + _lines(text, "EXACT5_LOOP_ASM") + _lines(text, "EXACT5_EPILOGUE_ASM"))
+    got = mem[base["out"]:base["out"] + len(parts["out"])].view(F)
+    peak = w.v[w.names["peak"][1]].view(F)
+    return got, ref[q_first:], n_out, peak, w, text
+
+
+@pytest.mark.parametrize("f_hz,usb,seed,shift", [(-26000, True, 11, 0), (48000, True, 12, 5), (1234, False, 13, 37)])
+def test_exact5_wave_program_writes_the_reference_bits(oracle, f_hz, usb, seed, shift):
+    seg_len, n_blocks = 8, 244                                 # 30 full lanes, one of 4 outputs, one idle; shift 37 puts the ring's end inside a stream
+    got, want, n_out, peak, w, text = _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, shift)
+    assert np.array_equal(got[:n_blocks].view(U), want[:n_blocks].view(U)), np.nonzero(got[:n_blocks].view(U) != want[:n_blocks].view(U))[0][:8]
+    assert (got[n_blocks:] == F(3.0e8)).all(), "a lane wrote past its own outputs"
+    assert np.abs(want[:n_blocks]).max() == peak.max() and (peak[:32] == 0).all()
+    # shape of a tile: the reference's arithmetic and nothing fused -- 16 matrix instructions (2048 products each), 15 x 32 ordered additions
+    loop = _lines(text, "EXACT5_LOOP_ASM")
+    assert sum(l.startswith("v_mfma_f32_32x32x1_2b_f32") for l in loop) == 4 * 16
+    assert sum(bool(re.match(r"v_add_f32 v(\d+), v\1, v(3[2-9]|[4-9]\d)$", l)) for l in loop) == 4 * 15 * 32
+    assert not any("fma" in l.split(" ")[0].replace("v_mfma", "") for l in loop)
+    regs = [int(x) for l in loop for x in re.findall(r"\bv(\d+)\b", l)] + [int(x) for l in loop for x in re.findall(r"v\[\d+:(\d+)\]", l)]
+    vtop = int(re.search(r"#define EXACT5_ASM_VTOP (\d+)", text).group(1))              # fixed registers: v0 .. VTOP - 1 and the second staging set v240 .. v255
+    assert all(r < vtop or 240 <= r <= 255 for r in regs)
+
+
+def test_exact5_inc_file_is_the_generators_output():
+    assert _gen() == open(os.path.join(ROOT, "cwsl_digi_amd", "csrc", "exact5_asm.inc")).read(), "exact5_asm.inc is not the generator's output"
