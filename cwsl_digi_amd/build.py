@@ -39,7 +39,7 @@ def _source_hash():
     import hashlib
     h = hashlib.sha256()
     deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if os.path.isfile(os.path.join(CSRC, f))]
-    deps += [os.path.join(CSRC, "host", f) for f in sorted(os.listdir(os.path.join(CSRC, "host")))]
+    deps += [os.path.join(CSRC, sub, f) for sub in ("host", "lab") for f in sorted(os.listdir(os.path.join(CSRC, sub)))]
     deps.append(os.path.join(HERE, "..", "include", "cwsl_gpu.h"))
     for d in deps:
         h.update(os.path.basename(d).encode())

@@ -36,6 +36,9 @@
 
 #include "../../include/cwsl_gpu.h"
 #include "demod_kernels.hpp"
+#if CWSLG_LAB
+#include "lab/demod_lab_kernels.hpp"
+#endif
 #include "host_dsp.hpp"
 #include "handoff.hpp"
 #include "host/slot_clock.hpp"
@@ -668,70 +671,7 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     span_begin(c, no_split ? 5 : 0, &ea, &eb);
     bool launched = false;
 #if CWSLG_LAB
-    launched = true;
-    if (c->exact && c->demod_variant == 20) {      // CWSLG_DEMOD_VARIANT=20: the round-1 exact kernel, one output per thread (same bits)
-        c->demod_kernel_name = "demod_exact_kernel";
-        hipLaunchKernelGGL((demod_exact_kernel<D, kTile, kDemodThreads>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
-                           c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
-    } else if (c->exact && c->demod_variant == 21) {   // round 2's exact kernel (taps through broadcast vector loads)
-        c->demod_kernel_name = "demod_exact2_kernel";
-        hipLaunchKernelGGL((demod_exact2_kernel<D, kTileExact2, 128>), dim3((unsigned)(per_xcd * 8)), dim3(128), 0,
-                           c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
-    } else if (c->exact) {
-        launched = false;
-    } else if (c->demod_variant == 1 || c->demod_variant == 2) {
-        // persistent variants (measured alternatives): as many workgroups as are resident at once
-        int occ = 0;
-        const bool loop = c->demod_variant == 2;
-        hipError_t oe = loop ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, demod_kernel<D, kTile, kDemodThreads, 2>, kDemodThreads, 0)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, demod_kernel<D, kTile, kDemodThreads, 1>, kDemodThreads, 0);
-        if (oe != hipSuccess || occ < 1) occ = 3;
-        if (const char *v = std::getenv("CWSLG_PERSIST_WGS_PER_CU")) occ = std::max(1, std::atoi(v));
-        long long wgs = std::min<long long>((long long)c->cu_count * occ, per_xcd * 8);
-        wgs = (wgs + 7) / 8 * 8;
-        c->demod_kernel_name = loop ? "demod_kernel<persistent loop>" : "demod_kernel<persistent prefetch>";
-        if (loop)
-            hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, 2>), dim3((unsigned)wgs), dim3(kDemodThreads), 0,
-                               c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
-        else
-            hipLaunchKernelGGL((demod_kernel<D, kTile, kDemodThreads, 1>), dim3((unsigned)wgs), dim3(kDemodThreads), 0,
-                               c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
-    } else if (c->demod_variant >= 4 && c->demod_variant <= 7 && D == 16) {
-        // FIR on the matrix cores, one plane resident at a time; variant = workgroups per CU the registers are capped for
-        auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0, c->stream, (const ChanWork *)w->d,
-                               (const float *)c->d_taps[fs], tiles_x, (int)works.size());
-        };
-        c->demod_kernel_name = "demod_mfma1p_kernel";
-        if (c->demod_variant == 4) go(demod_mfma1p_kernel<kTile, kDemodThreads, 4>);
-        else if (c->demod_variant == 5) go(demod_mfma1p_kernel<kTile, kDemodThreads, 5>);
-        else if (c->demod_variant == 6) go(demod_mfma1p_kernel<kTile, kDemodThreads, 6>);
-        else go(demod_mfma1p_kernel<kTile, kDemodThreads, 7>);
-    } else if (small_tile) {
-        c->demod_kernel_name = "demod_kernel<16,192,256,0>";
-        if constexpr (D == 16)
-            hipLaunchKernelGGL((demod_kernel<16, 192, kDemodThreads, 0>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0,
-                               c->stream, (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
-    } else if (c->demod_variant == 8 && D == 16) {
-        // the dense product on the bf16 matrix cores at fp32 accuracy (three-way split operands)
-        c->demod_kernel_name = "demod_mfma_bf16_kernel";
-        hipLaunchKernelGGL((demod_mfma_bf16_kernel<kTile, kDemodThreads, 4>), dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0, c->stream,
-                           (const ChanWork *)w->d, (const float *)c->d_taps[fs], tiles_x, (int)works.size());
-    } else if (c->demod_variant >= 9 && c->demod_variant <= 14) {
-        auto go = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3((unsigned)(per_xcd * 8)), dim3(kDemodThreads), 0, c->stream, (const ChanWork *)w->d,
-                               (const float *)c->d_taps[fs], tiles_x, (int)works.size());
-        };
-        c->demod_kernel_name = "ring_probe_kernel";
-        if (c->demod_variant == 9) go(ring_probe_kernel<D, kTile, kDemodThreads, 0>);
-        else if (c->demod_variant == 10) go(ring_probe_kernel<D, kTile, kDemodThreads, 1>);
-        else if (c->demod_variant == 11) go(ring_probe_kernel<D, kTile, kDemodThreads, 2>);
-        else if (c->demod_variant == 12) go(ring_probe_kernel<D, kTile, kDemodThreads, 3>);
-        else if (c->demod_variant == 13) go(ring_probe_kernel<D, kTile, kDemodThreads, 4>);
-        else go(ring_probe_kernel<D, kTile, kDemodThreads, 5>);
-    } else {
-        launched = false;
-    }
+#include "lab/demod_lab_dispatch.inc"      // CWSLG_DEMOD_VARIANT: the measured alternatives (sets `launched`)
 #endif
     bool use_exact4 = D == 16;             // 192 kHz: the two-stream form, eight waves per tile image (demod_exact4_kernel); 96 / 48 kHz: exact3
 #if CWSLG_LAB
