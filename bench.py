@@ -206,32 +206,56 @@ def main():
     S = args.slots if args.slots > 0 else 4096
     ctx = P.Context(local_rank)
     rendezvous = None
-    builtin_failed = None
+    builtin_failed = builtin_failed_kind = None
     if world > 1:
         rendezvous = args.rendezvous
         if rendezvous == "auto":
             rendezvous = "builtin" if (args.dist_backend == "nccl" and not args.same_device) else "torch"
         if rendezvous == "builtin":
-            # the library's own RCCL communicator: rank 0 makes the ncclUniqueId, torch.distributed only carries its 128 bytes
+            # The library's own RCCL communicator, brought up in three steps that EVERY rank agrees on (over the process group torch already has)
+            # before the next one starts -- a rank must never sit alone inside a collective:
+            #   load    librccl opens on every rank (each makes an ncclUniqueId; rank 0's is the one that is used)
+            #   init    cwslg_rccl_init (ncclCommInitRank) returns on every rank
+            #   gather  one boundary of a mode group without channels: the 32-byte all-gather itself runs on the new communicator
+            # The first step that fails anywhere names the reason class (multi_gpu.builtin_failed_kind) and the run goes on with the
+            # torch.distributed callback rendezvous.
+            def agree(err):
+                ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 1:
+                    return None
+                why = [None] * world
+                dist.all_gather_object(why, ("rank %d: %s" % (rank, err)) if err else None)     # (the exception text is the library's cwslg_last_error)
+                return "; ".join(w for w in why if w)
+            err, uid = None, b""
             try:
-                box = [P.rccl_unique_id() if rank == 0 else b""]
-            except Exception as e:                  # noqa: BLE001 -- reported below, on every rank
-                box, builtin_failed = [b""], "rank 0: %s" % e
-            dist.broadcast_object_list(box, src=0)
-            if box[0]:
+                uid = P.rccl_unique_id()
+            except Exception as e:                  # noqa: BLE001 -- reported below, by every rank that saw one
+                err = str(e)
+            builtin_failed = agree(err)
+            builtin_failed_kind = "load" if builtin_failed else None
+            if not builtin_failed:
+                box = [uid if rank == 0 else b""]
+                dist.broadcast_object_list(box, src=0)
                 try:
                     ctx.rccl_init(box[0], rank, world)
                 except Exception as e:              # noqa: BLE001
-                    builtin_failed = "rank %d: %s" % (rank, e)
-            # every rank must end up on the SAME rendezvous: agree (over the process group torch already has) whether the communicator came up everywhere
-            ok = torch.tensor([0 if (builtin_failed or not box[0]) else 1], dtype=torch.int32, device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                why = [None] * world
-                dist.all_gather_object(why, builtin_failed)
-                builtin_failed = "; ".join(w for w in why if w) or "a rank could not make the ncclUniqueId"
-                print(f"bench.py rank {rank}: the built-in RCCL rendezvous did not come up ({builtin_failed}): this run uses the torch.distributed "
-                      f"callback rendezvous instead -- the record says so (multi_gpu.rendezvous / builtin_failed)", file=sys.stderr)
+                    err = str(e)
+                builtin_failed = agree(err)
+                builtin_failed_kind = "init" if builtin_failed else None
+            if not builtin_failed:
+                try:
+                    ctx.slot_boundary("FT4", 0)     # no FT4 channel exists: nothing is finalised, the rendezvous runs with 0 frames
+                    assert ctx.stats()["rendezvous_frames"] == 0 and ctx.stats()["rccl_world"] == world
+                except Exception as e:              # noqa: BLE001
+                    err = str(e) or repr(e)
+                builtin_failed = agree(err)
+                builtin_failed_kind = "gather" if builtin_failed else None
+            if builtin_failed:
+                if rank == 0:
+                    print(f"bench.py: the built-in RCCL rendezvous did not come up [{builtin_failed_kind}] -- {builtin_failed}\n"
+                          f"bench.py: this run uses the torch.distributed callback rendezvous instead; the record says so (multi_gpu.rendezvous / "
+                          f"builtin_failed / builtin_failed_kind).  Re-run with NCCL_DEBUG=WARN for RCCL's own account.", file=sys.stderr)
                 rendezvous = "torch"
         if rendezvous != "builtin":
             shard.install_rendezvous(ctx, dev)  # cwslg_slot_boundary[_end] ends in torch.distributed's all-reduce (callback form)
@@ -550,7 +574,7 @@ def main():
                                     f"cwslg_slot_boundary_end (torch.distributed)") if world > 1 else "single GPU"},
             "mode": rec["mode"],
             "realtime_ft8_slots": rec["value"] / 0.192,
-            "multi_gpu": None if world == 1 else {"rendezvous": rendezvous, "builtin_failed": builtin_failed, "rccl_world": int(st.get("rccl_world", 0)),
+            "multi_gpu": None if world == 1 else {"rendezvous": rendezvous, "builtin_failed": builtin_failed, "builtin_failed_kind": builtin_failed_kind, "rccl_world": int(st.get("rccl_world", 0)),
                                                   "rendezvous_calls": int(st["rendezvous_calls"]), "rendezvous_frames": int(st["rendezvous_frames"]),
                                                   "rank_ms_per_step_min": min(st["rank_ms_per_step"]), "rank_ms_per_step_max": max(st["rank_ms_per_step"])},
             "roofline": rec["roofline"],

@@ -125,6 +125,40 @@ def test_builtin_rccl_rendezvous_world_1():
         assert first2 == 0 and st2["rendezvous_calls"] == 2 and st2["rendezvous_frames"] == 3 and crcs2 == crcs
 
 
+def test_builtin_rccl_communicator_life_cycle_world_1():
+    """What the driver's first real N = 8 run will lean on, as far as one GPU can show it: cwslg_rccl_init brings a communicator up, 100 boundaries
+    each run their all-gather on it (rendezvous_frames == the frames this -- only -- rank emitted, every time), a second cwslg_rccl_init on the same
+    context replaces the communicator, cwslg_destroy releases it, and a fresh context can do all of it again (five times: a leaked
+    communicator or staging buffer per cycle would show as a failure to create the next one or as growing device memory)."""
+    import cwsl_digi_amd as P
+    import torch
+    free0 = None
+    for cycle in range(5):
+        with P.Context(0) as ctx:
+            ctx.rccl_init(P.rccl_unique_id(), 0, 1)
+            if cycle == 0:
+                ctx.rccl_init(P.rccl_unique_id(), 0, 1)            # re-initialisation on a live context: the old communicator is destroyed first
+            rx = ctx.receiver_open(192000, 2048, 0)
+            chans = [ctx.channel_open(rx, -30000 + 9000 * k, "FT8") for k in range(4)]
+            blk = np.zeros(2048, np.complex64)
+            ctx.slot_boundary("FT8", 1)                            # the first, partial slot: discarded, 0 frames through the rendezvous
+            assert ctx.stats()["rendezvous_frames"] == 0
+            for e in range(2, 102):
+                ctx.push_iq(rx, blk)
+                ctx.slot_boundary("FT8", e)
+                st = ctx.stats()
+                assert st["rendezvous_frames"] == len(chans) and st["rccl_world"] == 1, (e, st)
+            st = ctx.stats()
+            assert st["rendezvous_calls"] == 101 and st["frames_emitted"] == 100 * len(chans)
+            ctx.slot_boundary("FT4", 7)                            # a group without channels: the rendezvous still runs (bench.py's probe)
+            assert ctx.stats()["rendezvous_calls"] == 102 and ctx.stats()["rendezvous_frames"] == 0
+        free, _ = torch.cuda.mem_get_info(0)
+        if cycle == 1:
+            free0 = free
+        if cycle == 4:
+            assert free >= free0 - (64 << 20), (free0, free)       # nothing accumulates from cycle to cycle
+
+
 def test_bench_py_gpus_2_launches_two_ranks_on_this_gpu():
     """The driver's N > 1 entry, end to end through bench.py itself: `python bench.py --gpus 2 ...` from a plain shell launches two ranks
     (torch.distributed.run, 127.0.0.1), each owns a real Context on the one GPU of the box (--same-device; gloo carries the rendezvous
@@ -160,5 +194,6 @@ def test_bench_py_falls_back_loudly_when_the_builtin_communicator_cannot_come_up
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     mg = line["multi_gpu"]
     assert line["n_gpus"] == 2 and mg["rendezvous"] == "torch" and mg["builtin_failed"], mg
+    assert mg["builtin_failed_kind"] == "init" and "rank 0" in mg["builtin_failed"] and "rank 1" in mg["builtin_failed"], mg   # every rank's own account
     assert mg["rendezvous_calls"] == 2 and mg["rendezvous_frames"] == 128
-    assert "did not come up" in p.stderr
+    assert "did not come up [init]" in p.stderr and "NCCL_DEBUG=WARN" in p.stderr
