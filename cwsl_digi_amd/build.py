@@ -15,8 +15,10 @@ LIB = os.path.join(LIBDIR, "libcwslgpu.so")
 # The product library above carries one kernel per job and reads no such switch.
 LAB_LIB = os.path.join(LIBDIR, "libcwslgpu_lab.so")
 BINDIR = os.path.join(HERE, "bin")
-SKIMMER = os.path.join(BINDIR, "cwsl_gpu_skimmer")
-REALTIME = os.path.join(BINDIR, "cwsl_gpu_realtime")
+# (CWSLG_SKIMMER_BIN / CWSLG_REALTIME_BIN: other builds of the two host programs for the tests that drive them -- the ThreadSanitizer builds of
+# scripts/gpu_r5_tsan.sh; test tooling only, the programs themselves read no such variable)
+SKIMMER = os.environ.get("CWSLG_SKIMMER_BIN") or os.path.join(BINDIR, "cwsl_gpu_skimmer")
+REALTIME = os.environ.get("CWSLG_REALTIME_BIN") or os.path.join(BINDIR, "cwsl_gpu_realtime")
 
 # -ffp-contract=off: every fused multiply-add in the kernels is an explicit __builtin_fmaf and every
 # bit-exact sequence (the float32 phasor recurrence, prepareAudio, the synthetic source) is plain * and +.
@@ -98,6 +100,8 @@ def build(force=False, verbose=False):
 def build_skimmer(force=False, verbose=False):
     """Compile the Linux host programs (plain C++17 over the C ABI): csrc/host/skimmer_main.cpp -> bin/cwsl_gpu_skimmer and
     csrc/host/realtime_main.cpp -> bin/cwsl_gpu_realtime (the wall-clock-paced ingest harness)."""
+    if os.environ.get("CWSLG_SKIMMER_BIN") or os.environ.get("CWSLG_REALTIME_BIN"):
+        return SKIMMER
     newest = max(os.path.getmtime(os.path.join(CSRC, "host", f)) for f in os.listdir(os.path.join(CSRC, "host")))
     if not force and all(os.path.isfile(b) and os.path.getmtime(b) >= newest for b in (SKIMMER, REALTIME)):
         return SKIMMER
