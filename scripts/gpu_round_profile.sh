@@ -16,6 +16,7 @@ run sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_
 run tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
 cd $R
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
+rm -rf $O/stats
 python3 - <<'PY'
 import csv,glob,collections,json,os
 O=os.path.join(os.environ['GRAFT_REPO_ROOT'],'gpurun_out','round')
@@ -36,4 +37,5 @@ with open(O+'/pmc_summary.txt','w') as fh:
         for c in sorted(tot[k]): fh.write('    %-26s %.6g\n'%(c,tot[k][c]))
 print(open(O+'/pmc_summary.txt').read())
 PY
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2 $O/pmc_tcc      # (the raw traces exceed what gpurun copies back; the summary is what is kept)
 tail -c 2500 $O/bench_default.json
