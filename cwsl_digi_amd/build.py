@@ -29,6 +29,11 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17"
                "-fno-slp-vectorize"]
 
 
+# CWSLG_HIPCC_EXTRA: extra compiler flags for a measurement build (-D switches of the A/B scripts); part of the source hash, so the library is rebuilt
+import shlex
+HIPCC_FLAGS += shlex.split(os.environ.get("CWSLG_HIPCC_EXTRA", ""))
+
+
 def sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hip")]
 

@@ -498,6 +498,23 @@ __device__ __forceinline__ void spectra_stage1_regs(const float2 (&z)[AMAX], flo
 #ifndef CWSLG_SPEC_WAVES
 #define CWSLG_SPEC_WAVES 4
 #endif
+// The spectra plane (6 GB per 4096-slot boundary) is written once by symbol_spectra_v2_kernel and read once by the search: CWSLG_PLANE_NT selects
+// non-temporal stores (bit 0) / loads (bit 1) for it (round 5 A/B: scripts/gpu_r5_plane_nt.sh).
+#ifndef CWSLG_PLANE_NT
+#define CWSLG_PLANE_NT 0
+#endif
+__device__ __forceinline__ void plane_store(CWSLG_GLOBAL v4f *p, v4f v)
+{
+    if (CWSLG_PLANE_NT & 1) __builtin_nontemporal_store(v, p); else *p = v;
+}
+__device__ __forceinline__ v4f plane_load4(const CWSLG_GLOBAL v4f *p)
+{
+    return (CWSLG_PLANE_NT & 2) ? __builtin_nontemporal_load(p) : *p;
+}
+__device__ __forceinline__ float plane_load1(const CWSLG_GLOBAL float *p)
+{
+    return (CWSLG_PLANE_NT & 2) ? __builtin_nontemporal_load(p) : *p;
+}
 // Symbol steps per workgroup of symbol_spectra_v2_kernel (a kernel argument).  A workgroup's prologue -- twiddles, 24 LDS addresses, the first window's
 // memory latency -- is paid once per `jper` transforms: same-box at 4096 slots 4.31 ms with 12 steps (31 workgroups per channel), 4.20 with 31, 4.18 with 62;
 // few channels need the short form to fill the chip (four workgroups per CU).
@@ -654,8 +671,8 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         CWSLG_GLOBAL v4f *out4 = reinterpret_cast<CWSLG_GLOBAL v4f *>(as_global_rw(w->spectra) + (size_t)(j - 1) * nbins);
         // by waves 2-3 only when stage 1 is the prime-factor form: their half of it is 32 instructions shorter than waves 0-1's (stamps: they
         // waited ~430 cycles at the barrier behind stage 1)
-        if (NA == 15) { if (tid >= 128) for (int k4 = tid - 128; 4 * k4 < nbins; k4 += 128) out4[k4] = *reinterpret_cast<const v4f *>(s_pw + 4 * k4); }
-        else for (int k4 = tid; 4 * k4 < nbins; k4 += 256) out4[k4] = *reinterpret_cast<const v4f *>(s_pw + 4 * k4);
+        if (NA == 15) { if (tid >= 128) for (int k4 = tid - 128; 4 * k4 < nbins; k4 += 128) plane_store(out4 + k4, *reinterpret_cast<const v4f *>(s_pw + 4 * k4)); }
+        else for (int k4 = tid; 4 * k4 < nbins; k4 += 256) plane_store(out4 + k4, *reinterpret_cast<const v4f *>(s_pw + 4 * k4));
     }
     if (j + 1 < jend) {                                   // wave-uniform: the next step's window, in flight during this transform
 #pragma unroll
@@ -766,7 +783,7 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     }   // next symbol step: s_y is rewritten after this barrier, s_pw only after four more
     if (jend > j0) {
         CWSLG_GLOBAL v4f *out4 = reinterpret_cast<CWSLG_GLOBAL v4f *>(as_global_rw(w->spectra) + (size_t)(jend - 1) * nbins);
-        for (int k4 = tid_; 4 * k4 < nbins; k4 += 256) out4[k4] = *reinterpret_cast<const v4f *>(s_pw + 4 * k4);
+        for (int k4 = tid_; 4 * k4 < nbins; k4 += 256) plane_store(out4 + k4, *reinterpret_cast<const v4f *>(s_pw + 4 * k4));
     }
 }
 
@@ -1235,7 +1252,7 @@ __global__ __launch_bounds__(SYNC2D_NT, 4) void ft8_sync2d_v3_kernel(const SyncW
 #pragma unroll
         for (int q = 0; q < UN; ++q) {
             const int m = wv + NW * q;
-            v[q] = (on && m < FT8_NHSYM) ? sp[(size_t)m * nbins] : 0.0f;
+            v[q] = (on && m < FT8_NHSYM) ? plane_load1(sp + (size_t)m * nbins) : 0.0f;
         }
         float *dst = &s_s[lane < ROWS ? lane : 0][S2_COL0 + 1 + wv];
 #pragma unroll
@@ -1559,7 +1576,7 @@ __global__ __launch_bounds__(SYNCC_NT, 4) void ft8_sync_chan_kernel(const SyncWo
 #pragma unroll
         for (int q = 0; q < UN; ++q) {
             const int m = wv + NW * q;
-            v[q] = (on && m < FT8_NHSYM) ? sp[(size_t)m * nbins] : 0.0f;
+            v[q] = (on && m < FT8_NHSYM) ? plane_load1(sp + (size_t)m * nbins) : 0.0f;
         }
         float *dst = &s_s[lane < ROWS ? lane : 0][S2_COL0 + 1 + wv];
 #pragma unroll
@@ -1591,7 +1608,7 @@ __global__ __launch_bounds__(SYNCC_NT, 4) void ft8_sync_chan_kernel(const SyncWo
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
                 const int m = 8 * (wv + NW * q) + s8;
-                pf[q] = (on && m < FT8_NHSYM) ? *reinterpret_cast<const CWSLG_GLOBAL v4f *>(spec + o0 + (unsigned)q * ostep) : v4f{0.f, 0.f, 0.f, 0.f};
+                pf[q] = (on && m < FT8_NHSYM) ? plane_load4(reinterpret_cast<const CWSLG_GLOBAL v4f *>(spec + o0 + (unsigned)q * ostep)) : v4f{0.f, 0.f, 0.f, 0.f};
             }
         }
         if (band == 1) SSTAMP1(1);
