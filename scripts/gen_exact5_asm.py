@@ -39,7 +39,9 @@ NPIM, P, STG, OB, PEAK, T = 193, 194, 196, 212, 216, 217           # P = (re, im
 VTOP = 225
 import os
 LOADER_IN_GAP = os.environ.get("X5_LOADER_IN_GAP", "1") == "1"
-RING_NT = " nt" if os.environ.get("X5_RING_NT", "1") == "1" else ""    # the ring is read once: non-temporal (same-box A/B: 2.5-2.8 % of the launch)
+# the ring is read once: non-temporal (same-box A/B: 2.5-2.8 % of the launch).  X5_RING_NT: "0" none, "1" nt, or the modifiers themselves ("sc1 nt", ...)
+_nt = os.environ.get("X5_RING_NT", "1")
+RING_NT = "" if _nt == "0" else (" nt" if _nt == "1" else " " + _nt.replace("_", " ").strip())
 STG2 = 240                                                         # the second staging set, at the top of the file (the operands sit between VTOP and it)
 ROW = 144                                                          # LDS row pitch: 16 samples + 16 bytes (conflict-free 16-byte reads, lane = row)
 BUF = 32 * ROW                                                     # one tile of one wave: 4608 bytes; two buffers

@@ -141,7 +141,7 @@ class Wave:
             op, _, rest = l.partition(" ")
             self.count[op] = self.count.get(op, 0) + 1
             off = 0
-            rest = re.sub(r"\s+nt$", "", rest)
+            rest = re.sub(r"(\s+(nt|sc0|sc1))+$", "", rest)
             m = re.search(r"\s+offset:(\d+)", rest)
             if m:
                 off = int(m.group(1))
