@@ -268,7 +268,7 @@ struct cwslg_ctx {
     // one workgroup's life (demod_exact3_kernel's `clk`), read back by drain_spans
     unsigned long long *clk_h = nullptr, *clk_dev = nullptr;
     unsigned clk_head = 0, clk_tail = 0;
-    unsigned exact5_seg_cap = kExact5SegCap;
+    unsigned exact5_seg_cap = kExact5SegCap, exact5_seg_force = 0;
     bool use_exact5 = true;            // 192 kHz exact mode: demod_exact5_kernel (lab build: CWSLG_DEMOD_VARIANT=27 keeps demod_exact4_kernel for A/B)
     unsigned stat_gen = 0;             // bumped by cwslg_reset_stats: work timed before a reset is not folded into the figures read after it
     double clk_sum_mhz = 0.0;
@@ -590,6 +590,7 @@ int launch_exact5(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max
     const uint64_t waves_min = (uint64_t)c->cu_count * 8 * 2;
     unsigned seg = (unsigned)std::min<uint64_t>(c->exact5_seg_cap, (total_blocks + 32 * waves_min - 1) / (32 * waves_min));
     seg = std::max(4u, (seg + 3) / 4 * 4);
+    if (c->exact5_seg_force) seg = c->exact5_seg_force;
     const int chunks = (int)((max_blocks + 32 * seg - 1) / (32 * seg));
     WorkBuf *w = acquire_workbuf(c, works.size() * sizeof(ChanWork));
     if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
@@ -1145,7 +1146,8 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
     // changes a kernel or the order of its arithmetic.
     if (const char *v = std::getenv("CWSLG_DEMOD_VARIANT")) c->demod_variant = std::atoi(v);
     if (c->demod_variant != 0) c->use_exact5 = false;          // every measured alternative is an alternative to round 4's launch shape (27: exact4 itself, for A/B)
-    if (const char *v = std::getenv("CWSLG_EXACT5_SEG")) c->exact5_seg_cap = (unsigned)std::max(4, std::atoi(v));
+    if (const char *v = std::getenv("CWSLG_EXACT5_SEG")) c->exact5_seg_cap = (unsigned)std::max(4, std::atoi(v));        // at most this many outputs per stream
+    if (const char *v = std::getenv("CWSLG_EXACT5_SEG_FORCE")) c->exact5_seg_force = (unsigned)std::max(4, std::atoi(v)) / 4 * 4;   // exactly this many (tests)
     if (const char *v = std::getenv("CWSLG_UPLOAD")) c->upload_by_dma = std::strcmp(v, "dma") == 0;
     if (const char *v = std::getenv("CWSLG_FT4_DFT")) c->ft4_dft_valu = std::strcmp(v, "valu") == 0;
     if (const char *v = std::getenv("CWSLG_ITEM_ORDER")) c->order_override = std::atoi(v);

@@ -109,7 +109,7 @@ def test_product_library_has_one_kernel_per_job_and_no_lab_switches():
     B.build()
     prod, lab = open(B.LIB, "rb").read(), open(B.LAB_LIB, "rb").read()
     for switch in (b"CWSLG_DEMOD_VARIANT", b"CWSLG_SYNC_VARIANT", b"CWSLG_LONG_VARIANT", b"CWSLG_FT4_DFT", b"CWSLG_ITEM_ORDER",
-                   b"CWSLG_UPLOAD", b"CWSLG_COPY_ON_MAIN", b"CWSLG_PERSIST_WGS_PER_CU", b"CWSLG_EXACT5_SEG"):
+                   b"CWSLG_UPLOAD", b"CWSLG_COPY_ON_MAIN", b"CWSLG_PERSIST_WGS_PER_CU", b"CWSLG_EXACT5_SEG", b"CWSLG_EXACT5_SEG_FORCE"):
         assert switch not in prod, switch
         assert switch in lab, switch
     kp, kl = _kernel_names(B.LIB), _kernel_names(B.LAB_LIB)

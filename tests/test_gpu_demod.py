@@ -281,11 +281,24 @@ def test_wav_file_is_the_reference_container(ctx, oracle, tmp_path):
     assert np.array_equal(np.frombuffer(raw[46:], np.int16), fr)
 
 
-@pytest.mark.parametrize("variant,mode", [("7", "fast"), ("8", "fast"), ("2", "fast"), ("20", "exact"), ("21", "exact"), ("23", "exact"), ("24", "exact")])
+@pytest.mark.parametrize("seg", ["4", "12", "36", "100", "360", "1408"])
+def test_exact5_stream_lengths(seg):
+    """demod_exact5_kernel cuts a channel's pending outputs into waves of 32 streams x seg_len outputs; the launch picks seg_len from the amount of
+    work.  Here it is forced (lab library: CWSLG_EXACT5_SEG_FORCE) through short, ragged and whole-slot values on the same 11 520-output slot of
+    four channels: 90 / 30 / 10 / 4 / 1 / 1 waves per channel, the last one partly or mostly idle -- every frame must keep the reference's bits."""
+    import os, subprocess, sys
+    env = dict(os.environ, CWSLG_LIB="lab", CWSLG_EXACT5_SEG_FORCE=seg)
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "lab_variant_check.py"), "exact"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "lab check OK: demod_exact5_kernel" in r.stdout
+
+
+@pytest.mark.parametrize("variant,mode", [("7", "fast"), ("8", "fast"), ("2", "fast"), ("20", "exact"), ("21", "exact"), ("23", "exact"), ("24", "exact"), ("27", "exact")])
 def test_measured_alternative_kernels_live_in_the_lab_library(variant, mode):
     """The measured alternatives of the demod kernels (CWSLG_DEMOD_VARIANT: 7 = FIR on the f32 matrix cores, 8 = on the bf16 matrix
     cores with three-way split operands, 2 = persistent workgroups; exact mode: 20 / 21 = round 1's and round 2's kernels, 23 / 24 =
-    demod_exact3_kernel with two-wave and one-wave workgroups) exist in libcwslgpu_lab.so only -- the product library has one kernel
+    demod_exact3_kernel with two-wave and one-wave workgroups, 27 = round 4's demod_exact4_kernel for every output) exist in libcwslgpu_lab.so only -- the product library has one kernel
     per job and reads no such switch -- and obey the mode's bound: 1e-5 of frame peak (fast), identical bits (exact).  Run in a
     child process: the library is chosen when the package is imported."""
     import os, subprocess, sys
