@@ -39,6 +39,7 @@ NPIM, P, STG, OB, PEAK, T = 193, 194, 196, 212, 216, 217           # P = (re, im
 VTOP = 225
 import os
 LOADER_IN_GAP = os.environ.get("X5_LOADER_IN_GAP", "1") == "1"
+GROUPED = os.environ.get("X5_GROUPED", "1") == "1"            # mix and sum * phase as groups of independent instructions (0: the first form's short dependent chains)
 # the ring is read once: non-temporal (same-box A/B: 2.5-2.8 % of the launch).  X5_RING_NT: "0" none, "1" nt, or the modifiers themselves ("sc1 nt", ...)
 _nt = os.environ.get("X5_RING_NT", "1")
 RING_NT = "" if _nt == "0" else (" nt" if _nt == "1" else " " + _nt.replace("_", " ").strip())
@@ -58,8 +59,20 @@ def adds(src):
 
 
 def mix(m):
-    mm, t = m & 7, T + 2 * (m & 1)
+    mm, t = m & 7, T + 2 * (m & 3)
     return [f"v_mul_f32 v{t}, v{IN + 2 * mm}, v{C1 + m}", f"v_mul_f32 v{t + 1}, v{IN + 2 * mm + 1}, v{C2 + m}", f"v_add_f32 v{Y + m}, v{t}, v{t + 1}"]
+
+
+def mix_group(ms):
+    """Four samples at a time, the eight products first: no instruction waits for the one just before it (a wave issues a dependent VALU
+    instruction later than an independent one; its partner wave fills only some of those slots)."""
+    out = []
+    if not GROUPED:
+        return [x for m in ms for x in mix(m)]
+    for g in range(0, len(ms), 4):
+        grp = [mix(m) for m in ms[g:g + 4]]
+        out += [x for tri in grp for x in tri[:2]] + [tri[2] for tri in grp]
+    return out
 
 
 def lds_read(buf, half):
@@ -86,14 +99,23 @@ def advance_offsets():
 
 
 def t_and_w(u):
-    """sum * phase, the component the output will read, and the workspace chain (descending r: every add reads the slot's previous occupant)."""
+    """sum * phase, the component the output will read, and the workspace chain (descending r: every add reads the slot's previous occupant).
+    The 32 products go to the product buffer DB, the 16 terms to DA -- both are free between the last sums of a tile and the next tile's MFMA 1 --
+    so that every group is 16 or 32 independent instructions."""
     out = []
-    for r in range(15, -1, -1):
+    if not GROUPED:
+        for r in range(15, -1, -1):
+            k1, k2 = (P, NPIM) if (u + r) & 1 else (P + 1, P)
+            t = T + 3 * (r & 1)
+            out += [f"v_mul_f32 v{t}, v{S + r}, v{k1}", f"v_mul_f32 v{t + 1}, v{S + 16 + r}, v{k2}", f"v_add_f32 v{t + 2}, v{t}, v{t + 1}",
+                    f"v_add_f32 v{W + r + 1}, v{W + r}, v{t + 2}"]
+        return out + [f"v_mov_b32 v{W}, 0"]
+    for r in range(16):
         re_type = (u + r) & 1                                       # output b = q + 31 - n is even: Re(sum * phase) = S.re p.re - S.im p.im
         k1, k2 = (P, NPIM) if re_type else (P + 1, P)               # odd: Im = S.re p.im + S.im p.re
-        t = T + 3 * (r & 1)
-        out += [f"v_mul_f32 v{t}, v{S + r}, v{k1}", f"v_mul_f32 v{t + 1}, v{S + 16 + r}, v{k2}", f"v_add_f32 v{t + 2}, v{t}, v{t + 1}",
-                f"v_add_f32 v{W + r + 1}, v{W + r}, v{t + 2}"]
+        out += [f"v_mul_f32 v{DB + r}, v{S + r}, v{k1}", f"v_mul_f32 v{DB + 16 + r}, v{S + 16 + r}, v{k2}"]
+    out += [f"v_add_f32 v{DA + r}, v{DB + r}, v{DB + 16 + r}" for r in range(16)]
+    out += [f"v_add_f32 v{W + r + 1}, v{W + r}, v{DA + r}" for r in range(15, -1, -1)]
     # the lower half's partial (tap blocks 0..15 done) becomes the upper half's W[0]; the lower half starts a fresh slot (+0)
     out += [f"v_mov_b32 v{W}, 0"]
     return out
@@ -116,8 +138,7 @@ def tile(u):
     two outstanding sets: vmcnt(4)), move them to LDS buffer (t + 1) & 1, and request tile t + 3 into the staging set that this freed."""
     buf = u & 1
     L = ["s_waitcnt lgkmcnt(0)"]                                    # samples 0..7 of this tile (read at the end of the previous one)
-    for m in range(8):
-        L += mix(m)
+    L += mix_group(list(range(8)))
     L += lds_read(buf, 1)                                           # samples 8..15 into the same registers
     loader = ["s_waitcnt vmcnt(4)"]                                 # the NEXT tile's rows have arrived from the ring ...
     loader += lds_write(u + 1)                                      # ... transposed through LDS ...
@@ -140,8 +161,7 @@ def tile(u):
             L += adds(where[m - 1])
         if m == 5:                                                  # samples 8..15 have long landed: mix them before MFMA 8 needs y[8]
             L += ["s_waitcnt lgkmcnt(0)"]
-            for mm in range(8, 16):
-                L += mix(mm)
+            L += mix_group(list(range(8, 16)))
             L += lds_read(buf ^ 1, 0)                               # the next tile's samples 0..7
     L += adds(where[15])
     L += t_and_w(u)
