@@ -582,6 +582,7 @@ int restore_open_tuning(cwslg_ctx *c, Channel &ch, const Receiver &rx)
 
 // demod_exact5_kernel (192 kHz, exact mode): one wave per (channel, chunk of 32 streams x seg_len outputs).  seg_len trades the 32-block warm-up
 // of every stream (32 / seg_len of extra work) against waves to fill the chip with: at least two rounds of resident waves where the work allows.
+template <int D>
 int launch_exact5(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_blocks, uint32_t fs, bool chunk_major)
 {
     if (works.empty()) return CWSLG_OK;
@@ -599,14 +600,14 @@ int launch_exact5(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max
     const long long items = (long long)chunks * (long long)works.size();
     hipEvent_t ea, eb;
     span_begin(c, 0, &ea, &eb);
-    c->demod_kernel_name = "demod_exact5_kernel";
+    c->demod_kernel_name = D == 16 ? "demod_exact5_kernel<16>" : D == 8 ? "demod_exact5_kernel<8>" : "demod_exact5_kernel<4>";
     unsigned long long *clk = nullptr;
     if (c->timing && c->clk_dev && c->clk_head - c->clk_tail < kClkSlots) {
         const unsigned slot = c->clk_head++ % kClkSlots;
         std::memset(c->clk_h + 4 * slot, 0, 4 * sizeof(unsigned long long));
         clk = c->clk_dev + 4 * slot;
     }
-    hipLaunchKernelGGL(demod_exact5_kernel, dim3((unsigned)((items + kExact5Waves - 1) / kExact5Waves)), dim3(64 * kExact5Waves), 0, c->stream,
+    hipLaunchKernelGGL(demod_exact5_kernel<D>, dim3((unsigned)((items + kExact5Waves - 1) / kExact5Waves)), dim3(64 * kExact5Waves), 0, c->stream,
                        (const ChanWork *)w->d, (const float *)c->d_taps[fs], chunk_major ? -chunks : chunks, (int)works.size(), (int)seg, clk);
     span_end(c, eb);
     HIPCHK(c, hipGetLastError());
@@ -620,14 +621,14 @@ template <int D>
 int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_blocks, uint32_t fs, bool tile_major, bool no_split = false)
 {
     if (works.empty()) return CWSLG_OK;
-    if (D == 16 && c->exact && c->use_exact5 && !no_split) {
-        // 192 kHz, exact mode: demod_exact5_kernel takes every output whose 32-block history exists (q_first >= 32); the first 32 outputs of a
-        // fresh demodulator -- and any work that does not meet its alignment rules -- go through demod_exact4_kernel
+    if (c->exact && c->use_exact5 && !no_split) {
+        // exact mode: demod_exact5_kernel<D> takes every output whose 32-block history exists (q_first >= 32); the first 32 outputs of a fresh
+        // demodulator -- and any work that does not meet its alignment rules -- go through demod_exact4_kernel (192 kHz) / demod_exact3_kernel
         std::vector<ChanWork> head, rest;
         unsigned max_head = 0, max_rest = 0;
         for (const ChanWork &w0 : works) {
             ChanWork w = w0;
-            const bool aligned = w.q_first % 4 == 0 && w.n_blocks % 4 == 0 && w.lo_mod % 64 == 0 && w.ring_cap % 64 == 0 && (uint64_t)w.ring_cap * 8 < (1ull << 32);
+            const bool aligned = w.q_first % 4 == 0 && w.n_blocks % 4 == 0 && w.lo_mod % (4 * D) == 0 && w.ring_cap % (4 * D) == 0 && (uint64_t)w.ring_cap * 8 < (1ull << 32);
             unsigned n_head = !aligned ? w.n_blocks : (w.q_first < 32 ? (unsigned)std::min<long long>(w.n_blocks, 32 - w.q_first) : 0u);
             if (n_head) {
                 ChanWork h = w;
@@ -643,7 +644,7 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
         }
         int rc = launch_demod<D>(c, head, max_head, fs, tile_major, true);
         if (rc) return rc;
-        return launch_exact5(c, rest, max_rest, fs, tile_major);
+        return launch_exact5<D>(c, rest, max_rest, fs, tile_major);
     }
     // the descriptors, then (64-byte aligned) the eight per-XCD work counters of demod_exact3_kernel, zero at launch
     const size_t ctr_off = (works.size() * sizeof(ChanWork) + 63) & ~size_t(63);

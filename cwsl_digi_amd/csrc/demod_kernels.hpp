@@ -1512,7 +1512,7 @@ __global__ __launch_bounds__(NT, 4) void demod_exact4_kernel(const ChanWork *__r
 }
 
 // ---------------------------------------------------------------------------------------------
-// demod_exact5_kernel (192 kHz; round 5): the reference's arithmetic with LANE = STREAM -- a wave serves 32 consecutive segments of seg_len
+// demod_exact5_kernel<D> (192 / 96 / 48 kHz: D = 16 / 8 / 4 samples per block; round 5): the reference's arithmetic with LANE = STREAM -- a wave serves 32 consecutive segments of seg_len
 // outputs of ONE channel, time runs along the lane, and everything a stream needs between two tiles (its 16 samples, the 32 x 2 running sums,
 // the workspace chain, its mixer phase) stays in registers.  The un-fused products fl(y * h) (SSBD.hpp:167-168) of a block against all 32 tap
 // blocks are ONE K = 1 matrix instruction per sample (v_mfma_f32_32x32x1_2b_f32, C = 0: bit-identical to v_mul_f32, scripts/micro/mfma_k1.hip);
@@ -1524,12 +1524,16 @@ __global__ __launch_bounds__(NT, 4) void demod_exact4_kernel(const ChanWork *__r
 //   rows are its own: the 32 x 128 bytes of a tile are loaded coalesced -- eight lanes per 128-byte line -- and read back lane = stream).
 //   A stream starts 32 blocks before its first output (the workspace needs an output's 32 blocks); the host therefore hands this kernel only
 //   work whose 32-block history exists: q_first >= 32 (the first 32 outputs of a fresh demodulator go through demod_exact4_kernel).
-//   Requires q_first, n_blocks, seg_len multiples of 4, lo_mod a multiple of 64 samples and the ring shorter than 4 GiB (host-checked).
+//   Requires q_first, n_blocks, seg_len multiples of 4, lo_mod and the ring's length multiples of 4 D samples (the push granularity) and the ring
+//   shorter than 4 GiB (host-checked).  At 96 / 48 kHz a block is 64 / 32 bytes: the wave still moves 128-byte rows (two / four tiles per row).
 #include "exact5_asm.inc"
 constexpr int kExact5Waves = 4;
+template <int D>
 __global__ __launch_bounds__(64 * kExact5Waves, 2) void demod_exact5_kernel(const ChanWork *__restrict__ works, const float *__restrict__ taps, int chunks_x,
                                                                               int n_ch, int seg_len, unsigned long long *__restrict__ clk)
 {
+    static_assert(D == 16 || D == 8 || D == 4, "192 / 96 / 48 kHz");
+    constexpr int TILES = D == 16 ? EXACT5_D16_TILES_PER_ITER : D == 8 ? EXACT5_D8_TILES_PER_ITER : EXACT5_D4_TILES_PER_ITER;
     __shared__ __attribute__((aligned(16))) unsigned char s_rows[kExact5Waves * 2 * EXACT5_ASM_BUF_BYTES];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int item = (int)blockIdx.x * kExact5Waves + wv;
@@ -1546,7 +1550,7 @@ __global__ __launch_bounds__(64 * kExact5Waves, 2) void demod_exact5_kernel(cons
     const unsigned most = (unsigned)min((long long)seg_len, (long long)n_blocks - first_seg * seg_len);   // outputs of the wave's first (fullest) stream
     // ring byte offset of the first sample of stream s (its 32-block warm-up included): lo_mod + 16 (first output - 32), modulo the ring
     auto stream_pos = [&](int s) -> unsigned {
-        long long rel = ((first_seg + s) * (long long)seg_len - 32) * 16 + (long long)lo_mod;
+        long long rel = ((first_seg + s) * (long long)seg_len - 32) * D + (long long)lo_mod;
         rel %= (long long)cap;
         if (rel < 0) rel += cap;
         return (unsigned)rel * 8u;
@@ -1564,7 +1568,7 @@ __global__ __launch_bounds__(64 * kExact5Waves, 2) void demod_exact5_kernel(cons
     unsigned outoff = (unsigned)my_first * 4u;
     // the matrix instruction's row i (operand lane i & 31) lands in the half (i >> 2) & 1, register (i & 3) + 4 (i >> 3): give row i tap block
     // n = register + 16 half, so that a lane of the lower half holds tap blocks 0..15 in register order and the upper half 16..31
-    const unsigned tapoff = (unsigned)((j & 3) + 4 * (j >> 3) + 16 * ((j >> 2) & 1)) * 64u;
+    const unsigned tapoff = (unsigned)((j & 3) + 4 * (j >> 3) + 16 * ((j >> 2) & 1)) * (unsigned)(4 * D);
     const float sign = __uint_as_float(uni(__float_as_uint(cw->sign)));
     const float nsign = -sign;
     const float incre = __uint_as_float(uni(__float_as_uint(cw->inc.x))), incim = __uint_as_float(uni(__float_as_uint(cw->inc.y)));
@@ -1572,7 +1576,7 @@ __global__ __launch_bounds__(64 * kExact5Waves, 2) void demod_exact5_kernel(cons
     float *out = uni_ptr(cw->out);
     unsigned *peak_word = uni_ptr(cw->peak);
     const float *taps_u = uni_ptr(taps);
-    int warm = EXACT5_ASM_WARM_STORES, iters = EXACT5_ASM_WARM_ITERS + (int)((most + 3) / 4);
+    int warm = EXACT5_ASM_WARM_STORES, iters = (int)((32u + most + TILES - 1) / TILES);       // 32 warm-up tiles, then one tile per output
     const unsigned long long hmask = 0xFFFFFFFF00000000ull;
     unsigned long long esave;
     float peak;
@@ -1583,13 +1587,18 @@ __global__ __launch_bounds__(64 * kExact5Waves, 2) void demod_exact5_kernel(cons
         as_global_rw(clk)[0] = t_;
         as_global_rw(clk)[1] = r_;
     }
-    asm volatile(EXACT5_PROLOGUE_ASM EXACT5_LOOP_ASM EXACT5_EPILOGUE_ASM
-                 : [off0] "+v"(off0), [off1] "+v"(off1), [off2] "+v"(off2), [off3] "+v"(off3), [rem] "+v"(rem), [outoff] "+v"(outoff), [peak] "=&v"(peak),
-                   [esave] "=&s"(esave), [warm] "+s"(warm), [iters] "+s"(iters)
-                 : [capl] "v"(capl), [pc16] "v"(pc16), [ldsr] "v"(ldsr), [ldsw] "v"(ldsw), [ckoff] "v"(ckoff), [tapoff] "v"(tapoff),
-                   [ring] "s"(ring), [taps] "s"(taps_u), [tone] "s"(tone), [ckpt] "s"(ckpt), [out] "s"(out),
-                   [incre] "s"(incre), [incim] "s"(incim), [sign] "s"(sign), [nsign] "s"(nsign), [hmask] "s"(hmask)
-                 : EXACT5_ASM_CLOBBERS);
+#define EXACT5_STATEMENT(TEXT)                                                                                                                             \
+    asm volatile(TEXT                                                                                                                                      \
+                 : [off0] "+v"(off0), [off1] "+v"(off1), [off2] "+v"(off2), [off3] "+v"(off3), [rem] "+v"(rem), [outoff] "+v"(outoff), [peak] "=&v"(peak), \
+                   [esave] "=&s"(esave), [warm] "+s"(warm), [iters] "+s"(iters)                                                                            \
+                 : [capl] "v"(capl), [pc16] "v"(pc16), [ldsr] "v"(ldsr), [ldsw] "v"(ldsw), [ckoff] "v"(ckoff), [tapoff] "v"(tapoff),                       \
+                   [ring] "s"(ring), [taps] "s"(taps_u), [tone] "s"(tone), [ckpt] "s"(ckpt), [out] "s"(out),                                               \
+                   [incre] "s"(incre), [incim] "s"(incim), [sign] "s"(sign), [nsign] "s"(nsign), [hmask] "s"(hmask)                                        \
+                 : EXACT5_ASM_CLOBBERS)
+    if constexpr (D == 16) EXACT5_STATEMENT(EXACT5_D16_PROLOGUE_ASM EXACT5_D16_LOOP_ASM EXACT5_D16_EPILOGUE_ASM);
+    else if constexpr (D == 8) EXACT5_STATEMENT(EXACT5_D8_PROLOGUE_ASM EXACT5_D8_LOOP_ASM EXACT5_D8_EPILOGUE_ASM);
+    else EXACT5_STATEMENT(EXACT5_D4_PROLOGUE_ASM EXACT5_D4_LOOP_ASM EXACT5_D4_EPILOGUE_ASM);
+#undef EXACT5_STATEMENT
     const float mx = wave_max_dpp(peak);
     if (lane == 0) publish_peak(peak_word, mx);
     if (stamp && lane == 0) {

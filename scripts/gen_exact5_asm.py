@@ -43,11 +43,19 @@ GROUPED = os.environ.get("X5_GROUPED", "1") == "1"            # mix and sum * ph
 # the ring is read once: non-temporal (same-box A/B: 2.5-2.8 % of the launch).  X5_RING_NT: "0" none, "1" nt, or the modifiers themselves ("sc1 nt", ...)
 _nt = os.environ.get("X5_RING_NT", "1")
 RING_NT = "" if _nt == "0" else (" nt" if _nt == "1" else " " + _nt.replace("_", " ").strip())
+D = 16                                                             # samples per block = Fs / 12 kHz: 16 (192 kHz), 8 (96 kHz), 4 (48 kHz); set by program(d)
 STG2 = 240                                                         # the second staging set, at the top of the file (the operands sit between VTOP and it)
 ROW = 144                                                          # LDS row pitch: 16 samples + 16 bytes (conflict-free 16-byte reads, lane = row)
 BUF = 32 * ROW                                                     # one tile of one wave: 4608 bytes; two buffers
 MFMA_WAIT = 18                                                     # issue slots between a 16-pass f32 MFMA and a VALU access to its result
 WARM_ITERS = 8                                                     # 32 warm-up tiles
+
+
+def geometry():
+    """R compute tiles share one 128-byte row ("load tile": 16 samples of every stream, whatever D); an iteration is four load tiles = NT compute
+    tiles; a tile's samples arrive in NSUB reads of SUB samples each."""
+    R = 16 // D
+    return R, 4 * R, min(D, 8), D // min(D, 8)
 
 
 def mfma(dst, m):
@@ -59,7 +67,7 @@ def adds(src):
 
 
 def mix(m):
-    mm, t = m & 7, T + 2 * (m & 3)
+    mm, t = m % min(D, 8), T + 2 * (m & 3)
     return [f"v_mul_f32 v{t}, v{IN + 2 * mm}, v{C1 + m}", f"v_mul_f32 v{t + 1}, v{IN + 2 * mm + 1}, v{C2 + m}", f"v_add_f32 v{Y + m}, v{t}, v{t + 1}"]
 
 
@@ -75,8 +83,12 @@ def mix_group(ms):
     return out
 
 
-def lds_read(buf, half):
-    return [f"ds_read_b128 v[{IN + 4 * k}:{IN + 4 * k + 3}], %[ldsr] offset:{buf * BUF + 64 * half + 16 * k}" for k in range(4)]
+def sub_read(c, sub):
+    """Sub-read `sub` of compute tile c of the iteration (c may be NT: the next iteration's tile 0): SUB samples from the tile's part of its row."""
+    R, NT, SUB, NSUB = geometry()
+    lt = c // R                                                    # load tile; its LDS buffer is lt & 1 (four load tiles per iteration: the parity carries over)
+    off = (lt & 1) * BUF + (c % R) * 8 * D + sub * 8 * SUB
+    return [f"ds_read_b128 v[{IN + 4 * k}:{IN + 4 * k + 3}], %[ldsr] offset:{off + 16 * k}" for k in range(SUB // 2)]
 
 
 def stg(tile):
@@ -88,13 +100,19 @@ def lds_write(tile):
 
 
 def ring_loads(tile):
-    return [f"global_load_dwordx4 v[{stg(tile) + 4 * i}:{stg(tile) + 4 * i + 3}], %[off{i}], %[ring] offset:{128 * (tile & 3)}{RING_NT}" for i in range(4)]
+    """The four 16-byte loads of a wave for one load tile (32 rows of 128 bytes).  192 kHz: a stream's start and the ring's length are multiples of 512
+    bytes (64 samples = 4 blocks: the push granularity), so four load tiles share one offset (immediates 0 / 128 / 256 / 384) and the offsets advance --
+    and wrap -- once per iteration.  96 / 48 kHz: the guaranteed alignment is 4 blocks = 256 / 128 bytes, so the offsets advance after every load tile."""
+    imm = 128 * (tile & 3) if D == 16 else 0
+    L = [f"global_load_dwordx4 v[{stg(tile) + 4 * i}:{stg(tile) + 4 * i + 3}], %[off{i}], %[ring] offset:{imm}{RING_NT}" for i in range(4)]
+    return L if D == 16 else L + ["s_nop 0"] + advance_offsets()
 
 
 def advance_offsets():
+    step = "0x200" if D == 16 else "0x80"
     out = []
-    for i in range(4):                                             # the next 512 bytes of each stream; the ring's end is a multiple of 512 bytes away from its start
-        out += [f"v_add_u32 %[off{i}], 0x200, %[off{i}]", f"v_cmp_eq_u32 vcc, %[off{i}], %[capl]", f"v_cndmask_b32 %[off{i}], %[off{i}], %[pc16], vcc"]
+    for i in range(4):                                             # the next 512 / 128 bytes of each stream; the ring's end is a multiple of that away from a stream's start
+        out += [f"v_add_u32 %[off{i}], {step}, %[off{i}]", f"v_cmp_eq_u32 vcc, %[off{i}], %[capl]", f"v_cndmask_b32 %[off{i}], %[off{i}], %[pc16], vcc"]
     return out
 
 
@@ -132,26 +150,32 @@ def phase_step():
             f"v_sub_f32 v{P}, v{t}, v{t + 1}", f"v_add_f32 v{P + 1}, v{t + 2}, v{t + 3}", f"v_mul_f32 v{NPIM}, -1.0, v{P + 1}"]
 
 
-def tile(u):
-    """Memory pipeline: TWO tiles of a stream are in flight (one tile per wave was 8 MB in flight chip-wide: at ~2.8 us of loaded HBM latency that
-    is the 2.9 TB/s the first form of this kernel ran at, whatever its arithmetic did).  At tile t: wait for tile t + 1's rows (the older of the
-    two outstanding sets: vmcnt(4)), move them to LDS buffer (t + 1) & 1, and request tile t + 3 into the staging set that this freed."""
-    buf = u & 1
-    L = ["s_waitcnt lgkmcnt(0)"]                                    # samples 0..7 of this tile (read at the end of the previous one)
-    L += mix_group(list(range(8)))
-    L += lds_read(buf, 1)                                           # samples 8..15 into the same registers
-    loader = ["s_waitcnt vmcnt(4)"]                                 # the NEXT tile's rows have arrived from the ring ...
-    loader += lds_write(u + 1)                                      # ... transposed through LDS ...
-    if u == 0:
-        loader += store_block()                                     # the previous iteration's four outputs (behind the older loads, ahead of the new ones: see vmcnt)
-    if u == 1:
-        loader += advance_offsets()
-    loader += ring_loads(u + 3)                                     # ... and the third tile from here is requested
+def tile(c):
+    """Compute tile c of an iteration (c mod 4 = the block's position mod 4).  Memory pipeline, per LOAD tile (16 samples of every stream): TWO are in
+    flight (one per wave was 8 MB in flight chip-wide: at ~2.8 us of loaded HBM latency that is the 2.9 TB/s the first form of this kernel ran at,
+    whatever its arithmetic did).  In the first compute tile of load tile t: wait for load tile t + 1's rows (the older of the two outstanding
+    sets: vmcnt(4)), move them to LDS buffer (t + 1) & 1, and request load tile t + 3 into the staging set that this freed."""
+    R, NT, SUB, NSUB = geometry()
+    u = c & 3
+    L = ["s_waitcnt lgkmcnt(0)"]                                    # this tile's first SUB samples (read during the previous tile)
+    L += mix_group(list(range(SUB)))
+    L += sub_read(c, 1) if NSUB == 2 else sub_read(c + 1, 0)        # the rest of this tile's samples / the next tile's, into the same registers
+    loader = []
+    if c % R == 0:
+        lt = c // R
+        loader = ["s_waitcnt vmcnt(4)"]                             # the NEXT load tile's rows have arrived from the ring ...
+        loader += lds_write(lt + 1)                                 # ... transposed through LDS ...
+        if c % 4 == 0:
+            loader += store_block(c // 4)                           # the previous four outputs (behind the older loads, ahead of the new ones: see vmcnt)
+        if lt == 1 and D == 16:
+            loader += advance_offsets()
+        loader += ring_loads(lt + 3)                                # ... and the third load tile from here is requested
+    elif c % 4 == 0:
+        raise AssertionError("a store slot that is not a loader slot")
     if not LOADER_IN_GAP:
         L += loader
     where = {}
-    second_half_mixed = False
-    for m in range(16):
+    for m in range(D):
         dst = S if m == 0 else (DA if m & 1 else DB)
         L.append(mfma(dst, m))
         where[m] = dst
@@ -159,11 +183,11 @@ def tile(u):
             L += loader
         if m >= 2:
             L += adds(where[m - 1])
-        if m == 5:                                                  # samples 8..15 have long landed: mix them before MFMA 8 needs y[8]
+        if m == 5 and NSUB == 2:                                    # samples 8..15 have long landed: mix them before MFMA 8 needs y[8]
             L += ["s_waitcnt lgkmcnt(0)"]
             L += mix_group(list(range(8, 16)))
-            L += lds_read(buf ^ 1, 0)                               # the next tile's samples 0..7
-    L += adds(where[15])
+            L += sub_read(c + 1, 0)                                 # the next tile's samples 0..7
+    L += adds(where[D - 1])
     L += t_and_w(u)
     L += phase_step()                                               # (two instructions at least between W[0]'s write and the swap that reads it)
     L += swap_and_out(u)
@@ -172,30 +196,34 @@ def tile(u):
 
 def prologue():
     L = ["s_nop 4"]                                                 # operands fresh from v_readfirstlane are read as addresses below (5 wait states)
-    L += [f"global_load_dwordx4 v[{H + 4 * k}:{H + 4 * k + 3}], %[tapoff], %[taps] offset:{16 * k}" for k in range(4)]
+    L += [f"global_load_dwordx4 v[{H + 4 * k}:{H + 4 * k + 3}], %[tapoff], %[taps] offset:{16 * k}" for k in range(D // 4)]
     L += [f"global_load_dwordx2 v[{P}:{P + 1}], %[ckoff], %[ckpt]"]
-    L += ["s_load_dwordx16 s[64:79], %[tone], 0x0", "s_load_dwordx16 s[80:95], %[tone], 0x40"]
+    L += {16: ["s_load_dwordx16 s[64:79], %[tone], 0x0", "s_load_dwordx16 s[80:95], %[tone], 0x40"], 8: ["s_load_dwordx16 s[64:79], %[tone], 0x0"],
+          4: ["s_load_dwordx8 s[64:71], %[tone], 0x0"]}[D]
     L += ring_loads(0) + ring_loads(1)
     L += [f"v_mov_b32 v{W + k}, 0" for k in range(17)] + [f"v_mov_b32 v{OB + k}, 0" for k in range(4)] + [f"v_mov_b32 v{PEAK}, 0"]
     L += ["s_waitcnt vmcnt(0) lgkmcnt(0)"]
     L += ["s_mov_b64 vcc, %[hmask]"]
-    for m in range(16):                                             # c1 = (tone.re | tone.im), c2 = (-tone.im | tone.re) by half
+    for m in range(D):                                              # c1 = (tone.re | tone.im), c2 = (-tone.im | tone.re) by half
         L += [f"v_mov_b32 v{T}, s{64 + 2 * m}", f"v_mov_b32 v{T + 1}, s{65 + 2 * m}", f"v_cndmask_b32 v{C1 + m}, v{T}, v{T + 1}, vcc",
               f"v_xor_b32 v{T + 2}, 0x80000000, v{T + 1}", f"v_cndmask_b32 v{C2 + m}, v{T + 2}, v{T}, vcc"]
     L += [f"v_mul_f32 v{NPIM}, -1.0, v{P + 1}"]
     L += lds_write(0)
     L += ring_loads(2)
-    L += lds_read(0, 0)
+    L += sub_read(0, 0)
     return L
 
 
-def store_block():
-    return ["s_cmp_gt_u32 %[warm], 0", "s_cbranch_scc1 L5_WARM_%=",
+def store_block(k):
+    """Four outputs per lane, 16 bytes: the streams of the upper half whose range is not exhausted; skipped for the first nine slots (the 32 warm-up
+    tiles' outputs and the slot before the first tile)."""
+    tag = "E" if k == "E" else str(k)
+    return ["s_cmp_gt_u32 %[warm], 0", f"s_cbranch_scc1 L5_WARM{tag}_%=",
             "v_cmp_lt_i32 vcc, 0, %[rem]", "s_and_b64 vcc, vcc, %[hmask]", "s_and_saveexec_b64 %[esave], vcc",
             f"global_store_dwordx4 %[outoff], v[{OB}:{OB + 3}], %[out]"] + \
-           [f"v_max_f32 v{PEAK}, v{PEAK}, |v{OB + k}|" for k in range(4)] + \
-           ["s_mov_b64 exec, %[esave]", "v_add_u32 %[outoff], 16, %[outoff]", "v_add_u32 %[rem], -4, %[rem]", "s_branch L5_NEXT_%=",
-            "L5_WARM_%=:", "s_sub_u32 %[warm], %[warm], 1", "L5_NEXT_%=:"]
+           [f"v_max_f32 v{PEAK}, v{PEAK}, |v{OB + j}|" for j in range(4)] + \
+           ["s_mov_b64 exec, %[esave]", "v_add_u32 %[outoff], 16, %[outoff]", "v_add_u32 %[rem], -4, %[rem]", f"s_branch L5_NEXT{tag}_%=",
+            f"L5_WARM{tag}_%=:", "s_sub_u32 %[warm], %[warm], 1", f"L5_NEXT{tag}_%=:"]
 
 
 def regs_of(tok):
@@ -260,28 +288,34 @@ def fix_hazards(L):
     return out
 
 
-def program():
+def program(d):
+    global D
+    D = d
+    R, NT, SUB, NSUB = geometry()
     pro = fix_hazards(prologue())
     body = []
-    for u in range(4):
-        body += tile(u)
+    for c in range(NT):
+        body += tile(c)
     body = fix_hazards(body + [mfma(S, 0)])[:-1]                    # (the loop wraps: the hazards of the first MFMA against the body's end hold as well)
     loop = ["L5_LOOP_%=:"] + body + ["s_sub_u32 %[iters], %[iters], 1", "s_cmp_lg_u32 %[iters], 0", "s_cbranch_scc1 L5_LOOP_%="]
-    epi = [l.replace("L5_", "L5E_") for l in store_block()] + ["s_waitcnt vmcnt(0) lgkmcnt(0)", f"v_mov_b32 %[peak], v{PEAK}"]
+    epi = store_block("E") + ["s_waitcnt vmcnt(0) lgkmcnt(0)", f"v_mov_b32 %[peak], v{PEAK}"]
     return pro, loop, epi
 
 
 def main():
-    pro, loop, epi = program()
     w = sys.stdout.write
     w("// GENERATED by scripts/gen_exact5_asm.py -- do not edit.  See that script and demod_exact5_kernel (demod_kernels.hpp).\n")
-    w(f"#define EXACT5_ASM_ROW_BYTES {ROW}\n#define EXACT5_ASM_BUF_BYTES {BUF}\n#define EXACT5_ASM_WARM_ITERS {WARM_ITERS}\n#define EXACT5_ASM_WARM_STORES {WARM_ITERS + 1}\n#define EXACT5_ASM_VTOP {VTOP}\n")
-    w("#define EXACT5_ASM_CLOBBERS " + ", ".join(f'"v{i}"' for i in list(range(VTOP)) + list(range(STG2, STG2 + 16))) + ", " + ", ".join(f'"s{i}"' for i in range(64, 96)) + ', "vcc", "scc", "memory"\n')
-    for name, lines in (("EXACT5_PROLOGUE_ASM", pro), ("EXACT5_LOOP_ASM", loop), ("EXACT5_EPILOGUE_ASM", epi)):
-        w(f"#define {name} \\\n")
-        for l in lines:
-            w(f'    "{l}\\n\\t" \\\n')
-        w('    ""\n\n')
+    w(f"#define EXACT5_ASM_ROW_BYTES {ROW}\n#define EXACT5_ASM_BUF_BYTES {BUF}\n#define EXACT5_ASM_WARM_STORES 9\n#define EXACT5_ASM_VTOP {VTOP}\n")
+    w("#define EXACT5_ASM_CLOBBERS " + ", ".join(f'"v{i}"' for i in list(range(VTOP)) + list(range(STG2, STG2 + 16))) + ", " +
+      ", ".join(f'"s{i}"' for i in range(64, 96)) + ', "vcc", "scc", "memory"\n')
+    for d in (16, 8, 4):
+        pro, loop, epi = program(d)
+        w(f"#define EXACT5_D{d}_TILES_PER_ITER {geometry()[1]}\n")
+        for name, lines in ((f"EXACT5_D{d}_PROLOGUE_ASM", pro), (f"EXACT5_D{d}_LOOP_ASM", loop), (f"EXACT5_D{d}_EPILOGUE_ASM", epi)):
+            w(f"#define {name} \\\n")
+            for l in lines:
+                w(f'    "{l}\\n\\t" \\\n')
+            w('    ""\n\n')
 
 
 if __name__ == "__main__":

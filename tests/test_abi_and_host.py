@@ -124,10 +124,11 @@ def test_product_library_has_one_kernel_per_job_and_no_lab_switches():
     # (tile by decimation: 256 outputs at 192 kHz, 512 at 96 kHz, 768 at 48 kHz -- the same amount of IQ per workgroup)
     assert len(demod) == 3 and sum(t in k for k in demod for t in ("ILi16ELi256ELi256ELi0E", "ILi8ELi512ELi256ELi0E", "ILi4ELi768ELi256ELi0E")) == 3, demod
     exact = sorted(k for k in kp if "demod_exact" in k)
-    # exact mode at 192 kHz: the stream form (round 5: lane = stream, K = 1 matrix products) for every output whose 32-block history exists, the
-    # two-stream tile form for the first 32 outputs of a demodulator; round 3's one-stream form at 96 / 48 kHz
-    assert len(exact) == 4 and sum("demod_exact4_kernelILi512ELi512E" in k for k in exact) == 1 and sum("demod_exact5_kernel" in k for k in exact) == 1, exact
+    # exact mode: the stream form (round 5: lane = stream, K = 1 matrix products) at all three rates for every output whose 32-block history exists; for
+    # the first 32 outputs of a demodulator the two-stream tile form (192 kHz) / round 3's one-stream form (96 / 48 kHz)
+    assert len(exact) == 6 and sum("demod_exact4_kernelILi512ELi512E" in k for k in exact) == 1, exact
+    assert sorted(k for k in exact if "demod_exact5_kernel" in k) == sorted("_ZN5cwslg19demod_exact5_kernelILi%dEEEvPKNS_8ChanWorkEPKfiiiPy" % d for d in (16, 8, 4)), exact
     assert sum("demod_exact3_kernelILi8ELi512ELi256E" in k or "demod_exact3_kernelILi4ELi512ELi256E" in k for k in exact) == 2, exact
     # FT8: Costas search + candidate selection in one launch per boundary, or (few channels) one workgroup per band + the selection
     assert any("ft8_sync_chan_kernel" in k for k in kp) and any("ft8_sync2d_v3_kernel" in k for k in kp)
-    assert len(kp) <= 38, sorted(kp)                   # round 4: + scatter_blocks_kernel (cwslg_push_iq_many); round 5: + demod_exact5_kernel
+    assert len(kp) <= 40, sorted(kp)                   # round 4: + scatter_blocks_kernel (cwslg_push_iq_many); round 5: + demod_exact5_kernel<16 / 8 / 4>

@@ -15,7 +15,6 @@ from wave_emulator import Wave
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F, U = np.float32, np.uint32
-FS, D = 192000, 16
 
 
 def _gen():
@@ -39,9 +38,10 @@ def _tap_block_of_row(i):
     return (i & 3) + 4 * (i >> 3) + 16 * ((i >> 2) & 1)
 
 
-def _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, ring_shift_blocks):
+def _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, ring_shift_blocks, D=16):
     text = _gen()
-    row, buf, warm = _define(text, "EXACT5_ASM_ROW_BYTES"), _define(text, "EXACT5_ASM_BUF_BYTES"), _define(text, "EXACT5_ASM_WARM_ITERS")
+    FS = 12000 * D
+    row, buf, per_iter = _define(text, "EXACT5_ASM_ROW_BYTES"), _define(text, "EXACT5_ASM_BUF_BYTES"), _define(text, "EXACT5_D%d_TILES_PER_ITER" % D)
     q_first = 32                                              # the demodulator's first 32 outputs are not this kernel's (no 32-block history)
     total_blocks = q_first + n_blocks
     n_samp = total_blocks * D
@@ -51,7 +51,9 @@ def _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, ring_shift_blocks):
     taps, tone, inc = dm.taps.astype(F), dm.tone, dm.phase_inc
     # ---- global memory image ----
     cap = ((n_samp + 64 * 37) // 64) * 64                     # ring capacity in samples, a multiple of 64
-    shift = ring_shift_blocks * D                             # logical sample i lives at ring[(i + shift) % cap]
+    # logical sample i lives at ring[(i + shift) % cap]; a negative argument puts the ring's END that many blocks into the data (4-block granularity,
+    # the push granularity of the library: 512 / 256 / 128 bytes at 192 / 96 / 48 kHz)
+    shift = ring_shift_blocks * D if ring_shift_blocks >= 0 else cap + ring_shift_blocks * D
     ring = (np.arange(2 * cap, dtype=np.float32) * 0 + 7.0e8)  # junk everywhere the stream must not read
     ring = ring.reshape(cap, 2)
     pos = (np.arange(n_samp) + shift) % cap
@@ -89,7 +91,7 @@ def _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, ring_shift_blocks):
     ops["ldsr"] = ("v", (j * row).astype(U))
     ops["ldsw"] = ("v", ((lane >> 3) * row + (lane & 7) * 16).astype(U))
     ops["ckoff"] = ("v", (((q_first + j * seg_len - 32) // 4) * 8).astype(U))
-    ops["tapoff"] = ("v", np.array([64 * _tap_block_of_row(int(i)) for i in j], U))
+    ops["tapoff"] = ("v", np.array([4 * D * _tap_block_of_row(int(i)) for i in j], U))
     ops["rem"] = ("v", n_out.astype(U))
     ops["outoff"] = ("v", (j * seg_len * 4).astype(U))
     ops["peak"] = ("v", np.zeros(64, U))
@@ -98,25 +100,29 @@ def _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, ring_shift_blocks):
         ops[name] = ("s64", base[name])
     ops.update(incre=("s", int(np.array(inc.real, F).view(U))), incim=("s", int(np.array(inc.imag, F).view(U))),
                sign=("s", int(np.array(sign, F).view(U))), nsign=("s", int(np.array(-sign, F).view(U))),
-               hmask=("s64", 0xFFFFFFFF00000000), esave=("s64", 0), warm=("s", _define(text, "EXACT5_ASM_WARM_STORES")), iters=("s", warm + int(n_out.max() + 3) // 4))
+               hmask=("s64", 0xFFFFFFFF00000000), esave=("s64", 0), warm=("s", _define(text, "EXACT5_ASM_WARM_STORES")), iters=("s", (32 + int(n_out.max()) + per_iter - 1) // per_iter))
     w = Wave(mem, 2 * buf, ops)
-    w.run(_lines(text, "EXACT5_PROLOGUE_ASM") + _lines(text, "EXACT5_LOOP_ASM") + _lines(text, "EXACT5_EPILOGUE_ASM"))
+    w.run(_lines(text, "EXACT5_D%d_PROLOGUE_ASM" % D) + _lines(text, "EXACT5_D%d_LOOP_ASM" % D) + _lines(text, "EXACT5_D%d_EPILOGUE_ASM" % D))
     got = mem[base["out"]:base["out"] + len(parts["out"])].view(F)
     peak = w.v[w.names["peak"][1]].view(F)
     return got, ref[q_first:], n_out, peak, w, text
 
 
-@pytest.mark.parametrize("f_hz,usb,seed,shift", [(-26000, True, 11, 0), (48000, True, 12, 5), (1234, False, 13, 37)])
-def test_exact5_wave_program_writes_the_reference_bits(oracle, f_hz, usb, seed, shift):
-    seg_len, n_blocks = 8, 244                                 # 30 full lanes, one of 4 outputs, one idle; shift 37 puts the ring's end inside a stream
-    got, want, n_out, peak, w, text = _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, shift)
+@pytest.mark.parametrize("d,f_hz,usb,seed,shift", [(16, -26000, True, 11, 0), (16, 48000, True, 12, 8), (16, 1234, False, 13, -100),
+                                                   (8, -26000, True, 14, 0), (8, 30000, False, 15, -100), (8, 5000, True, 18, -140),
+                                                   (4, 11000, True, 16, 0), (4, -20500, True, 17, -100), (4, 800, False, 19, -204)])
+def test_exact5_wave_program_writes_the_reference_bits(oracle, d, f_hz, usb, seed, shift):
+    """All three decimations (192 / 96 / 48 kHz: 16, 8, 4 samples per block; a 128-byte row of the transposing LDS image then holds 1, 2 or 4 tiles)."""
+    seg_len, n_blocks = 8, 244                                 # 30 full lanes, one of 4 outputs, one idle; a negative shift puts the ring's end inside a stream
+    got, want, n_out, peak, w, text = _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, shift, D=d)
     assert np.array_equal(got[:n_blocks].view(U), want[:n_blocks].view(U)), np.nonzero(got[:n_blocks].view(U) != want[:n_blocks].view(U))[0][:8]
     assert (got[n_blocks:] == F(3.0e8)).all(), "a lane wrote past its own outputs"
     assert np.abs(want[:n_blocks]).max() == peak.max() and (peak[:32] == 0).all()
     # shape of a tile: the reference's arithmetic and nothing fused -- 16 matrix instructions (2048 products each), 15 x 32 ordered additions
-    loop = _lines(text, "EXACT5_LOOP_ASM")
-    assert sum(l.startswith("v_mfma_f32_32x32x1_2b_f32") for l in loop) == 4 * 16
-    assert sum(bool(re.match(r"v_add_f32 v(\d+), v\1, v(3[2-9]|[4-9]\d)$", l)) for l in loop) == 4 * 15 * 32
+    loop = _lines(text, "EXACT5_D%d_LOOP_ASM" % d)
+    tiles = _define(text, "EXACT5_D%d_TILES_PER_ITER" % d)
+    assert tiles * d == 64 and sum(l.startswith("v_mfma_f32_32x32x1_2b_f32") for l in loop) == tiles * d
+    assert sum(bool(re.match(r"v_add_f32 v(\d+), v\1, v(3[2-9]|[4-9]\d)$", l)) for l in loop) == tiles * (d - 1) * 32
     assert not any("fma" in l.split(" ")[0].replace("v_mfma", "") for l in loop)
     regs = [int(x) for l in loop for x in re.findall(r"\bv(\d+)\b", l)] + [int(x) for l in loop for x in re.findall(r"v\[\d+:(\d+)\]", l)]
     vtop = int(re.search(r"#define EXACT5_ASM_VTOP (\d+)", text).group(1))              # fixed registers: v0 .. VTOP - 1 and the second staging set v240 .. v255
