@@ -461,13 +461,10 @@ def main():
                 "sync_avg_ms": st_["sync_ms"] / max(1, st_["sync_launches"]),
                 "whole_path_frac": BYTES_PER_SAMPLE_PATH * spl * args.steps / dt_ / 1e9 / HBM_PEAK_GBS}
         if exact and "exact5" in kname:
-            # demod_exact5_kernel (round 5): per tile (one 16-sample block of 32 streams = the work of 32 outputs) 16 K = 1 matrix instructions -- the
+            # demod_exact5_kernel<16> (round 5; a demodulator's first outputs included: one launch per step): per tile (one 16-sample block of 32 streams = the work of 32 outputs) 16 K = 1 matrix instructions -- the
             # 32 768 un-fused products fl(y * h) -- and 603 one-lane FP32 instructions (15 x 32 ordered additions, mix 48, sum * phase and workspace 64 + 3,
             # phasor 7, ...).  The f32 MFMA occupies the SIMD's FP32 lanes: its 64 cycles and the VALU's time ADD (scripts/micro/mfma_k1.hip,
             # profiles/r5_mfma_k1.txt: gapN / both_* rows), so the bound is a one-pipe sum, priced at the clock measured inside the timed launches.
-            roof["demod_head"] = {"kernel": "demod_exact4_kernel<512,512>", "launches": st_.get("demod_head_launches", 0),
-                                  "avg_ms": st_.get("demod_head_ms", 0.0) / max(1, st_.get("demod_head_launches", 0)),
-                                  "what": "the first 32 outputs after a demodulator's creation (no 32-block history yet); not in avg_launch_ms"}
             clk_mhz = float(st_.get("demod_clock_mhz", 0.0))
             tiles = spl / 16.0 / 32.0 / (n_cu * 4.0)                                   # per SIMD and launch (the streams' 32-block warm-up not counted: it is overhead)
             mfma_cyc, valu_insts = 16 * 64, 603

@@ -106,8 +106,7 @@ class Stats(C.Structure):
                 ("sync_ms", C.c_double), ("phasor_regrows", C.c_uint64), ("rendezvous_calls", C.c_uint64),
                 ("rendezvous_frames", C.c_uint64), ("rccl_world", C.c_uint64), ("rendezvous_flags_and", C.c_uint64),
                 ("demod_clock_mhz", C.c_double), ("demod_clock_launches", C.c_uint64), ("push_calls", C.c_uint64),
-                ("push_batches", C.c_uint64), ("push_host_ms", C.c_double), ("sync_spectra_ms", C.c_double), ("sync_search_ms", C.c_double),
-                ("demod_head_launches", C.c_uint64), ("demod_head_ms", C.c_double)]
+                ("push_batches", C.c_uint64), ("push_host_ms", C.c_double), ("sync_spectra_ms", C.c_double), ("sync_search_ms", C.c_double)]
 
 
 # int (*)(void *user, int group, uint64_t epoch_s, uint64_t frames_local, uint64_t *frames_total)

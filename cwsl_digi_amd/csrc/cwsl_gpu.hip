@@ -209,7 +209,7 @@ struct WorkBuf {
 
 struct TimedSpan {
     hipEvent_t a, b;
-    int kind;                          // 0 demod, 1 finalize, 2 sync stage (whole), 3 / 4 its FT8 spectra / search + selection kernels, 5 demod head launch
+    int kind;                          // 0 demod, 1 finalize, 2 sync stage (whole), 3 / 4 its FT8 spectra / search + selection kernels
     unsigned gen;                      // cwslg_reset_stats generation it was started in: a span of an older generation is not accounted
 };
 
@@ -452,7 +452,6 @@ void drain_spans(cwslg_ctx *c)
             else if (s.kind == 1) c->stats.finalize_ms += ms;
             else if (s.kind == 3) c->stats.sync_spectra_ms += ms;
             else if (s.kind == 4) c->stats.sync_search_ms += ms;
-            else if (s.kind == 5) c->stats.demod_head_ms += ms;
             else c->stats.sync_ms += ms;
         }
         c->ev_pool.push_back({s.a, s.b});
@@ -480,8 +479,9 @@ int ensure_taps(cwslg_ctx *c, uint32_t fs)
     HIPCHK(c, hipMalloc(&d, h.size() * sizeof(float)));
     HIPCHK(c, hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
     c->d_taps[fs] = d;
-    // demod_exact3_kernel reads the taps as wave-uniform PAIRS: step n of a thread's two adjacent outputs uses tap block n for the
-    // even one and n - 1 for the odd one; blocks -1 and 32 do not exist (their addends are masked in the kernel): zeros
+#if CWSLG_LAB
+    // (lab library) demod_exact3_kernel / demod_exact4_kernel read the taps as wave-uniform PAIRS: step n of a thread's two adjacent outputs uses tap
+    // block n for the even one and n - 1 for the odd one; blocks -1 and 32 do not exist (their addends are masked in the kernel): zeros
     const size_t D = h.size() / 32;
     std::vector<float> h2(33 * D * 2, 0.0f);
     for (size_t n = 0; n < 33; ++n)
@@ -493,6 +493,7 @@ int ensure_taps(cwslg_ctx *c, uint32_t fs)
     HIPCHK(c, hipMalloc(&d2, h2.size() * sizeof(float)));
     HIPCHK(c, hipMemcpy(d2, h2.data(), h2.size() * sizeof(float), hipMemcpyHostToDevice));
     c->d_taps2[fs] = d2;
+#endif
     c->h_taps[fs] = std::move(h);
     return CWSLG_OK;
 }
@@ -618,33 +619,17 @@ int launch_exact5(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max
 }
 
 template <int D>
-int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_blocks, uint32_t fs, bool tile_major, bool no_split = false)
+int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_blocks, uint32_t fs, bool tile_major)
 {
     if (works.empty()) return CWSLG_OK;
-    if (c->exact && c->use_exact5 && !no_split) {
-        // exact mode: demod_exact5_kernel<D> takes every output whose 32-block history exists (q_first >= 32); the first 32 outputs of a fresh
-        // demodulator -- and any work that does not meet its alignment rules -- go through demod_exact4_kernel (192 kHz) / demod_exact3_kernel
-        std::vector<ChanWork> head, rest;
-        unsigned max_head = 0, max_rest = 0;
-        for (const ChanWork &w0 : works) {
-            ChanWork w = w0;
-            const bool aligned = w.q_first % 4 == 0 && w.n_blocks % 4 == 0 && w.lo_mod % (4 * D) == 0 && w.ring_cap % (4 * D) == 0 && (uint64_t)w.ring_cap * 8 < (1ull << 32);
-            unsigned n_head = !aligned ? w.n_blocks : (w.q_first < 32 ? (unsigned)std::min<long long>(w.n_blocks, 32 - w.q_first) : 0u);
-            if (n_head) {
-                ChanWork h = w;
-                h.n_blocks = n_head;
-                head.push_back(h);
-                max_head = std::max(max_head, n_head);
-                w.out += n_head;
-                w.n_blocks -= n_head;
-                w.lo_mod = (unsigned)(((uint64_t)w.lo_mod + (uint64_t)n_head * D) % w.ring_cap);
-                w.q_first += n_head;
-            }
-            if (w.n_blocks) { rest.push_back(w); max_rest = std::max(max_rest, w.n_blocks); }
-        }
-        int rc = launch_demod<D>(c, head, max_head, fs, tile_major, true);
-        if (rc) return rc;
-        return launch_exact5<D>(c, rest, max_rest, fs, tile_major);
+    if (c->exact && c->use_exact5) {
+        // exact mode: demod_exact5_kernel<D> takes everything that meets its alignment rules -- which every push through this library does (pushes are
+        // whole multiples of 4 blocks, cwslg_push_iq's CWSLG_ERR_BLOCK); anything else is refused below (the lab library still has round 3/4's tile kernels)
+        bool aligned = true;
+        for (const ChanWork &w : works)
+            aligned = aligned && w.q_first >= 0 && w.q_first % 4 == 0 && w.n_blocks % 4 == 0 && w.lo_mod % (4 * D) == 0 && w.ring_cap % (4 * D) == 0 &&
+                      (uint64_t)w.ring_cap * 8 < (1ull << 32);
+        if (aligned) return launch_exact5<D>(c, works, max_blocks, fs, tile_major);
     }
     // the descriptors, then (64-byte aligned) the eight per-XCD work counters of demod_exact3_kernel, zero at launch
     const size_t ctr_off = (works.size() * sizeof(ChanWork) + 63) & ~size_t(63);
@@ -670,53 +655,17 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     const long long total = (long long)tiles_n * (long long)works.size();
     const long long per_xcd = (total + 7) / 8;
     hipEvent_t ea, eb;
-    span_begin(c, no_split ? 5 : 0, &ea, &eb);
+    span_begin(c, 0, &ea, &eb);
     bool launched = false;
 #if CWSLG_LAB
 #include "lab/demod_lab_dispatch.inc"      // CWSLG_DEMOD_VARIANT: the measured alternatives (sets `launched`)
 #endif
-    bool use_exact4 = D == 16;             // 192 kHz: the two-stream form, eight waves per tile image (demod_exact4_kernel); 96 / 48 kHz: exact3
 #if CWSLG_LAB
-    if (c->demod_variant == 26 || tile != kTileExact) use_exact4 = false;       // CWSLG_DEMOD_VARIANT=26: round 3's exact3 at 192 kHz (same bits; A/B)
+#include "lab/demod_lab_exact_dispatch.inc" // exact mode through round 3/4's tile kernels (CWSLG_DEMOD_VARIANT 23-27; sets `launched`)
 #endif
     if (!launched && c->exact) {
-        c->demod_kernel_name = D == 16 ? (use_exact4 ? "demod_exact4_kernel<512,512>" : "demod_exact3_kernel<16,512,256>")
-                             : D == 8 ? "demod_exact3_kernel<8,512,256>" : "demod_exact3_kernel<4,512,256>";
-        // Large launches: as many workgroups as are resident at once (two per CU, LDS-bound: one wave of each on every SIMD), each
-        // drawing runs of tiles with the next tile's loads in flight under its FIR; small launches (real-time pushes): one
-        // workgroup per run of tiles.
-        auto go = [&](auto kern, int nt, int &occ) {
-            if (occ == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, nt, 0) != hipSuccess || occ < 1)) occ = 1;
-            const long long slots = std::max<long long>(1, (long long)c->cu_count * occ / 8);     // resident workgroups per XCD
-            const int run_len = (int)std::min<long long>(8, std::max<long long>(1, per_xcd / slots));  // items per draw
-            const long long wgs = 8 * std::min(slots, (per_xcd + run_len - 1) / run_len);
-            unsigned long long *clk = nullptr;
-            if (c->timing && c->clk_dev && !no_split && c->clk_head - c->clk_tail < kClkSlots) {     // (a head launch is not what the clock figure is about)
-                const unsigned slot = c->clk_head++ % kClkSlots;
-                std::memset(c->clk_h + 4 * slot, 0, 4 * sizeof(unsigned long long));
-                clk = c->clk_dev + 4 * slot;
-            }
-            hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(nt), 0, c->stream, (const ChanWork *)w->d, (const float *)c->d_taps2[fs],
-                               tiles_x, (int)works.size(), (unsigned *)((char *)w->d + ctr_off), run_len, clk);
-        };
-        int (&occ_cache)[3][5] = c->occ_cache;              // resident workgroups per CU on THIS device, by D and tile form (asked once; guarded by c->mu)
-        const int di = D == 16 ? 0 : D == 8 ? 1 : 2;
-#if CWSLG_LAB
-        if (tile == 256) go(demod_exact3_kernel<D, 256, 128>, 128, occ_cache[di][1]);
-        else if (tile == 128) go(demod_exact3_kernel<D, 128, 64>, 64, occ_cache[di][2]);
-        else if (c->demod_variant == 25) {                   // the FIR as C++ with hand-issued 8-byte loads (round 3's first form; same bits)
-            go(demod_exact3_kernel<D, kTileExact, kExactThreads, false>, kExactThreads, occ_cache[di][4]);
-        } else
-#endif
-        if (use_exact4) {
-            if constexpr (D == 16) go(demod_exact4_kernel<kTileExact, kTileExact>, kTileExact, occ_cache[di][0]);
-        } else {
-#if CWSLG_LAB
-            go(demod_exact3_kernel<D, kTileExact, kExactThreads>, kExactThreads, occ_cache[di][3]);
-#else
-            if constexpr (D != 16) go(demod_exact3_kernel<D, kTileExact, kExactThreads>, kExactThreads, occ_cache[di][0]);
-#endif
-        }
+        span_end(c, eb);
+        return fail(c, CWSLG_ERR_UNSUPPORTED, "exact mode: a launch that does not meet demod_exact5_kernel's alignment rules (pushes are multiples of 4 blocks)");
     } else if (!launched) {
         c->demod_kernel_name = D == 16 ? "demod_kernel<16,256,256,0>" : D == 8 ? "demod_kernel<8,512,256,0>" : "demod_kernel<4,768,256,0>";
         unsigned long long *clk = nullptr;
@@ -732,7 +681,7 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(w->done, c->stream));
     w->in_flight = true;
-    if (no_split) c->stats.demod_head_launches++; else c->stats.demod_launches++;
+    c->stats.demod_launches++;
     return CWSLG_OK;
 }
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CWSLG_ABI_VERSION 5
+#define CWSLG_ABI_VERSION 4
 
 /* ---- status codes ---- */
 #define CWSLG_OK                  0
@@ -391,9 +391,6 @@ typedef struct {
     double   push_host_ms;         /* wall time spent inside host pushes (staging copy + enqueue), summed over the calling threads      */
     double   sync_spectra_ms;      /* of sync_ms: the FT8 symbol-spectra kernel ...                                                     */
     double   sync_search_ms;       /* ... and the FT8 Costas search + candidate selection                                                */
-    /* ABI 5 */
-    uint64_t demod_head_launches;  /* 192 kHz exact mode: launches of demod_exact4_kernel for the FIRST 32 outputs after a demodulator's creation    */
-    double   demod_head_ms;        /* (demod_exact5_kernel needs an output's 32-block history); not part of demod_launches / demod_ms              */
 } cwslg_stats;
 int cwslg_get_stats(cwslg_ctx *ctx, cwslg_stats *out);
 int cwslg_reset_stats(cwslg_ctx *ctx);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates cwsl_digi_amd/csrc/exact3_asm.inc: the 33 FIR steps of demod_exact3_kernel<16, ...> as ONE assembly statement.
+"""Generates cwsl_digi_amd/csrc/lab/exact3_asm.inc: the 33 FIR steps of demod_exact3_kernel<16, ...> as ONE assembly statement.
 
 The C++ form of this loop (rounds 2-3) had hipcc in the way at every turn: loads sunk to their first use, waits hoisted, a pad
 instruction at every statement boundary, and -- what this file is for -- no way to name the upper pair of a 128-bit register
@@ -13,7 +13,7 @@ Arithmetic and order are those of the C++ form: per step and sa
 and one step later the tail   W += sX * (ph.x, ph.y) + sY * (-ph.y, ph.x)   (:170), whose first (step 0) and last (step 32)
 instances drop the component of the tap block that does not exist.
 
-    python scripts/gen_exact3_asm.py > cwsl_digi_amd/csrc/exact3_asm.inc
+    python scripts/gen_exact3_asm.py > cwsl_digi_amd/csrc/lab/exact3_asm.inc
 """
 VBASE = {16: 160, 8: 100, 4: 76}     # first fixed VGPR: high enough to leave the compiler its own registers (next tile's prefetch: 68 / 36 / 20),
                                        # low enough for three (96 kHz) and four (48 kHz) waves per SIMD where the LDS image allows them

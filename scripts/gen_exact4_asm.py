@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generates cwsl_digi_amd/csrc/exact4_asm.inc: the FIR of demod_exact4_kernel (192 kHz) as TWO assembly streams, one per half of the 33 steps.
+"""Generates cwsl_digi_amd/csrc/lab/exact4_asm.inc: the FIR of demod_exact4_kernel (192 kHz) as TWO assembly streams, one per half of the 33 steps.
 
 Round 4.  demod_exact3_kernel keeps a pair of adjacent outputs on one lane for all 33 steps: 250 registers per lane and a 78 KB LDS image per
 four waves, i.e. two waves per SIMD -- and scripts/micro/pk_issue.hip shows what that costs: a SIMD retires a packed FP32 operation every 5.2
@@ -17,7 +17,7 @@ registers that is refilled half a step ahead (samples 0-7 are re-read for step n
 versa: two `s_waitcnt lgkmcnt(0)` per step, each draining reads issued half a step earlier), the block phase rotates through two register
 pairs, and B's sixteen R_n take 32 more.  Arithmetic and its order are exact3's (gen_exact3_asm.py), operation for operation.
 
-    python scripts/gen_exact4_asm.py > cwsl_digi_amd/csrc/exact4_asm.inc
+    python scripts/gen_exact4_asm.py > cwsl_digi_amd/csrc/lab/exact4_asm.inc
 """
 D = 16
 SPLIT = 17                 # stream A: steps 0..16, stream B: steps 17..32

@@ -95,8 +95,32 @@ def stg(tile):
     return STG2 if tile & 1 else STG                                # tile t's rows travel through staging set t & 1 into LDS buffer t & 1
 
 
+_uid = [0]
+
+
 def lds_write(tile):
-    return [f"ds_write_b128 %[ldsw], v[{stg(tile) + 4 * i}:{stg(tile) + 4 * i + 3}] offset:{(tile & 1) * BUF + 8 * ROW * i}" for i in range(4)]
+    """The staged rows go to LDS -- after the rows that lie BEFORE the demodulator's origin have been replaced by zeros (x[i < 0] = 0, SSBD.hpp:117-121: a
+    fresh SSBD has a zero workspace).  Only the first wave of a channel whose first pending output is one of the demodulator's first 32 has such rows
+    (%[holdlt] load tiles of them at most: a wave-uniform count; every other wave pays the compare and the branch).  A loader lane keeps the count of its
+    FIRST stream's pre-origin load tiles (%[tapoff], recycled after the prologue); its i-th stream starts 8 i streams = %[st<i>] load tiles later."""
+    _uid[0] += 1
+    k = _uid[0]
+    z = ["s_cmp_eq_u32 %[holdlt], 0", f"s_cbranch_scc1 L5_Z{k}_%=", "s_sub_u32 %[holdlt], %[holdlt], 1"]
+    for i in range(4):
+        z += [f"v_cmp_lt_i32 vcc, {'0' if i == 0 else '%%[st%d]' % i}, %[tapoff]"]
+        z += [f"v_cndmask_b32_e64 v{stg(tile) + 4 * i + j}, v{stg(tile) + 4 * i + j}, 0, vcc" for j in range(4)]
+    z += ["v_add_u32 %[tapoff], -1, %[tapoff]", f"L5_Z{k}_%=:"]
+    return z + [f"ds_write_b128 %[ldsw], v[{stg(tile) + 4 * i}:{stg(tile) + 4 * i + 3}] offset:{(tile & 1) * BUF + 8 * ROW * i}" for i in range(4)]
+
+
+def phase_hold():
+    """phase = (1, 0) at the origin (SSBD.hpp:121): while a stream's blocks precede it (%[ckoff] tiles left, per lane; %[hold] = the wave's largest) its
+    phase is put back to (1, 0) after every step -- what it multiplied zeros with in between does not matter."""
+    _uid[0] += 1
+    k = _uid[0]
+    return ["s_cmp_eq_u32 %[hold], 0", f"s_cbranch_scc1 L5_H{k}_%=", "s_sub_u32 %[hold], %[hold], 1", "v_cmp_lt_i32 vcc, 0, %[ckoff]",
+            f"v_cndmask_b32_e64 v{P}, v{P}, 1.0, vcc", f"v_cndmask_b32_e64 v{P + 1}, v{P + 1}, 0, vcc", f"v_mul_f32 v{NPIM}, -1.0, v{P + 1}",
+            "v_add_u32 %[ckoff], -1, %[ckoff]", f"L5_H{k}_%=:"]
 
 
 def ring_loads(tile):
@@ -190,6 +214,7 @@ def tile(c):
     L += adds(where[D - 1])
     L += t_and_w(u)
     L += phase_step()                                               # (two instructions at least between W[0]'s write and the swap that reads it)
+    L += phase_hold()
     L += swap_and_out(u)
     return L
 
@@ -203,6 +228,8 @@ def prologue():
     L += ring_loads(0) + ring_loads(1)
     L += [f"v_mov_b32 v{W + k}, 0" for k in range(17)] + [f"v_mov_b32 v{OB + k}, 0" for k in range(4)] + [f"v_mov_b32 v{PEAK}, 0"]
     L += ["s_waitcnt vmcnt(0) lgkmcnt(0)"]
+    # the two address operands have done their work: from here on they count pre-origin tiles (this lane's stream) / load tiles (this loader lane's first stream)
+    L += ["v_and_b32 %[ckoff], 0xffff, %[pk]", "v_lshrrev_b32 %[tapoff], 16, %[pk]"]
     L += ["s_mov_b64 vcc, %[hmask]"]
     for m in range(D):                                              # c1 = (tone.re | tone.im), c2 = (-tone.im | tone.re) by half
         L += [f"v_mov_b32 v{T}, s{64 + 2 * m}", f"v_mov_b32 v{T + 1}, s{65 + 2 * m}", f"v_cndmask_b32 v{C1 + m}, v{T}, v{T + 1}, vcc",
@@ -291,6 +318,7 @@ def fix_hazards(L):
 def program(d):
     global D
     D = d
+    _uid[0] = 0
     R, NT, SUB, NSUB = geometry()
     pro = fix_hazards(prologue())
     body = []

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in cwsl_gpu.h but not exported"
     assert sorted(api.ABI_SYMBOLS) == names, set(api.ABI_SYMBOLS) ^ set(names)
-    assert L.cwslg_abi_version() == 5
+    assert L.cwslg_abi_version() == 4
 
 
 def test_fails_loudly_without_gpu():
@@ -114,7 +114,7 @@ def test_product_library_has_one_kernel_per_job_and_no_lab_switches():
         assert switch in lab, switch
     kp, kl = _kernel_names(B.LIB), _kernel_names(B.LAB_LIB)
     assert kp < kl                                      # the lab library has everything the product has, and more
-    for lab_only in ("ring_probe_kernel", "demod_mfma1p_kernel", "demod_mfma_bf16_kernel", "demod_exact_kernel", "demod_exact2_kernel",
+    for lab_only in ("ring_probe_kernel", "demod_mfma1p_kernel", "demod_mfma_bf16_kernel", "demod_exact_kernel", "demod_exact2_kernel", "demod_exact3_kernel", "demod_exact4_kernel",
                      "ft8_sync2d_kernelE", "ft8_sync2d_v2_kernel", "ft8_candidates_kernelILi256E", "symbol_spectra_kernelI",
                      "ft4_dft567_kernelE"):
         assert not any(lab_only in k for k in kp), lab_only
@@ -124,11 +124,10 @@ def test_product_library_has_one_kernel_per_job_and_no_lab_switches():
     # (tile by decimation: 256 outputs at 192 kHz, 512 at 96 kHz, 768 at 48 kHz -- the same amount of IQ per workgroup)
     assert len(demod) == 3 and sum(t in k for k in demod for t in ("ILi16ELi256ELi256ELi0E", "ILi8ELi512ELi256ELi0E", "ILi4ELi768ELi256ELi0E")) == 3, demod
     exact = sorted(k for k in kp if "demod_exact" in k)
-    # exact mode: the stream form (round 5: lane = stream, K = 1 matrix products) at all three rates for every output whose 32-block history exists; for
-    # the first 32 outputs of a demodulator the two-stream tile form (192 kHz) / round 3's one-stream form (96 / 48 kHz)
-    assert len(exact) == 6 and sum("demod_exact4_kernelILi512ELi512E" in k for k in exact) == 1, exact
-    assert sorted(k for k in exact if "demod_exact5_kernel" in k) == sorted("_ZN5cwslg19demod_exact5_kernelILi%dEEEvPKNS_8ChanWorkEPKfiiiPy" % d for d in (16, 8, 4)), exact
-    assert sum("demod_exact3_kernelILi8ELi512ELi256E" in k or "demod_exact3_kernelILi4ELi512ELi256E" in k for k in exact) == 2, exact
+    # exact mode: ONE kernel per rate -- the stream form (round 5: lane = stream, K = 1 matrix products), a demodulator's first outputs included; the tile
+    # kernels of rounds 3 and 4 are lab-only
+    assert exact == sorted("_ZN5cwslg19demod_exact5_kernelILi%dEEEvPKNS_8ChanWorkEPKfiiiPy" % d for d in (16, 8, 4)), exact
+    assert any("demod_exact4_kernel" in k for k in kl) and any("demod_exact3_kernel" in k for k in kl)
     # FT8: Costas search + candidate selection in one launch per boundary, or (few channels) one workgroup per band + the selection
     assert any("ft8_sync_chan_kernel" in k for k in kp) and any("ft8_sync2d_v3_kernel" in k for k in kp)
-    assert len(kp) <= 40, sorted(kp)                   # round 4: + scatter_blocks_kernel (cwslg_push_iq_many); round 5: + demod_exact5_kernel<16 / 8 / 4>
+    assert len(kp) <= 37, sorted(kp)                   # round 4: + scatter_blocks_kernel (cwslg_push_iq_many); round 5: exact5<16 / 8 / 4> for exact4 + exact3<8 / 4>

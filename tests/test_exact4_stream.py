@@ -77,7 +77,7 @@ def test_exact3_stream_on_the_emulator_validates_it(seed, d):
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])
 def test_exact4_streams_hand_over_and_match_the_reference_bits(seed):
     text = _gen("gen_exact4_asm.py")
-    assert text == open(os.path.join(ROOT, "cwsl_digi_amd", "csrc", "exact4_asm.inc")).read(), "exact4_asm.inc is not the generator's output"
+    assert text == open(os.path.join(ROOT, "cwsl_digi_amd", "csrc", "lab", "exact4_asm.inc")).read(), "exact4_asm.inc is not the generator's output"
     row_bytes = int(re.search(r"#define EXACT4_ASM_ROW_BYTES (\d+)", text).group(1))
     split = int(re.search(r"#define EXACT4_ASM_SPLIT (\d+)", text).group(1))
     lds, taps2, want = _problem(seed, row_bytes)

@@ -38,11 +38,11 @@ def _tap_block_of_row(i):
     return (i & 3) + 4 * (i >> 3) + 16 * ((i >> 2) & 1)
 
 
-def _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, ring_shift_blocks, D=16):
+def _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, ring_shift_blocks, D=16, q_first=32):
     text = _gen()
     FS = 12000 * D
     row, buf, per_iter = _define(text, "EXACT5_ASM_ROW_BYTES"), _define(text, "EXACT5_ASM_BUF_BYTES"), _define(text, "EXACT5_D%d_TILES_PER_ITER" % D)
-    q_first = 32                                              # the demodulator's first 32 outputs are not this kernel's (no 32-block history)
+    # q_first = block index (since the demodulator's creation) of the wave's first output; below 32, stream 0's warm-up reaches before the origin
     total_blocks = q_first + n_blocks
     n_samp = total_blocks * D
     iq = oracle.synth_iq(seed, n_samp, FS, tones_hz=[f_hz + 700.0, f_hz + 2250.5], amp=1.7e4)
@@ -90,17 +90,20 @@ def _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, ring_shift_blocks, D=1
     ops["pc16"] = ("v", ((lane & 7) * 16).astype(U))
     ops["ldsr"] = ("v", (j * row).astype(U))
     ops["ldsw"] = ("v", ((lane >> 3) * row + (lane & 7) * 16).astype(U))
-    ops["ckoff"] = ("v", (((q_first + j * seg_len - 32) // 4) * 8).astype(U))
+    ops["ckoff"] = ("v", (np.maximum(q_first + j * seg_len - 32, 0) // 4 * 8).astype(U))
     ops["tapoff"] = ("v", np.array([4 * D * _tap_block_of_row(int(i)) for i in j], U))
     ops["rem"] = ("v", n_out.astype(U))
     ops["outoff"] = ("v", (j * seg_len * 4).astype(U))
     ops["peak"] = ("v", np.zeros(64, U))
+    # pre-origin counts: tiles of this lane's stream (low half), load tiles of this LOADER lane's first stream (high half)
+    ops["pk"] = ("v", (np.maximum(32 - q_first - j * seg_len, 0) | ((np.maximum(32 - q_first - (lane >> 3) * seg_len, 0) * D // 16) << 16)).astype(U))
     sign = F(1.0 if usb else -1.0)
     for name in ("ring", "taps", "tone", "ckpt", "out"):
         ops[name] = ("s64", base[name])
     ops.update(incre=("s", int(np.array(inc.real, F).view(U))), incim=("s", int(np.array(inc.imag, F).view(U))),
                sign=("s", int(np.array(sign, F).view(U))), nsign=("s", int(np.array(-sign, F).view(U))),
-               hmask=("s64", 0xFFFFFFFF00000000), esave=("s64", 0), warm=("s", _define(text, "EXACT5_ASM_WARM_STORES")), iters=("s", (32 + int(n_out.max()) + per_iter - 1) // per_iter))
+               hmask=("s64", 0xFFFFFFFF00000000), esave=("s64", 0),
+               hold=("s", max(0, 32 - q_first)), holdlt=("s", max(0, 32 - q_first) * D // 16), st1=("s", seg_len * D // 2), st2=("s", seg_len * D), st3=("s", 3 * seg_len * D // 2), warm=("s", _define(text, "EXACT5_ASM_WARM_STORES")), iters=("s", (32 + int(n_out.max()) + per_iter - 1) // per_iter))
     w = Wave(mem, 2 * buf, ops)
     w.run(_lines(text, "EXACT5_D%d_PROLOGUE_ASM" % D) + _lines(text, "EXACT5_D%d_LOOP_ASM" % D) + _lines(text, "EXACT5_D%d_EPILOGUE_ASM" % D))
     got = mem[base["out"]:base["out"] + len(parts["out"])].view(F)
@@ -127,6 +130,17 @@ def test_exact5_wave_program_writes_the_reference_bits(oracle, d, f_hz, usb, see
     regs = [int(x) for l in loop for x in re.findall(r"\bv(\d+)\b", l)] + [int(x) for l in loop for x in re.findall(r"v\[\d+:(\d+)\]", l)]
     vtop = int(re.search(r"#define EXACT5_ASM_VTOP (\d+)", text).group(1))              # fixed registers: v0 .. VTOP - 1 and the second staging set v240 .. v255
     assert all(r < vtop or 240 <= r <= 255 for r in regs)
+
+
+@pytest.mark.parametrize("d,q_first,shift", [(16, 0, 0), (16, 12, -8), (16, 28, 40), (8, 0, 0), (8, 20, -4), (4, 0, 0), (4, 8, -12)])
+def test_exact5_first_outputs_of_a_demodulator(oracle, d, q_first, shift):
+    """The wave whose first output is one of the demodulator's first 32: stream 0's warm-up blocks precede the origin (x[i < 0] = 0, phase (1, 0) at block 0:
+    SSBD.hpp:117-121).  Their rows -- here junk, or the END of the ring's data when the origin sits at the ring's start -- are zeroed on their way into LDS
+    and the stream's phase is held; the other 31 streams of the wave run as ever.  Bits of every output, from the very first."""
+    seg_len, n_blocks = 8, 200
+    got, want, n_out, peak, w, text = _run_wave(oracle, 9000 - 300 * q_first, True, seg_len, n_blocks, 40 + q_first, shift, D=d, q_first=q_first)
+    assert np.array_equal(got[:n_blocks].view(U), want[:n_blocks].view(U)), np.nonzero(got[:n_blocks].view(U) != want[:n_blocks].view(U))[0][:8]
+    assert (got[n_blocks:] == F(3.0e8)).all()
 
 
 def test_exact5_inc_file_is_the_generators_output():

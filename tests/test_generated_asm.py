@@ -15,7 +15,7 @@ def _lines(text, macro):
 
 
 def test_committed_files_are_the_generators_output():
-    for script, inc in (("gen_sync2d_asm.py", "sync2d_asm.inc"), ("gen_exact3_asm.py", "exact3_asm.inc"), ("gen_exact4_asm.py", "exact4_asm.inc")):
+    for script, inc in (("gen_sync2d_asm.py", "sync2d_asm.inc"), ("gen_exact3_asm.py", "lab/exact3_asm.inc"), ("gen_exact4_asm.py", "lab/exact4_asm.inc")):
         assert _gen(script) == open(os.path.join(ROOT, "cwsl_digi_amd", "csrc", inc)).read(), inc
 
 

@@ -105,10 +105,8 @@ def test_no_product_kernel_has_flat_memory_instructions(product_isa):
 
 
 def test_exact_kernel_register_budget(product_isa):
-    """192 kHz exact mode.  demod_exact4_kernel (a demodulator's first 32 outputs): eight waves per tile image, two images per CU = four waves
-    per SIMD, i.e. at most 128 VGPRs per lane.  demod_exact5_kernel: two waves per SIMD = at most 256 (its generated statement fixes 241 of
-    them; the rest are the statement's operands)."""
-    k = [v for n, v in product_isa.items() if "demod_exact4_kernel" in n]
-    assert len(k) == 1 and k[0]["vgpr"] <= 128, k
+    """Exact mode, demod_exact5_kernel<16 / 8 / 4>: two waves per SIMD = at most 256 VGPRs (the generated statement fixes 241 of them; the rest are its
+    operands), 36 KB of LDS per four-wave workgroup (two per CU); no other exact-mode kernel in the product."""
     k = [v for n, v in product_isa.items() if "demod_exact5_kernel" in n]                # 192 / 96 / 48 kHz
     assert len(k) == 3 and all(v["vgpr"] <= 256 for v in k), k
+    assert not [n for n in product_isa if "demod_exact3" in n or "demod_exact4" in n]

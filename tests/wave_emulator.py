@@ -166,9 +166,9 @@ class Wave:
                 if op == "s_branch" or (op == "s_cbranch_scc1") == bool(self.scc):
                     pc = labels[toks[0]]
                 continue
-            if op in ("s_cmp_gt_u32", "s_cmp_lg_u32"):
+            if op in ("s_cmp_gt_u32", "s_cmp_lg_u32", "s_cmp_eq_u32"):
                 a, b = [self.s[re.fullmatch(r"%\[(\w+)\]", t).group(1)] if t.startswith("%") else int(t) for t in toks]
-                self.scc = int(a > b) if op == "s_cmp_gt_u32" else int(a != b)
+                self.scc = int(a > b) if op == "s_cmp_gt_u32" else int(a != b) if op == "s_cmp_lg_u32" else int(a == b)
                 continue
             if op == "s_sub_u32":
                 name = re.fullmatch(r"%\[(\w+)\]", toks[0]).group(1)
@@ -277,7 +277,7 @@ class Wave:
                 assert toks[0] == "vcc"
                 self.vcc = np.where(self.exec, r, False)
                 continue
-            if op == "v_cndmask_b32":
+            if op in ("v_cndmask_b32", "v_cndmask_b32_e64"):
                 a, b = self._src32(toks[1]), self._src32(toks[2])
                 assert toks[3] == "vcc"
                 self._wr(toks[0], np.where(self.vcc, b, a))
@@ -285,9 +285,10 @@ class Wave:
             if op == "v_mov_b32":
                 self._wr(toks[0], self._src32(toks[1]))
                 continue
-            if op in ("v_xor_b32", "v_add_u32"):
+            if op in ("v_xor_b32", "v_add_u32", "v_and_b32", "v_lshrrev_b32"):
                 a, b = self._src32(toks[1]), self._src32(toks[2])
-                self._wr(toks[0], (a ^ b) if op == "v_xor_b32" else (a + b).astype(U))
+                r = {"v_xor_b32": lambda: a ^ b, "v_add_u32": lambda: (a + b).astype(U), "v_and_b32": lambda: a & b, "v_lshrrev_b32": lambda: b >> (a & U(31))}[op]()
+                self._wr(toks[0], r)
                 continue
             if op in ("v_mul_f32", "v_add_f32", "v_sub_f32", "v_max_f32"):
                 a, b = _f(self._src32(toks[1])), _f(self._src32(toks[2]))
