@@ -52,7 +52,7 @@ namespace cwslg {
 
 // ---------------------------------------------------------------------------------------------
 constexpr int kTile = 256;             // outputs per demod workgroup
-constexpr int kTileExact = 512;        // ... of demod_exact3_kernel (two outputs per thread, 256 threads; two tiles of 72.5 KB per CU)
+constexpr int kTileExact = 512;        // ... of the lab library's demod_exact3_kernel / demod_exact4_kernel (rounds 3-4)
 constexpr int kExactThreads = kTileExact / 2;
 constexpr int kTileMax = 768;          // the largest tile any demod kernel walks a channel with (sizes the phasor checkpoint tables)
 // Fast mode: outputs per workgroup by decimation.  A tile is D (T + 31) samples, so a fixed T = 256 makes the tiles of the lower rates small
@@ -234,7 +234,7 @@ struct cwslg_ctx {
     std::vector<Receiver> rxs;
     std::vector<Channel> chans;
     std::map<uint32_t, float *> d_taps;            // per sample rate
-    std::map<uint32_t, float *> d_taps2;           // the same taps interleaved for demod_exact3_kernel: [33][D][2] = (h[m + D n], h[m + D (n-1)])
+    std::map<uint32_t, float *> d_taps2;           // (lab library only) the same taps interleaved for demod_exact3_kernel: [33][D][2] = (h[m + D n], h[m + D (n-1)])
     const char *demod_kernel_name = "";           // the demod kernel the last launch used (cwslg_demod_kernel_name)
     std::map<uint32_t, std::vector<float>> h_taps;
     std::map<std::tuple<uint32_t, int32_t, int, size_t>, PhasorTable> phasors;
@@ -265,14 +265,14 @@ struct cwslg_ctx {
     std::atomic<unsigned> batch_next{0};
     std::atomic<uint64_t> push_calls_a{0}, push_host_ns_a{0};   // cwslg_push_iq's share of stats.push_calls / push_host_ms
     // in-kernel clock of timed exact-mode demod launches: a host-mapped ring of (s_memtime, s_memrealtime) pairs at the start and the end of
-    // one workgroup's life (demod_exact3_kernel's `clk`), read back by drain_spans
+    // one wave's / workgroup's life (the demod kernels' `clk` argument), read back by drain_spans
     unsigned long long *clk_h = nullptr, *clk_dev = nullptr;
     unsigned clk_head = 0, clk_tail = 0;
     unsigned exact5_seg_cap = kExact5SegCap, exact5_seg_force = 0;
-    bool use_exact5 = true;            // 192 kHz exact mode: demod_exact5_kernel (lab build: CWSLG_DEMOD_VARIANT=27 keeps demod_exact4_kernel for A/B)
+    bool use_exact5 = true;            // exact mode: demod_exact5_kernel<D> (lab build: a non-zero CWSLG_DEMOD_VARIANT selects round 3/4's tile kernels instead)
     unsigned stat_gen = 0;             // bumped by cwslg_reset_stats: work timed before a reset is not folded into the figures read after it
     double clk_sum_mhz = 0.0;
-    int occ_cache[3][5] = {};          // launch_demod: resident demod_exact3 workgroups per CU by (D, tile form); per context = per device
+    int occ_cache[3][5] = {};          // (lab library) launch_demod: resident demod_exact3 / exact4 workgroups per CU by (D, tile form); per context = per device
     // launch descriptors
     WorkBuf wb[kWorkBufs];
     int wb_next = 0;
@@ -631,14 +631,14 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
                       (uint64_t)w.ring_cap * 8 < (1ull << 32);
         if (aligned) return launch_exact5<D>(c, works, max_blocks, fs, tile_major);
     }
-    // the descriptors, then (64-byte aligned) the eight per-XCD work counters of demod_exact3_kernel, zero at launch
+    // the descriptors, then (64-byte aligned) eight per-XCD work counters (the lab library's persistent tile kernels draw from them), zero at launch
     const size_t ctr_off = (works.size() * sizeof(ChanWork) + 63) & ~size_t(63);
     WorkBuf *w = acquire_workbuf(c, ctr_off + 64);
     if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
     std::memcpy(w->h, works.data(), works.size() * sizeof(ChanWork));
     std::memset((char *)w->h + works.size() * sizeof(ChanWork), 0, ctr_off + 64 - works.size() * sizeof(ChanWork));
     HIPCHK(c, upload_workbuf(c, w, ctr_off + 64));
-    // product build: ONE kernel per job -- demod_exact3_kernel in exact mode (the default), demod_kernel in fast mode.  The measured
+    // product build: ONE kernel per job -- demod_exact5_kernel<D> in exact mode (the default; launched above), demod_kernel in fast mode.  The measured
     // alternatives (CWSLG_DEMOD_VARIANT) exist in the lab build only (-DCWSLG_LAB=1 -> libcwslgpu_lab.so).
     int tile = c->exact ? kTileExact : fast_tile(D);
 #if CWSLG_LAB
@@ -1095,7 +1095,7 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
     // lab build only: the switches that select a measured alternative.  The product library reads no environment variable that
     // changes a kernel or the order of its arithmetic.
     if (const char *v = std::getenv("CWSLG_DEMOD_VARIANT")) c->demod_variant = std::atoi(v);
-    if (c->demod_variant != 0) c->use_exact5 = false;          // every measured alternative is an alternative to round 4's launch shape (27: exact4 itself, for A/B)
+    if (c->demod_variant != 0) c->use_exact5 = false;          // every measured alternative is an alternative to the tile-shaped launch (26 / 27: round 3's / round 4's exact kernels themselves, for A/B)
     if (const char *v = std::getenv("CWSLG_EXACT5_SEG")) c->exact5_seg_cap = (unsigned)std::max(4, std::atoi(v));        // at most this many outputs per stream
     if (const char *v = std::getenv("CWSLG_EXACT5_SEG_FORCE")) c->exact5_seg_force = (unsigned)std::max(4, std::atoi(v)) / 4 * 4;   // exactly this many (tests)
     if (const char *v = std::getenv("CWSLG_UPLOAD")) c->upload_by_dma = std::strcmp(v, "dma") == 0;

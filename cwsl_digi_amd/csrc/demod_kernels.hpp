@@ -161,7 +161,7 @@ __device__ __forceinline__ float2 cmul_exact(float2 a, float2 b)
 }
 // The same four products, the same difference and sum (each rounded on its own: un-fused), as THREE packed operations: (ac, ad),
 // (bd, bc), then (ac - bd, ad + bc) with the first component's addend negated (a + (-b) is a - b exactly).  Half the issue slots
-// of the six scalar operations; used where what bounds the code is what one wave can issue (demod_exact3_kernel's mix).
+// of the six scalar operations; used where what bounds the code is what one wave can issue (the mix of the lab library's demod_exact3_kernel).
 __device__ __forceinline__ v2f cmul_exact_pk(v2f a, v2f b)
 {
     v2f p1, p2, r;
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
     int item = xcd * per_xcd + slot;
     if (item >= hi_item) return;
     // The shader clock in the middle of a timed launch (cwslg_set_timing): ONE workgroup, the one in the middle of the grid, reads s_memtime and
-    // s_memrealtime when it starts and when it ends (see demod_exact3_kernel); untimed launches pass clk = nullptr and execute none of it.
+    // s_memrealtime when it starts and when it ends (see demod_exact5_kernel); untimed launches pass clk = nullptr and execute none of it.
     const bool clk_wg = clk != nullptr && blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0;
     if (clk_wg) {
         unsigned long long t_, r_;
