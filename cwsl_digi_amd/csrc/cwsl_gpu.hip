@@ -628,7 +628,7 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
         bool aligned = true;
         for (const ChanWork &w : works)
             aligned = aligned && w.q_first >= 0 && w.q_first % 4 == 0 && w.n_blocks % 4 == 0 && w.lo_mod % (4 * D) == 0 && w.ring_cap % (4 * D) == 0 &&
-                      (uint64_t)w.ring_cap * 8 < (1ull << 32);
+                      (uint64_t)w.ring_cap * 8 < (1ull << 32) - 4096;      // (32-bit byte offsets into the ring, advanced by up to 512 before the wrap test)
         if (aligned) return launch_exact5<D>(c, works, max_blocks, fs, tile_major);
     }
     // the descriptors, then (64-byte aligned) eight per-XCD work counters (the lab library's persistent tile kernels draw from them), zero at launch
@@ -1217,7 +1217,8 @@ int cwslg_receiver_open(cwslg_ctx *c, uint32_t fs, uint32_t iq_len, int32_t lo_h
     uint64_t cap = blocks * iq_len;
     const uint64_t min_cap = 2ull * (D * (kTileMax + 31)) + 64;    // the tile loader wraps at most once (whatever tile the mode's kernel walks: kTileMax)
     if (cap < min_cap) cap = (min_cap + iq_len - 1) / iq_len * iq_len;
-    if (cap > 0xFFFFFFF0ull) return fail(c, CWSLG_ERR_ARG, "ring too large");
+    // demod_exact5_kernel addresses the ring with 32-bit byte offsets: 512 M samples (44 minutes at 192 kHz) less a margin
+    if (cap * sizeof(float2) >= (1ull << 32) - 4096) return fail(c, CWSLG_ERR_ARG, "ring too large (%llu samples: a ring is shorter than 4 GiB)", (unsigned long long)cap);
     rx.cap = (uint32_t)cap;
     HIPCHK(c, hipMalloc(&rx.d_ring, (size_t)rx.cap * sizeof(float2)));
     rx.open = true;

@@ -92,7 +92,8 @@ int  cwslg_set_exact(cwslg_ctx *ctx, int on);
 
 /* ---- receivers: replaces Receiver::init + the SPMC ring (Receiver.hpp:115-163, ring_buffer_spmc.h) ----
  * fs, iq_len, lo_hz are SM_HDR.SampleRate / BlockInSamples / L0 (SharedMemory.h:10-21, Receiver.hpp:86-88).
- * ring_blocks = 0 selects the reference depth 3*(fs/iq_len+1) blocks (Receiver.hpp:132).  The ring lives in HBM. */
+ * ring_blocks = 0 selects the reference depth 3*(fs/iq_len+1) blocks (Receiver.hpp:132).  The ring lives in HBM and is shorter than 4 GiB
+ * (512 M samples: CWSLG_ERR_ARG beyond). */
 int cwslg_receiver_open(cwslg_ctx *ctx, uint32_t fs, uint32_t iq_len, int32_t lo_hz,
                         uint32_t ring_blocks, int *rx_id);
 int cwslg_receiver_close(cwslg_ctx *ctx, int rx_id);
