@@ -422,6 +422,16 @@ __device__ __forceinline__ void decode_item(const ChanWork *sd, int tile, TileCt
     if (c.n_out == 0) { c.base = 0; c.ck_first = 0; c.pb0 = 0; c.first_valid = 0; }
 }
 
+// Cache policy of the IQ ring's loads in demod_kernel (round 5 A/B, scripts/gpu_r5_fast_nt.sh): a private stream is read once (31 of every 287 blocks twice:
+// the tile halo, by the neighbouring workgroup), so non-temporal is a candidate; demod_exact5_kernel gained 2.7 % from it.
+#ifndef CWSLG_RING_NT
+#define CWSLG_RING_NT 0
+#endif
+__device__ __forceinline__ v4f ring_ld(const CWSLG_GLOBAL v4f *p)
+{
+    return CWSLG_RING_NT ? __builtin_nontemporal_load(p) : *p;
+}
+
 template <int D, int T, int NT>
 __device__ __forceinline__ void issue_tile_loads(const TileCtx<D, T> &c, int tid, v4f (&xs)[(DemodGeom<D, T>::NSAMP + 2 * NT - 1) / (2 * NT)],
                                                  float2 &ck, v4f &tn)
@@ -434,10 +444,10 @@ __device__ __forceinline__ void issue_tile_loads(const TileCtx<D, T> &c, int tid
         // tid, no per-load wrap arithmetic (it was 6 VALU instructions per load)
         const CWSLG_GLOBAL v4f *p = ring4 + (c.base >> 1);
 #pragma unroll
-        for (int it = CWSLG_DIAG_NOHALO; it < NIT - 1; ++it) xs[it] = p[tid + it * NT];
+        for (int it = CWSLG_DIAG_NOHALO; it < NIT - 1; ++it) xs[it] = ring_ld(p + tid + it * NT);
         int r = 2 * tid + (NIT - 1) * 2 * NT;
         if (r > Geo::NSAMP - 2) r = Geo::NSAMP - 2;            // clamp: the load is unconditional
-        xs[NIT - 1] = p[r >> 1];
+        xs[NIT - 1] = ring_ld(p + (r >> 1));
     } else {
 #pragma unroll
         for (int it = CWSLG_DIAG_NOHALO; it < NIT; ++it) {
@@ -445,7 +455,7 @@ __device__ __forceinline__ void issue_tile_loads(const TileCtx<D, T> &c, int tid
             if (r > Geo::NSAMP - 2) r = Geo::NSAMP - 2;
             unsigned idx = c.base + (unsigned)r;
             if (idx >= c.cap) idx -= c.cap;
-            xs[it] = ring4[idx >> 1];
+            xs[it] = ring_ld(ring4 + (idx >> 1));
         }
     }
     // unconditional (clamped) checkpoint load: a predicated load would be merged with a default right away,
