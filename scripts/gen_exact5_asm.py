@@ -43,6 +43,12 @@ GROUPED = os.environ.get("X5_GROUPED", "1") == "1"            # mix and sum * ph
 # the ring is read once: non-temporal (same-box A/B: 2.5-2.8 % of the launch).  X5_RING_NT: "0" none, "1" nt, or the modifiers themselves ("sc1 nt", ...)
 _nt = os.environ.get("X5_RING_NT", "1")
 RING_NT = "" if _nt == "0" else (" nt" if _nt == "1" else " " + _nt.replace("_", " ").strip())
+# X5_DMA=1: the rows go from HBM straight into LDS (global_load_lds_dwordx4: no staging registers, no ds_write); the LDS image is then lane-linear
+# (32 unpadded rows of 128 bytes per load tile, four buffers), conflict-free through a swizzle on the SOURCE side: lane l of a load fetches piece
+# (l & 7) ^ f(row) of its row, f(row) = (row >> 1) & 7, and lane j reads piece k of its row from slot k ^ f(j).
+DMA = os.environ.get("X5_DMA", "0") == "1"
+AK, ZQ = 196, 204                                                  # DMA form: v196-v203 the eight read addresses of the lane's row, v204-v207 a quad of zeros
+DBUF = 4096                                                        # DMA form: bytes of one load tile in LDS (32 rows x 128)
 D = 16                                                             # samples per block = Fs / 12 kHz: 16 (192 kHz), 8 (96 kHz), 4 (48 kHz); set by program(d)
 STG2 = 240                                                         # the second staging set, at the top of the file (the operands sit between VTOP and it)
 ROW = 144                                                          # LDS row pitch: 16 samples + 16 bytes (conflict-free 16-byte reads, lane = row)
@@ -87,6 +93,9 @@ def sub_read(c, sub):
     """Sub-read `sub` of compute tile c of the iteration (c may be NT: the next iteration's tile 0): SUB samples from the tile's part of its row."""
     R, NT, SUB, NSUB = geometry()
     lt = c // R                                                    # load tile; its LDS buffer is lt & 1 (four load tiles per iteration: the parity carries over)
+    if DMA:                                                        # four buffers, one per load tile of the iteration; piece k of the row through address register k
+        k0 = ((c % R) * 8 * D + sub * 8 * SUB) // 16
+        return [f"ds_read_b128 v[{IN + 4 * k}:{IN + 4 * k + 3}], v{AK + k0 + k} offset:{(lt & 3) * DBUF}" for k in range(SUB // 2)]
     off = (lt & 1) * BUF + (c % R) * 8 * D + sub * 8 * SUB
     return [f"ds_read_b128 v[{IN + 4 * k}:{IN + 4 * k + 3}], %[ldsr] offset:{off + 16 * k}" for k in range(SUB // 2)]
 
@@ -105,6 +114,12 @@ def lds_write(tile):
     FIRST stream's pre-origin load tiles (%[tapoff], recycled after the prologue); its i-th stream starts 8 i streams = %[st<i>] load tiles later."""
     _uid[0] += 1
     k = _uid[0]
+    if DMA:                                                        # the rows are in LDS already: overwrite the pre-origin ones there (loader lane l owns bytes 16 l .. of each load)
+        z = ["s_cmp_eq_u32 %[holdlt], 0", f"s_cbranch_scc1 L5_Z{k}_%=", "s_sub_u32 %[holdlt], %[holdlt], 1"]
+        for i in range(4):
+            z += [f"v_cmp_lt_i32 vcc, {'0' if i == 0 else '%%[st%d]' % i}, %[tapoff]", "s_and_saveexec_b64 %[esave], vcc",
+                  f"ds_write_b128 %[ldsw], v[{ZQ}:{ZQ + 3}] offset:{(tile & 3) * DBUF + 1024 * i}", "s_mov_b64 exec, %[esave]"]
+        return z + ["v_add_u32 %[tapoff], -1, %[tapoff]", f"L5_Z{k}_%=:"]
     z = ["s_cmp_eq_u32 %[holdlt], 0", f"s_cbranch_scc1 L5_Z{k}_%=", "s_sub_u32 %[holdlt], %[holdlt], 1"]
     for i in range(4):
         z += [f"v_cmp_lt_i32 vcc, {'0' if i == 0 else '%%[st%d]' % i}, %[tapoff]"]
@@ -128,6 +143,12 @@ def ring_loads(tile):
     bytes (64 samples = 4 blocks: the push granularity), so four load tiles share one offset (immediates 0 / 128 / 256 / 384) and the offsets advance --
     and wrap -- once per iteration.  96 / 48 kHz: the guaranteed alignment is 4 blocks = 256 / 128 bytes, so the offsets advance after every load tile."""
     imm = 128 * (tile & 3) if D == 16 else 0
+    if DMA:                                                        # M0 = where the load's 1024 bytes go; the immediate would move BOTH addresses, so 192 kHz uses four ring bases
+        L = []
+        for i in range(4):
+            L += [f"s_add_u32 m0, %[ldsb], {(tile & 3) * DBUF + 1024 * i}", "s_nop 0",
+                  f"global_load_lds_dwordx4 %[off{i}], %[ring{(tile & 3) if D == 16 else 0}]{RING_NT}"]
+        return L if D == 16 else L + ["s_nop 0"] + advance_offsets()
     L = [f"global_load_dwordx4 v[{stg(tile) + 4 * i}:{stg(tile) + 4 * i + 3}], %[off{i}], %[ring] offset:{imm}{RING_NT}" for i in range(4)]
     return L if D == 16 else L + ["s_nop 0"] + advance_offsets()
 
@@ -136,7 +157,8 @@ def advance_offsets():
     step = "0x200" if D == 16 else "0x80"
     out = []
     for i in range(4):                                             # the next 512 / 128 bytes of each stream; the ring's end is a multiple of that away from a stream's start
-        out += [f"v_add_u32 %[off{i}], {step}, %[off{i}]", f"v_cmp_eq_u32 vcc, %[off{i}], %[capl]", f"v_cndmask_b32 %[off{i}], %[off{i}], %[pc16], vcc"]
+        par = str(i & 1) if DMA else ""                                # (DMA form: the swizzled piece of a lane differs between even and odd loads)
+        out += [f"v_add_u32 %[off{i}], {step}, %[off{i}]", f"v_cmp_eq_u32 vcc, %[off{i}], %[capl{par}]", f"v_cndmask_b32 %[off{i}], %[off{i}], %[pc16{par}], vcc"]
     return out
 
 
@@ -235,6 +257,10 @@ def prologue():
         L += [f"v_mov_b32 v{T}, s{64 + 2 * m}", f"v_mov_b32 v{T + 1}, s{65 + 2 * m}", f"v_cndmask_b32 v{C1 + m}, v{T}, v{T + 1}, vcc",
               f"v_xor_b32 v{T + 2}, 0x80000000, v{T + 1}", f"v_cndmask_b32 v{C2 + m}, v{T + 2}, v{T}, vcc"]
     L += [f"v_mul_f32 v{NPIM}, -1.0, v{P + 1}"]
+    if DMA:                                                         # slot of piece k in this lane's row: k ^ f(row); %[fj16] = f(row) << 4
+        for k in range(8):
+            L += [f"v_xor_b32 v{AK + k}, {16 * k}, %[fj16]", f"v_add_u32 v{AK + k}, %[ldsr], v{AK + k}"]
+        L += [f"v_mov_b32 v{ZQ + j}, 0" for j in range(4)]
     L += lds_write(0)
     L += ring_loads(2)
     L += sub_read(0, 0)
@@ -321,20 +347,24 @@ def program(d):
     _uid[0] = 0
     R, NT, SUB, NSUB = geometry()
     pro = fix_hazards(prologue())
+    if DMA:
+        pro = ["s_mov_b32 %[m0keep], m0"] + pro
     body = []
     for c in range(NT):
         body += tile(c)
     body = fix_hazards(body + [mfma(S, 0)])[:-1]                    # (the loop wraps: the hazards of the first MFMA against the body's end hold as well)
     loop = ["L5_LOOP_%=:"] + body + ["s_sub_u32 %[iters], %[iters], 1", "s_cmp_lg_u32 %[iters], 0", "s_cbranch_scc1 L5_LOOP_%="]
-    epi = store_block("E") + ["s_waitcnt vmcnt(0) lgkmcnt(0)", f"v_mov_b32 %[peak], v{PEAK}"]
+    epi = store_block("E") + ["s_waitcnt vmcnt(0) lgkmcnt(0)", f"v_mov_b32 %[peak], v{PEAK}"] + (["s_mov_b32 m0, %[m0keep]"] if DMA else [])
     return pro, loop, epi
 
 
 def main():
     w = sys.stdout.write
     w("// GENERATED by scripts/gen_exact5_asm.py -- do not edit.  See that script and demod_exact5_kernel (demod_kernels.hpp).\n")
-    w(f"#define EXACT5_ASM_ROW_BYTES {ROW}\n#define EXACT5_ASM_BUF_BYTES {BUF}\n#define EXACT5_ASM_WARM_STORES 9\n#define EXACT5_ASM_VTOP {VTOP}\n")
-    w("#define EXACT5_ASM_CLOBBERS " + ", ".join(f'"v{i}"' for i in list(range(VTOP)) + list(range(STG2, STG2 + 16))) + ", " +
+    w(f"#define EXACT5_ASM_DMA {int(DMA)}\n")
+    w(f"#define EXACT5_ASM_ROW_BYTES {128 if DMA else ROW}\n#define EXACT5_ASM_BUF_BYTES {DBUF if DMA else BUF}\n#define EXACT5_ASM_NBUF {4 if DMA else 2}\n"
+      f"#define EXACT5_ASM_WARM_STORES 9\n#define EXACT5_ASM_VTOP {VTOP}\n")
+    w("#define EXACT5_ASM_CLOBBERS " + ", ".join(f'"v{i}"' for i in list(range(VTOP)) + ([] if DMA else list(range(STG2, STG2 + 16)))) + ", " +
       ", ".join(f'"s{i}"' for i in range(64, 96)) + ', "vcc", "scc", "memory"\n')
     for d in (16, 8, 4):
         pro, loop, epi = program(d)

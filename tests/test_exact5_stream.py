@@ -17,8 +17,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F, U = np.float32, np.uint32
 
 
-def _gen():
-    return subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_exact5_asm.py")], check=True, capture_output=True, text=True).stdout
+def _gen(dma=None):
+    env = dict(os.environ)
+    if dma is not None:
+        env["X5_DMA"] = "1" if dma else "0"
+    return subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_exact5_asm.py")], check=True, capture_output=True, text=True, env=env).stdout
 
 
 def _lines(text, macro):
@@ -38,8 +41,9 @@ def _tap_block_of_row(i):
     return (i & 3) + 4 * (i >> 3) + 16 * ((i >> 2) & 1)
 
 
-def _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, ring_shift_blocks, D=16, q_first=32):
-    text = _gen()
+def _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, ring_shift_blocks, D=16, q_first=32, dma=None):
+    text = _gen(dma)
+    dma = bool(_define(text, "EXACT5_ASM_DMA"))
     FS = 12000 * D
     row, buf, per_iter = _define(text, "EXACT5_ASM_ROW_BYTES"), _define(text, "EXACT5_ASM_BUF_BYTES"), _define(text, "EXACT5_D%d_TILES_PER_ITER" % D)
     # q_first = block index (since the demodulator's creation) of the wave's first output; below 32, stream 0's warm-up reaches before the origin
@@ -84,12 +88,23 @@ def _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, ring_shift_blocks, D=1
         return (((qs * D + shift) % cap) * 8).astype(np.int64)
     n_out = np.clip(n_blocks - j * seg_len, 0, seg_len)
     ops = {}
-    for i in range(4):
-        ops["off%d" % i] = ("v", (stream_pos_bytes(8 * i + (lane >> 3)) + (lane & 7) * 16).astype(U))
-    ops["capl"] = ("v", (cap * 8 + (lane & 7) * 16).astype(U))
-    ops["pc16"] = ("v", ((lane & 7) * 16).astype(U))
-    ops["ldsr"] = ("v", (j * row).astype(U))
-    ops["ldsw"] = ("v", ((lane >> 3) * row + (lane & 7) * 16).astype(U))
+    if dma:                                                    # the source-side swizzle: lane l of load i fetches piece (l & 7) ^ f(row) of row 8 i + (l >> 3), f(row) = (row >> 1) & 7
+        piece = lambda i: ((lane & 7) ^ (((8 * i + (lane >> 3)) >> 1) & 7)) * 16
+        for i in range(4):
+            ops["off%d" % i] = ("v", (stream_pos_bytes(8 * i + (lane >> 3)) + piece(i)).astype(U))
+        for par in (0, 1):
+            ops["capl%d" % par] = ("v", (cap * 8 + piece(par)).astype(U))
+            ops["pc16%d" % par] = ("v", piece(par).astype(U))
+        ops["ldsr"] = ("v", (j * 128).astype(U))
+        ops["ldsw"] = ("v", (lane * 16).astype(U))
+        ops["fj16"] = ("v", (((j >> 1) & 7) * 16).astype(U))
+    else:
+        for i in range(4):
+            ops["off%d" % i] = ("v", (stream_pos_bytes(8 * i + (lane >> 3)) + (lane & 7) * 16).astype(U))
+        ops["capl"] = ("v", (cap * 8 + (lane & 7) * 16).astype(U))
+        ops["pc16"] = ("v", ((lane & 7) * 16).astype(U))
+        ops["ldsr"] = ("v", (j * row).astype(U))
+        ops["ldsw"] = ("v", ((lane >> 3) * row + (lane & 7) * 16).astype(U))
     ops["ckoff"] = ("v", (np.maximum(q_first + j * seg_len - 32, 0) // 4 * 8).astype(U))
     ops["tapoff"] = ("v", np.array([4 * D * _tap_block_of_row(int(i)) for i in j], U))
     ops["rem"] = ("v", n_out.astype(U))
@@ -100,11 +115,16 @@ def _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, ring_shift_blocks, D=1
     sign = F(1.0 if usb else -1.0)
     for name in ("ring", "taps", "tone", "ckpt", "out"):
         ops[name] = ("s64", base[name])
+    if dma:
+        for k in range(4):
+            ops["ring%d" % k] = ("s64", base["ring"] + 128 * k)
+        ops.update(ldsb=("s", 0), m0keep=("s", 0))
     ops.update(incre=("s", int(np.array(inc.real, F).view(U))), incim=("s", int(np.array(inc.imag, F).view(U))),
                sign=("s", int(np.array(sign, F).view(U))), nsign=("s", int(np.array(-sign, F).view(U))),
                hmask=("s64", 0xFFFFFFFF00000000), esave=("s64", 0),
                hold=("s", max(0, 32 - q_first)), holdlt=("s", max(0, 32 - q_first) * D // 16), st1=("s", seg_len * D // 2), st2=("s", seg_len * D), st3=("s", 3 * seg_len * D // 2), warm=("s", _define(text, "EXACT5_ASM_WARM_STORES")), iters=("s", (32 + int(n_out.max()) + per_iter - 1) // per_iter))
-    w = Wave(mem, 2 * buf, ops)
+    w = Wave(mem, _define(text, "EXACT5_ASM_NBUF") * buf, ops)
+    assert w.n_operand_vgprs <= (31 if dma else 15)            # what is left beside the program's fixed registers
     w.run(_lines(text, "EXACT5_D%d_PROLOGUE_ASM" % D) + _lines(text, "EXACT5_D%d_LOOP_ASM" % D) + _lines(text, "EXACT5_D%d_EPILOGUE_ASM" % D))
     got = mem[base["out"]:base["out"] + len(parts["out"])].view(F)
     peak = w.v[w.names["peak"][1]].view(F)
@@ -141,6 +161,16 @@ def test_exact5_first_outputs_of_a_demodulator(oracle, d, q_first, shift):
     got, want, n_out, peak, w, text = _run_wave(oracle, 9000 - 300 * q_first, True, seg_len, n_blocks, 40 + q_first, shift, D=d, q_first=q_first)
     assert np.array_equal(got[:n_blocks].view(U), want[:n_blocks].view(U)), np.nonzero(got[:n_blocks].view(U) != want[:n_blocks].view(U))[0][:8]
     assert (got[n_blocks:] == F(3.0e8)).all()
+
+
+@pytest.mark.parametrize("d,q_first,shift", [(16, 32, -100), (16, 0, 0), (8, 32, -140), (8, 20, -4), (4, 32, -204), (4, 8, -12)])
+def test_exact5_dma_form(oracle, d, q_first, shift):
+    """The LDS-DMA form of the same program (X5_DMA=1: rows straight from HBM into a lane-linear, source-swizzled LDS image, four buffers, no staging registers)."""
+    seg_len, n_blocks = 8, 200
+    got, want, n_out, peak, w, text = _run_wave(oracle, 9000 - 100 * q_first, True, seg_len, n_blocks, 60 + q_first + d, shift, D=d, q_first=q_first, dma=True)
+    assert np.array_equal(got[:n_blocks].view(U), want[:n_blocks].view(U)), np.nonzero(got[:n_blocks].view(U) != want[:n_blocks].view(U))[0][:8]
+    assert (got[n_blocks:] == F(3.0e8)).all()
+    assert w.count.get("global_load_lds_dwordx4", 0) > 0 and "ds_write_b128" not in w.count or q_first < 32
 
 
 def test_exact5_inc_file_is_the_generators_output():

@@ -31,7 +31,7 @@ class Wave:
         self.v = np.zeros((256, 64), U)
         self.s = {}
         self.names = {}
-        nxt = 225                              # operands sit between the program's fixed registers (v0..v224) and its second staging set (v240..v255)
+        nxt = 225                              # operands sit above the program's fixed registers (v0..v224; the register form also fixes v240..v255: asserted by the caller)
         for k, (kind, val) in operands.items():
             if kind == "v":
                 self.names[k] = ("v", nxt)
@@ -40,12 +40,15 @@ class Wave:
             else:
                 self.names[k] = ("s", k)
                 self.s[k] = int(val)
-        assert nxt <= 240
+        self.n_operand_vgprs = nxt - 225
+        assert nxt <= 256
         self.exec = np.ones(64, bool)
         self.vcc = np.zeros(64, bool)
         self.scc = 0
         self.pending = {}                      # vgpr -> "vm" | "lgkm"
         self.vm_queue = []                     # outstanding vector-memory operations, oldest first: the registers each will write (a store: none)
+        self.dma = []                          # LDS byte ranges that an LDS-DMA load still in vm_queue will write: (queue entry, lo, hi)
+        self.m0 = 0
         self.mfma = []                         # (set of regs, slot of issue, mfma ordinal)
         self.n_mfma = 0
         self.slot = 0
@@ -161,6 +164,7 @@ class Wave:
                         for r in self.vm_queue.pop(0):
                             if self.pending.get(r) == "vm":
                                 del self.pending[r]
+                    self.dma = [(e, lo, hi) for (e, lo, hi) in self.dma if any(e is q for q in self.vm_queue)]
                 continue
             if op in ("s_branch", "s_cbranch_scc1", "s_cbranch_scc0"):
                 if op == "s_branch" or (op == "s_cbranch_scc1") == bool(self.scc):
@@ -221,15 +225,37 @@ class Wave:
                     self.mem[a:a + 16] = np.array([self.v[r, lane] for r in data], U).view(np.uint8)
                 self.vm_queue.append([])
                 continue
+            if op == "s_add_u32" and toks[0] == "m0":
+                self.m0 = (self.s[re.fullmatch(r"%\[(\w+)\]", toks[1]).group(1)] + int(toks[2])) & 0xFFFFFFFF
+                continue
+            if op == "s_mov_b32":
+                if toks[0] == "m0":
+                    self.m0 = self.s[re.fullmatch(r"%\[(\w+)\]", toks[1]).group(1)]
+                else:
+                    assert toks[1] == "m0"
+                    self.s[re.fullmatch(r"%\[(\w+)\]", toks[0]).group(1)] = self.m0
+                continue
+            if op == "global_load_lds_dwordx4":                # 16 bytes per lane from its own address to LDS[M0 + 16 lane]: no register written
+                addr = self._src32(toks[0]).astype(np.int64) + self.s[re.fullmatch(r"%\[(\w+)\]", toks[1]).group(1)] + off
+                entry = []
+                for lane in np.nonzero(self.exec)[0]:
+                    a, d = int(addr[lane]), self.m0 + off + 16 * int(lane)
+                    assert a % 16 == 0 and 0 <= a and a + 16 <= len(self.mem) and d + 16 <= len(self.lds), (l, lane, a, d)
+                    self.lds[d:d + 16] = self.mem[a:a + 16]
+                self.vm_queue.append(entry)
+                self.dma.append((entry, self.m0 + off, self.m0 + off + 1024))
+                continue
             if op in ("ds_read_b128", "ds_write_b128"):
                 rd = op == "ds_read_b128"
                 regs = self._vidx(toks[0] if rd else toks[1])
                 assert len(regs) == 4 and regs[0] % 2 == 0
                 addr = self._src32(toks[1] if rd else toks[0]).astype(np.int64) + off
                 self._touch(regs, op)
+                live = [(lo, hi) for (e, lo, hi) in self.dma if any(e is q for q in self.vm_queue)]
                 for lane in np.nonzero(self.exec)[0]:
                     a = int(addr[lane])
                     assert a % 16 == 0 and a + 16 <= len(self.lds), (l, lane, a)
+                    assert not any(lo < a + 16 and a < hi for lo, hi in live), f"{l}: LDS bytes {a}.. are the target of an LDS-DMA load still in flight (no covering vmcnt)"
                     if rd:
                         w = self.lds[a:a + 16].view(U)
                         for k in range(4):
