@@ -462,14 +462,14 @@ def main():
                 "whole_path_frac": BYTES_PER_SAMPLE_PATH * spl * args.steps / dt_ / 1e9 / HBM_PEAK_GBS}
         if exact and "exact5" in kname:
             # demod_exact5_kernel<16> (round 5; a demodulator's first outputs included: one launch per step): per tile (one 16-sample block of 32 streams = the work of 32 outputs) 16 K = 1 matrix instructions -- the
-            # 32 768 un-fused products fl(y * h) -- and 603 one-lane FP32 instructions (15 x 32 ordered additions, mix 48, sum * phase and workspace 64 + 3,
-            # phasor 7, ...).  The f32 MFMA occupies the SIMD's FP32 lanes: its 64 cycles and the VALU's time ADD (scripts/micro/mfma_k1.hip,
+            # 32 768 un-fused products fl(y * h) -- and the FP32 pipe time of 603 one-lane instructions (15 x 32 ordered additions -- issued as 240 v_pk_add_f32
+            # on register pairs, two passes each: the same pipe time at less power --, mix 48, sum * phase and workspace 64 + 3, phasor 7, ...).  The f32 MFMA occupies the SIMD's FP32 lanes: its 64 cycles and the VALU's time ADD (scripts/micro/mfma_k1.hip,
             # profiles/r5_mfma_k1.txt: gapN / both_* rows), so the bound is a one-pipe sum, priced at the clock measured inside the timed launches.
             clk_mhz = float(st_.get("demod_clock_mhz", 0.0))
             tiles = spl / 16.0 / 32.0 / (n_cu * 4.0)                                   # per SIMD and launch (the streams' 32-block warm-up not counted: it is overhead)
             mfma_cyc, valu_insts = 16 * 64, 603
             vp = {"bound": "fp32 lanes: K = 1 MFMA products + un-fused one-lane sums (one pipe: the times add, profiles/r5_mfma_k1.txt)",
-                  "mfma_per_tile": 16, "cycles_per_mfma": 64, "valu_insts_per_tile": valu_insts, "cycles_per_valu_inst": 2,
+                  "mfma_per_tile": 16, "cycles_per_mfma": 64, "valu_insts_per_tile": valu_insts, "cycles_per_valu_inst": 2, "of_which_issued_as_packed_pairs": 480,
                   "clock_mhz": clk_mhz or None, "clock_source": f"in-kernel s_memtime / s_memrealtime over {int(st_.get('demod_clock_launches', 0))} timed launches",
                   "bound_ms": None, "frac": None}
             if clk_mhz > 0 and avg_ms > 0:

@@ -812,7 +812,7 @@ __global__ __launch_bounds__(64 * kExact5Waves, 2) void demod_exact5_kernel(cons
 {
     static_assert(D == 16 || D == 8 || D == 4, "192 / 96 / 48 kHz");
     constexpr int TILES = D == 16 ? EXACT5_D16_TILES_PER_ITER : D == 8 ? EXACT5_D8_TILES_PER_ITER : EXACT5_D4_TILES_PER_ITER;
-    __shared__ __attribute__((aligned(16))) unsigned char s_rows[kExact5Waves * 2 * EXACT5_ASM_BUF_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char s_rows[kExact5Waves * EXACT5_ASM_NBUF * EXACT5_ASM_BUF_BYTES];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int item = (int)blockIdx.x * kExact5Waves + wv;
     const int n_items = (chunks_x < 0 ? -chunks_x : chunks_x) * n_ch;
@@ -834,11 +834,23 @@ __global__ __launch_bounds__(64 * kExact5Waves, 2) void demod_exact5_kernel(cons
         return (unsigned)rel * 8u;
     };
     const int j = lane & 31;
+    const unsigned lds0 = (unsigned)(size_t)(s_rows + wv * EXACT5_ASM_NBUF * EXACT5_ASM_BUF_BYTES);
+#if EXACT5_ASM_DMA
+    // LDS-DMA form (lab builds: X5_DMA=1 at generation): a load's 64 lanes land lane-linear (row r = lanes 8 r .. 8 r + 7), so the pieces of a row are
+    // swizzled on the SOURCE side -- lane l of load i fetches piece (l & 7) ^ f(row), f(row) = (row >> 1) & 7 -- and a reader undoes it with its address
+    const unsigned pc160 = (unsigned)((lane & 7) ^ ((lane >> 4) & 7)) * 16u, pc161 = (unsigned)((lane & 7) ^ ((4 + (lane >> 4)) & 7)) * 16u;
+    unsigned off0 = stream_pos(0 + (lane >> 3)) + pc160, off1 = stream_pos(8 + (lane >> 3)) + pc161;
+    unsigned off2 = stream_pos(16 + (lane >> 3)) + pc160, off3 = stream_pos(24 + (lane >> 3)) + pc161;
+    const unsigned capl0 = cap * 8u + pc160, capl1 = cap * 8u + pc161;
+    const unsigned ldsr = lds0 + (unsigned)j * 128u, ldsw = lds0 + (unsigned)lane * 16u, fj16 = (unsigned)((j >> 1) & 7) * 16u;
+    const unsigned ldsb = uni(lds0);
+    unsigned m0keep;
+#else
     unsigned off0 = stream_pos(0 + (lane >> 3)) + (unsigned)(lane & 7) * 16u, off1 = stream_pos(8 + (lane >> 3)) + (unsigned)(lane & 7) * 16u;
     unsigned off2 = stream_pos(16 + (lane >> 3)) + (unsigned)(lane & 7) * 16u, off3 = stream_pos(24 + (lane >> 3)) + (unsigned)(lane & 7) * 16u;
     const unsigned pc16 = (unsigned)(lane & 7) * 16u, capl = cap * 8u + pc16;
-    const unsigned lds0 = (unsigned)(size_t)(s_rows + wv * 2 * EXACT5_ASM_BUF_BYTES);
     const unsigned ldsr = lds0 + (unsigned)j * EXACT5_ASM_ROW_BYTES, ldsw = lds0 + (unsigned)(lane >> 3) * EXACT5_ASM_ROW_BYTES + pc16;
+#endif
     const long long my_first = (first_seg + j) * (long long)seg_len;
     int rem = (int)max(0ll, min((long long)seg_len, (long long)n_blocks - my_first));
     const long long q_start = q_first + my_first - 32;                                   // < 0: the stream's warm-up reaches before the demodulator's origin
@@ -874,6 +886,21 @@ __global__ __launch_bounds__(64 * kExact5Waves, 2) void demod_exact5_kernel(cons
         as_global_rw(clk)[0] = t_;
         as_global_rw(clk)[1] = r_;
     }
+#if EXACT5_ASM_DMA
+    const float2 *ring1 = ring + 16, *ring2 = ring + 32, *ring3 = ring + 48;            // a load's immediate would move the LDS address too: four ring bases instead
+#define EXACT5_STATEMENT(TEXT)                                                                                                                             \
+    asm volatile(TEXT                                                                                                                                      \
+                 : [off0] "+v"(off0), [off1] "+v"(off1), [off2] "+v"(off2), [off3] "+v"(off3), [rem] "+v"(rem), [outoff] "+v"(outoff), [peak] "=&v"(peak), \
+                   [ckoff] "+v"(ckoff), [tapoff] "+v"(tapoff), [esave] "=&s"(esave), [warm] "+s"(warm), [iters] "+s"(iters), [hold] "+s"(hold),            \
+                   [holdlt] "+s"(holdlt), [m0keep] "=&s"(m0keep)                                                                                           \
+                 : [capl0] "v"(capl0), [capl1] "v"(capl1), [pc160] "v"(pc160), [pc161] "v"(pc161), [ldsr] "v"(ldsr), [ldsw] "v"(ldsw), [fj16] "v"(fj16),   \
+                   [pk] "v"(pk), [ldsb] "s"(ldsb),                                                                                                         \
+                   [ring0] "s"(ring), [ring1] "s"(ring1), [ring2] "s"(ring2), [ring3] "s"(ring3), [taps] "s"(taps_u), [tone] "s"(tone), [ckpt] "s"(ckpt),  \
+                   [out] "s"(out),                                                                                                                         \
+                   [incre] "s"(incre), [incim] "s"(incim), [sign] "s"(sign), [nsign] "s"(nsign), [hmask] "s"(hmask), [st1] "s"(st1), [st2] "s"(st2),       \
+                   [st3] "s"(st3)                                                                                                                          \
+                 : EXACT5_ASM_CLOBBERS)
+#else
 #define EXACT5_STATEMENT(TEXT)                                                                                                                             \
     asm volatile(TEXT                                                                                                                                      \
                  : [off0] "+v"(off0), [off1] "+v"(off1), [off2] "+v"(off2), [off3] "+v"(off3), [rem] "+v"(rem), [outoff] "+v"(outoff), [peak] "=&v"(peak), \
@@ -884,6 +911,7 @@ __global__ __launch_bounds__(64 * kExact5Waves, 2) void demod_exact5_kernel(cons
                    [incre] "s"(incre), [incim] "s"(incim), [sign] "s"(sign), [nsign] "s"(nsign), [hmask] "s"(hmask), [st1] "s"(st1), [st2] "s"(st2),       \
                    [st3] "s"(st3)                                                                                                                          \
                  : EXACT5_ASM_CLOBBERS)
+#endif
     if constexpr (D == 16) EXACT5_STATEMENT(EXACT5_D16_PROLOGUE_ASM EXACT5_D16_LOOP_ASM EXACT5_D16_EPILOGUE_ASM);
     else if constexpr (D == 8) EXACT5_STATEMENT(EXACT5_D8_PROLOGUE_ASM EXACT5_D8_LOOP_ASM EXACT5_D8_EPILOGUE_ASM);
     else EXACT5_STATEMENT(EXACT5_D4_PROLOGUE_ASM EXACT5_D4_LOOP_ASM EXACT5_D4_EPILOGUE_ASM);

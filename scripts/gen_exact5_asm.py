@@ -46,7 +46,8 @@ RING_NT = "" if _nt == "0" else (" nt" if _nt == "1" else " " + _nt.replace("_",
 # X5_DMA=1: the rows go from HBM straight into LDS (global_load_lds_dwordx4: no staging registers, no ds_write); the LDS image is then lane-linear
 # (32 unpadded rows of 128 bytes per load tile, four buffers), conflict-free through a swizzle on the SOURCE side: lane l of a load fetches piece
 # (l & 7) ^ f(row) of its row, f(row) = (row >> 1) & 7, and lane j reads piece k of its row from slot k ^ f(j).
-DMA = os.environ.get("X5_DMA", "0") == "1"
+DMA = os.environ.get("X5_DMA", "1") == "1"
+PK = os.environ.get("X5_PK", "1") == "1"                      # the block sums as v_pk_add_f32 pairs: same issue time, less power (same-box: clock 2.00 -> 2.05-2.08 GHz, -1.2 %)
 AK, ZQ = 196, 204                                                  # DMA form: v196-v203 the eight read addresses of the lane's row, v204-v207 a quad of zeros
 DBUF = 4096                                                        # DMA form: bytes of one load tile in LDS (32 rows x 128)
 D = 16                                                             # samples per block = Fs / 12 kHz: 16 (192 kHz), 8 (96 kHz), 4 (48 kHz); set by program(d)
@@ -69,6 +70,8 @@ def mfma(dst, m):
 
 
 def adds(src):
+    if PK:                                                          # X5_PK=1: the sums as register pairs (two independently rounded additions per instruction: the same bits)
+        return [f"v_pk_add_f32 v[{S + k}:{S + k + 1}], v[{S + k}:{S + k + 1}], v[{src + k}:{src + k + 1}]" for k in range(0, 32, 2)]
     return [f"v_add_f32 v{S + k}, v{S + k}, v{src + k}" for k in range(32)]
 
 

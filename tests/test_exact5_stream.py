@@ -17,8 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F, U = np.float32, np.uint32
 
 
-def _gen(dma=None):
+def _gen(dma=None, extra=None):
     env = dict(os.environ)
+    env.update(extra or {})
     if dma is not None:
         env["X5_DMA"] = "1" if dma else "0"
     return subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gen_exact5_asm.py")], check=True, capture_output=True, text=True, env=env).stdout
@@ -41,8 +42,8 @@ def _tap_block_of_row(i):
     return (i & 3) + 4 * (i >> 3) + 16 * ((i >> 2) & 1)
 
 
-def _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, ring_shift_blocks, D=16, q_first=32, dma=None):
-    text = _gen(dma)
+def _run_wave(oracle, f_hz, usb, seg_len, n_blocks, seed, ring_shift_blocks, D=16, q_first=32, dma=None, extra=None):
+    text = _gen(dma, extra)
     dma = bool(_define(text, "EXACT5_ASM_DMA"))
     FS = 12000 * D
     row, buf, per_iter = _define(text, "EXACT5_ASM_ROW_BYTES"), _define(text, "EXACT5_ASM_BUF_BYTES"), _define(text, "EXACT5_D%d_TILES_PER_ITER" % D)
@@ -145,7 +146,8 @@ def test_exact5_wave_program_writes_the_reference_bits(oracle, d, f_hz, usb, see
     loop = _lines(text, "EXACT5_D%d_LOOP_ASM" % d)
     tiles = _define(text, "EXACT5_D%d_TILES_PER_ITER" % d)
     assert tiles * d == 64 and sum(l.startswith("v_mfma_f32_32x32x1_2b_f32") for l in loop) == tiles * d
-    assert sum(bool(re.match(r"v_add_f32 v(\d+), v\1, v(3[2-9]|[4-9]\d)$", l)) for l in loop) == tiles * (d - 1) * 32
+    # the ordered sums: 15 x 32 additions per tile, issued as register pairs (v_pk_add_f32: two additions, each rounded on its own)
+    assert sum(bool(re.match(r"v_pk_add_f32 v\[(\d+):(\d+)\], v\[\1:\2\], v\[(3[2-9]|[4-9]\d):\d+\]$", l)) for l in loop) == tiles * (d - 1) * 16
     assert not any("fma" in l.split(" ")[0].replace("v_mfma", "") for l in loop)
     regs = [int(x) for l in loop for x in re.findall(r"\bv(\d+)\b", l)] + [int(x) for l in loop for x in re.findall(r"v\[\d+:(\d+)\]", l)]
     vtop = int(re.search(r"#define EXACT5_ASM_VTOP (\d+)", text).group(1))              # fixed registers: v0 .. VTOP - 1 and the second staging set v240 .. v255
@@ -164,13 +166,23 @@ def test_exact5_first_outputs_of_a_demodulator(oracle, d, q_first, shift):
 
 
 @pytest.mark.parametrize("d,q_first,shift", [(16, 32, -100), (16, 0, 0), (8, 32, -140), (8, 20, -4), (4, 32, -204), (4, 8, -12)])
-def test_exact5_dma_form(oracle, d, q_first, shift):
-    """The LDS-DMA form of the same program (X5_DMA=1: rows straight from HBM into a lane-linear, source-swizzled LDS image, four buffers, no staging registers)."""
+def test_exact5_register_staged_form(oracle, d, q_first, shift):
+    """The generator's other form of the same program (X5_DMA=0: rows through staging registers and ds_write_b128 into a pitch-144 image, two buffers) --
+    the form of the round's first half, kept as the A/B partner of the LDS-DMA form the product runs (profiles/r5_x5_dma_ab.txt)."""
     seg_len, n_blocks = 8, 200
-    got, want, n_out, peak, w, text = _run_wave(oracle, 9000 - 100 * q_first, True, seg_len, n_blocks, 60 + q_first + d, shift, D=d, q_first=q_first, dma=True)
+    got, want, n_out, peak, w, text = _run_wave(oracle, 9000 - 100 * q_first, True, seg_len, n_blocks, 60 + q_first + d, shift, D=d, q_first=q_first, dma=False)
     assert np.array_equal(got[:n_blocks].view(U), want[:n_blocks].view(U)), np.nonzero(got[:n_blocks].view(U) != want[:n_blocks].view(U))[0][:8]
     assert (got[n_blocks:] == F(3.0e8)).all()
-    assert w.count.get("global_load_lds_dwordx4", 0) > 0 and "ds_write_b128" not in w.count or q_first < 32
+    assert w.count.get("global_load_lds_dwordx4", 0) == 0 and w.count.get("ds_write_b128", 0) > 0
+
+
+@pytest.mark.parametrize("d,q_first,shift", [(16, 32, -100), (8, 20, -4), (4, 8, -12)])
+def test_exact5_one_lane_sums_form(oracle, d, q_first, shift):
+    """X5_PK=0: the block sums as one-lane v_add_f32 (the product's form has them as v_pk_add_f32 on register pairs: the same bits) -- the A/B partner."""
+    seg_len, n_blocks = 8, 200
+    got, want, n_out, peak, w, text = _run_wave(oracle, 9000 - 100 * q_first, True, seg_len, n_blocks, 90 + d, shift, D=d, q_first=q_first, extra={"X5_PK": "0"})
+    assert np.array_equal(got[:n_blocks].view(U), want[:n_blocks].view(U))
+    assert w.count.get("v_pk_add_f32", 0) == 0
 
 
 def test_exact5_inc_file_is_the_generators_output():

@@ -322,5 +322,16 @@ class Wave:
                     r = {"v_mul_f32": lambda: a * b, "v_add_f32": lambda: a + b, "v_sub_f32": lambda: a - b, "v_max_f32": lambda: np.maximum(a, b)}[op]()
                 self._wr(toks[0], _u(r.astype(F)))
                 continue
+            if op == "v_pk_add_f32":                            # two one-lane additions on a register pair, each rounded on its own (no op_sel / neg modifiers here)
+                lo = [int(re.fullmatch(r"v\[(\d+):(\d+)\]", t).group(1)) for t in toks]
+                assert all(x % 2 == 0 for x in lo), l
+                res = []
+                for h in (0, 1):
+                    a, b = _f(self._src32(f"v{lo[1] + h}")), _f(self._src32(f"v{lo[2] + h}"))
+                    with np.errstate(all="ignore"):
+                        res.append(_u((a + b).astype(F)))
+                for h in (0, 1):
+                    self._wr(f"v{lo[0] + h}", res[h])
+                continue
             raise AssertionError("wave emulator: unknown instruction: " + l)
         return self
