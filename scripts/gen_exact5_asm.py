@@ -47,6 +47,12 @@ RING_NT = "" if _nt == "0" else (" nt" if _nt == "1" else " " + _nt.replace("_",
 # (32 unpadded rows of 128 bytes per load tile, four buffers), conflict-free through a swizzle on the SOURCE side: lane l of a load fetches piece
 # (l & 7) ^ f(row) of its row, f(row) = (row >> 1) & 7, and lane j reads piece k of its row from slot k ^ f(j).
 DMA = os.environ.get("X5_DMA", "1") == "1"
+# X5_DEEP=1 (LDS-DMA form only): THREE load tiles in flight instead of two, in the same four buffers -- nothing has to be done when rows arrive, so the wait for
+# load tile t + 1 moves from the start of tile t to just before its first read (near the end of tile t), and tile t + 3 is requested before it, not after
+DEEP = DMA and os.environ.get("X5_DEEP", "0") == "1"
+# X5_BURST=1 (LDS-DMA form only): load tiles are requested in PAIRS (every second load tile: 256 contiguous bytes of every stream at 192 kHz instead of 128 --
+# half as many DRAM row activations), waits as in the DEEP form
+BURST = DMA and os.environ.get("X5_BURST", "0") == "1"
 PK = os.environ.get("X5_PK", "1") == "1"                      # the block sums as v_pk_add_f32 pairs: same issue time, less power (same-box: clock 2.00 -> 2.05-2.08 GHz, -1.2 %)
 AK, ZQ = 196, 204                                                  # DMA form: v196-v203 the eight read addresses of the lane's row, v204-v207 a quad of zeros
 DBUF = 4096                                                        # DMA form: bytes of one load tile in LDS (32 rows x 128)
@@ -206,19 +212,32 @@ def tile(c):
     sets: vmcnt(4)), move them to LDS buffer (t + 1) & 1, and request load tile t + 3 into the staging set that this freed."""
     R, NT, SUB, NSUB = geometry()
     u = c & 3
+    # DEEP: the next compute tile's first samples come from the NEXT load tile -- its rows must have landed (three load tiles outstanding: vmcnt(8); a store
+    # among them only makes the wait stricter), and its pre-origin rows are zeroed, just before that read
+    arrive = []
+    if (DEEP or BURST) and (c + 1) % R == 0:
+        n = (c + 1) // R                                            # the load tile about to be read; BURST: an even one was requested together with n + 1, an odd one
+        arrive = [f"s_waitcnt vmcnt({8 if DEEP or n & 1 else 4})"] + lds_write(n)   # with n - 1, and the pair n + 1, n + 2 has been requested since
     L = ["s_waitcnt lgkmcnt(0)"]                                    # this tile's first SUB samples (read during the previous tile)
     L += mix_group(list(range(SUB)))
-    L += sub_read(c, 1) if NSUB == 2 else sub_read(c + 1, 0)        # the rest of this tile's samples / the next tile's, into the same registers
+    L += sub_read(c, 1) if NSUB == 2 else arrive + sub_read(c + 1, 0)   # the rest of this tile's samples / the next tile's, into the same registers
     loader = []
     if c % R == 0:
         lt = c // R
-        loader = ["s_waitcnt vmcnt(4)"]                             # the NEXT load tile's rows have arrived from the ring ...
-        loader += lds_write(lt + 1)                                 # ... transposed through LDS ...
+        if not (DEEP or BURST):
+            loader = ["s_waitcnt vmcnt(4)"]                         # the NEXT load tile's rows have arrived from the ring ...
+            loader += lds_write(lt + 1)                             # ... transposed through LDS ...
         if c % 4 == 0:
             loader += store_block(c // 4)                           # the previous four outputs (behind the older loads, ahead of the new ones: see vmcnt)
-        if lt == 1 and D == 16:
-            loader += advance_offsets()
-        loader += ring_loads(lt + 3)                                # ... and the third load tile from here is requested
+        if BURST:
+            if lt % 2 == 0:
+                if lt == 2 and D == 16:
+                    loader += advance_offsets()
+                loader += ring_loads(lt + 2) + ring_loads(lt + 3)
+        else:
+            if lt == 1 and D == 16:
+                loader += advance_offsets()
+            loader += ring_loads(lt + 3)                            # ... and the third load tile from here is requested
     elif c % 4 == 0:
         raise AssertionError("a store slot that is not a loader slot")
     if not LOADER_IN_GAP:
@@ -235,7 +254,7 @@ def tile(c):
         if m == 5 and NSUB == 2:                                    # samples 8..15 have long landed: mix them before MFMA 8 needs y[8]
             L += ["s_waitcnt lgkmcnt(0)"]
             L += mix_group(list(range(8, 16)))
-            L += sub_read(c + 1, 0)                                 # the next tile's samples 0..7
+            L += arrive + sub_read(c + 1, 0)                        # the next tile's samples 0..7
     L += adds(where[D - 1])
     L += t_and_w(u)
     L += phase_step()                                               # (two instructions at least between W[0]'s write and the swap that reads it)
@@ -265,7 +284,8 @@ def prologue():
             L += [f"v_xor_b32 v{AK + k}, {16 * k}, %[fj16]", f"v_add_u32 v{AK + k}, %[ldsr], v{AK + k}"]
         L += [f"v_mov_b32 v{ZQ + j}, 0" for j in range(4)]
     L += lds_write(0)
-    L += ring_loads(2)
+    if not BURST:
+        L += ring_loads(2)
     L += sub_read(0, 0)
     return L
 

@@ -185,5 +185,25 @@ def test_exact5_one_lane_sums_form(oracle, d, q_first, shift):
     assert w.count.get("v_pk_add_f32", 0) == 0
 
 
+@pytest.mark.parametrize("d,q_first,shift", [(16, 32, -100), (16, 0, 0), (8, 32, -140), (8, 20, -4), (4, 32, -204), (4, 8, -12)])
+def test_exact5_three_load_tiles_in_flight(oracle, d, q_first, shift):
+    """X5_DEEP=1: the wait for a load tile's rows just before their first read, three load tiles outstanding (the emulator refuses a read of LDS bytes that an
+    LDS-DMA load still in flight will write, and lands every load at once: both ends of the race)."""
+    seg_len, n_blocks = 8, 200
+    got, want, n_out, peak, w, text = _run_wave(oracle, 9000 - 100 * q_first, True, seg_len, n_blocks, 70 + q_first + d, shift, D=d, q_first=q_first, extra={"X5_DEEP": "1"})
+    assert np.array_equal(got[:n_blocks].view(U), want[:n_blocks].view(U)), np.nonzero(got[:n_blocks].view(U) != want[:n_blocks].view(U))[0][:8]
+    assert (got[n_blocks:] == F(3.0e8)).all()
+    assert "s_waitcnt vmcnt(8)" in text and "s_waitcnt vmcnt(4)" not in text
+
+
+@pytest.mark.parametrize("d,q_first,shift", [(16, 32, -100), (16, 0, 0), (8, 32, -140), (8, 20, -4), (4, 32, -204), (4, 8, -12)])
+def test_exact5_load_tiles_requested_in_pairs(oracle, d, q_first, shift):
+    """X5_BURST=1: two load tiles per request slot (256 contiguous bytes of a stream at 192 kHz)."""
+    seg_len, n_blocks = 8, 200
+    got, want, n_out, peak, w, text = _run_wave(oracle, 9000 - 100 * q_first, True, seg_len, n_blocks, 75 + q_first + d, shift, D=d, q_first=q_first, extra={"X5_BURST": "1"})
+    assert np.array_equal(got[:n_blocks].view(U), want[:n_blocks].view(U)), np.nonzero(got[:n_blocks].view(U) != want[:n_blocks].view(U))[0][:8]
+    assert (got[n_blocks:] == F(3.0e8)).all()
+
+
 def test_exact5_inc_file_is_the_generators_output():
     assert _gen() == open(os.path.join(ROOT, "cwsl_digi_amd", "csrc", "exact5_asm.inc")).read(), "exact5_asm.inc is not the generator's output"
