@@ -794,12 +794,13 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
 // outputs of ONE channel, time runs along the lane, and everything a stream needs between two tiles (its 16 samples, the 32 x 2 running sums,
 // the workspace chain, its mixer phase) stays in registers.  The un-fused products fl(y * h) (SSBD.hpp:167-168) of a block against all 32 tap
 // blocks are ONE K = 1 matrix instruction per sample (v_mfma_f32_32x32x1_2b_f32, C = 0: bit-identical to v_mul_f32, scripts/micro/mfma_k1.hip);
-// the ordered sums, sum * phase and the workspace accumulation are plain v_add_f32 / v_mul_f32 in the reference's order.  Why this shape, what
+// the ordered sums (as v_pk_add_f32 register pairs, each half rounded on its own), sum * phase and the workspace accumulation are plain FP32 adds / products in the reference's order.  Why this shape, what
 // the matrix instruction does and does not buy (it shares the FP32 lanes with the VALU: no second pipe), the register map and the zero-sign
 // argument: scripts/gen_exact5_asm.py and DESIGN.md 4.1d; profiles/r5_mfma_k1.txt.  The wave's whole life is one generated assembly statement
 // (exact5_asm.inc), executed on the CPU against the oracle before it ever reached a GPU (tests/test_exact5_stream.py, tests/wave_emulator.py).
 //   Work item = (channel, chunk of 32 x seg_len outputs); one wave per item, four waves per workgroup, no barrier anywhere (a wave's LDS
-//   rows are its own: the 32 x 128 bytes of a tile are loaded coalesced -- eight lanes per 128-byte line -- and read back lane = stream).
+//   rows are its own: the 32 x 128 bytes of a tile travel coalesced -- eight lanes per 128-byte line -- from the ring straight into LDS (LDS-DMA,
+//   four 4 KB buffers per wave, swizzled on the source side) and are read back lane = stream).
 //   A stream starts 32 blocks before its first output (the workspace needs an output's 32 blocks); where that reaches before the demodulator's
 //   origin (the first 32 outputs after its creation) the missing blocks are zeros and the phase is held at (1, 0): see `hold` below.
 //   Requires q_first, n_blocks, seg_len multiples of 4, lo_mod and the ring's length multiples of 4 D samples (the push granularity) and the ring

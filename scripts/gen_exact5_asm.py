@@ -17,10 +17,12 @@ and 2.38 GHz, against exact4's 1570 ns.  Here therefore LANE = STREAM and time r
   * the 32-term accumulation of an output (:170, oldest block first) runs down a 17-register shift chain: W[r + 1] = W[r] + T_r (tap block r of the
     lower half, 16 + r of the upper); once per tile the lower half's finished partial (n = 0..15) crosses to the upper half (v_permlane32_swap)
     where it collects n = 16..31, and the upper half's W[16] is the finished output;
-  * the wave streams its 32 x 128 bytes per tile through LDS only to transpose them (coalesced 16-byte loads -> one row per stream, read back
-    lane = stream); nothing is re-read: 12 KB of LDS traffic per 1024 sums where exact4 moves 72 KB.
-A stream starts 32 blocks before its first output (the workspace warm-up: an output needs its 32 blocks); the host hands over only work whose
-32-block history exists (the first 32 outputs after a demodulator's creation go through demod_exact4_kernel).
+  * the wave streams its 32 x 128 bytes per tile through LDS only to transpose them (coalesced 16-byte pieces, eight lanes per line -> one row per
+    stream, read back lane = stream); nothing is re-read: 12 KB of LDS traffic per 1024 sums where exact4 moves 72 KB.  Product form (X5_DMA=1): the
+    pieces go from the ring straight into LDS (global_load_lds_dwordx4), four buffers per wave; X5_DMA=0 is the round's first form (staging registers
+    and ds_write_b128, two buffers).  The ordered sums are issued as register pairs (X5_PK=1: v_pk_add_f32, each half rounded on its own).
+A stream starts 32 blocks before its first output (the workspace warm-up: an output needs its 32 blocks); where that reaches before the
+demodulator's origin the rows are zeros and the phase is held at (1, 0) (lds_write, phase_hold).
 
 Zeros.  The MFMA computes fmaf(a, b, +0): an exact-zero product arrives as +0 where v_mul_f32 gives -0.  That cannot change an output: the
 reference's running sum starts as (+0 + p_0) and is therefore never -0, so adding either zero leaves it unchanged; where a whole sum is zero its
@@ -209,7 +211,8 @@ def tile(c):
     """Compute tile c of an iteration (c mod 4 = the block's position mod 4).  Memory pipeline, per LOAD tile (16 samples of every stream): TWO are in
     flight (one per wave was 8 MB in flight chip-wide: at ~2.8 us of loaded HBM latency that is the 2.9 TB/s the first form of this kernel ran at,
     whatever its arithmetic did).  In the first compute tile of load tile t: wait for load tile t + 1's rows (the older of the two outstanding
-    sets: vmcnt(4)), move them to LDS buffer (t + 1) & 1, and request load tile t + 3 into the staging set that this freed."""
+    sets: vmcnt(4)), zero what lies before the origin (register form: move them to LDS buffer (t + 1) & 1), and request load tile t + 3 into the
+    buffer (staging set) that load tile t - 1 has left.  X5_DEEP / X5_BURST: measured alternatives of this schedule (profiles/r5_experiments.txt)."""
     R, NT, SUB, NSUB = geometry()
     u = c & 3
     # DEEP: the next compute tile's first samples come from the NEXT load tile -- its rows must have landed (three load tiles outstanding: vmcnt(8); a store
