@@ -995,6 +995,40 @@ __device__ __forceinline__ void wave_first_max(float v, int lag, float &best, in
     best_lag = __builtin_amdgcn_readlane(lag, src);
 }
 
+// The search's two reductions of a bin (+-62 over every lag, +-10 over the near ones) together, as fused DPP maxima (v_max_f32_dpp: permute and
+// compare in one instruction) -- rows of 16 by quad_perm / row_half_mirror / row_mirror, then row_bcast:15 / :31 into the last lane.  hipcc's form of
+// wave_first_max is a move, a DPP move and two v_max (one to canonicalise) per step plus four v_readlane and three more maxima: ~36 issue slots per
+// reduction, 72 of a bin's ~340; here 2 x 13.  The two chains interleave (a DPP read of a register wants two wait states behind its VALU write).  No
+// NaN reaches this (sync_finish returns 0 for 0 / 0), a maximum is exact: the same values, the same first lane.
+#ifndef CWSLG_SEARCH_DPPMAX
+#define CWSLG_SEARCH_DPPMAX 1          // 0: hipcc's wave_first_max twice (the A/B partner: scripts/gpu_r5_dppmax.sh)
+#endif
+__device__ __forceinline__ void wave_first_max2(float va, int laga, float vb, int lagb, float &besta, int &best_laga, float &bestb, int &best_lagb)
+{
+    float ma = va, mb = vb;
+#define CWSLG_DPP_MAX2(CTRL)                                                                  \
+    "v_max_f32_dpp %0, %0, %0 " CTRL "\n\t"                                                   \
+    "v_max_f32_dpp %1, %1, %1 " CTRL "\n\t"                                                   \
+    "s_nop 0\n\t"
+    asm volatile("s_nop 1\n\t"
+                 CWSLG_DPP_MAX2("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 CWSLG_DPP_MAX2("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 CWSLG_DPP_MAX2("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 CWSLG_DPP_MAX2("row_mirror row_mask:0xf bank_mask:0xf")
+                 CWSLG_DPP_MAX2("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 CWSLG_DPP_MAX2("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 0"
+                 : "+v"(ma), "+v"(mb));
+#undef CWSLG_DPP_MAX2
+    const float wa = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ma), 63));
+    const float wb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mb), 63));
+    const unsigned long long hita = __builtin_amdgcn_ballot_w64(va == wa), hitb = __builtin_amdgcn_ballot_w64(vb == wb);
+    const int srca = hita ? (int)__builtin_ctzll(hita) : 0, srcb = hitb ? (int)__builtin_ctzll(hitb) : 0;
+    // (the value is read from that lane too: a maximum of zero can be held with either sign)
+    besta = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(va), srca)); best_laga = __builtin_amdgcn_readlane(laga, srca);
+    bestb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vb), srcb)); best_lagb = __builtin_amdgcn_readlane(lagb, srcb);
+}
+
 // x / 6.0f, correctly rounded, in three operations instead of the ten of the IEEE division sequence: q0 = x * fl(1/6), the residual
 // x - 6 q0 is exact in one fmaf, one more fmaf corrects q0.  Checked against the division for EVERY float (tests/div6_check.c,
 // tests/test_div6_shortcut.py): identical for all x with 2^-125 <= |x| < inf and for +-0; below that range the quotient is denormal
@@ -1023,6 +1057,28 @@ __device__ __forceinline__ float sync_finish(float ta, float tb, float tc, float
     float sy = (sync_abc > sync_bc) ? sync_abc : sync_bc;
     if (!(sy == sy)) sy = 0.0f;                        // 0/0 on all-zero windows: defined as 0 (as the oracle)
     return sy;
+}
+
+// sync_finish for a lane's two lags at once: the four x / 6 share ONE range test (the maximum of the four biased magnitudes against the bound: 11 vector
+// instructions and one branch where four div6_exact take 12 and four); a lane outside the range -- never, on audio -- redoes all four by division, which
+// gives what the short form gives wherever that is valid.  Same operations on the same operands: the same bits as sync_finish twice.
+__device__ __forceinline__ void sync_finish2(v2f ta, v2f tb, v2f tc, v2f ua, v2f ub, v2f uc, float &sx, float &sy)
+{
+    const float r = 0x1.555556p-3f;                     // fl(1/6)
+    const float t1x = ta.x + tb.x + tc.x, t1y = ta.y + tb.y + tc.y;
+    const float d1x = (ua.x + ub.x + uc.x) - t1x, d1y = (ua.y + ub.y + uc.y) - t1y;
+    const float t2x = tb.x + tc.x, t2y = tb.y + tc.y;
+    const float d2x = (ub.x + uc.x) - t2x, d2y = (ub.y + uc.y) - t2y;
+    auto short6 = [&](float x) { const float q0 = x * r; return __builtin_fmaf(__builtin_fmaf(-6.0f, q0, x), r, q0); };
+    auto biased = [](float x) { return (__float_as_uint(x) & 0x7fffffffu) - 0x10000000u; };
+    float q1x = short6(d1x), q1y = short6(d1y), q2x = short6(d2x), q2y = short6(d2y);
+    const unsigned worst = max(max(biased(d1x), biased(d1y)), max(biased(d2x), biased(d2y)));
+    if (__builtin_expect(worst >= 0x6f800000u, 0)) { q1x = d1x / 6.0f; q1y = d1y / 6.0f; q2x = d2x / 6.0f; q2y = d2y / 6.0f; }
+    const float ax = t1x / q1x, bx = t2x / q2x, ay = t1y / q1y, by = t2y / q2y;
+    sx = (ax > bx) ? ax : bx;
+    sy = (ay > by) ? ay : by;
+    if (!(sx == sx)) sx = 0.0f;                        // 0/0 on all-zero windows: defined as 0 (as the oracle)
+    if (!(sy == sy)) sy = 0.0f;
 }
 
 #if defined(CWSLG_STAMP) && defined(CWSLG_STAMP_SYNC)
@@ -1207,20 +1263,28 @@ __device__ __forceinline__ void sync2d_search_band(const SyncWork *w, unsigned s
                          : SYNC2D_ASM_CLOBBERS);
         if (rr == rr0) SSTAMP(3);
         // (computed on every lane and selected afterwards: 62 or 63 of the 64 lanes hold a lag, a branch around the divisions saves nothing)
-        float sa = sync_finish(ta.x, tb.x, tc.x, ua.x, ub.x, uc.x);
-        float sb = sync_finish(ta.y, tb.y, tc.y, ua.y, ub.y, uc.y);
+        float sa, sb;
+#if CWSLG_SEARCH_DPPMAX
+        sync_finish2(ta, tb, tc, ua, ub, uc, sa, sb);
+#else
+        sa = sync_finish(ta.x, tb.x, tc.x, ua.x, ub.x, uc.x);
+        sb = sync_finish(ta.y, tb.y, tc.y, ua.y, ub.y, uc.y);
+#endif
         asm volatile("" : "+v"(sa), "+v"(sb));
         sa = ok0 ? sa : ninf;
         sb = ok1 ? sb : ninf;
         if (rr == rr0) SSTAMP(4);
         // +-62: the lane's own first maximum (lag j before j + 1), then the wavefront's
         const bool b2 = sb > sa;
-        float r2; int l2;
-        wave_first_max(b2 ? sb : sa, b2 ? j + 1 : j, r2, l2);
         const float na = near0 ? sa : ninf, nb = near1 ? sb : ninf;
         const bool b1 = nb > na;
-        float r1; int l1;
+        float r1, r2; int l1, l2;
+#if CWSLG_SEARCH_DPPMAX
+        wave_first_max2(b2 ? sb : sa, b2 ? j + 1 : j, b1 ? nb : na, b1 ? j + 1 : j, r2, l2, r1, l1);
+#else
+        wave_first_max(b2 ? sb : sa, b2 ? j + 1 : j, r2, l2);
         wave_first_max(b1 ? nb : na, b1 ? j + 1 : j, r1, l1);
+#endif
         if (lane == 0) {
             as_global_rw(w->red)[bin] = r1;  as_global_rw(w->jpeak)[bin] = l1;       // (HBM addresses: global_store, not flat_store)
             as_global_rw(w->red2)[bin] = r2; as_global_rw(w->jpeak2)[bin] = l2;
