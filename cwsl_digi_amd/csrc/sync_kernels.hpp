@@ -498,6 +498,9 @@ __device__ __forceinline__ void spectra_stage1_regs(const float2 (&z)[AMAX], flo
 #ifndef CWSLG_SPEC_WAVES
 #define CWSLG_SPEC_WAVES 4
 #endif
+#ifndef CWSLG_SPEC_TIGHT
+#define CWSLG_SPEC_TIGHT 1             // 0: the addressing / prefetch forms of round 4 (the A/B partner: scripts/gpu_r5_dppmax.sh with SWITCH=CWSLG_SPEC_TIGHT)
+#endif
 // The spectra plane (6 GB per 4096-slot boundary) is written once by symbol_spectra_v2_kernel and read once by the search: CWSLG_PLANE_NT selects
 // non-temporal stores (bit 0) / loads (bit 1) for it (round 5 A/B: scripts/gpu_r5_plane_nt.sh).
 #ifndef CWSLG_PLANE_NT
@@ -674,9 +677,12 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         if (NA == 15) { if (tid >= 128) for (int k4 = tid - 128; 4 * k4 < nbins; k4 += 128) plane_store(out4 + k4, *reinterpret_cast<const v4f *>(s_pw + 4 * k4)); }
         else for (int k4 = tid; 4 * k4 < nbins; k4 += 256) plane_store(out4 + k4, *reinterpret_cast<const v4f *>(s_pw + 4 * k4));
     }
-    if (j + 1 < jend) {                                   // wave-uniform: the next step's window, in flight during this transform
+    {   // the next step's window, in flight during this transform.  Unconditional (the workgroup's last step fetches its own window again: eight loads per
+        // jper transforms): under `if (j + 1 < jend)` the registers were a merge of two paths, which hipcc kept as two sets and eight 64-bit moves per transform
+        const int jn = CWSLG_SPEC_TIGHT ? min(j + 1, jend - 1) : j + 1;
+        if (CWSLG_SPEC_TIGHT || j + 1 < jend)
 #pragma unroll
-        for (int a = 0; a < AMAX; ++a) raw[a] = (128 * a + b < NPACK) ? d32[(STEP / 2) * (j + 1) + 128 * a] : 0u;
+        for (int a = 0; a < AMAX; ++a) raw[a] = (128 * a + b < NPACK) ? d32[(STEP / 2) * jn + 128 * a] : 0u;
     }
 
     // stage 1 (wave-uniform split of the outputs between waves 0-1 and waves 2-3)
@@ -692,10 +698,12 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         const int gb = (int)(__brev((unsigned)g) >> 28);
         float2 e[8];
         if (tid < NGRP) {
+            // (one address, the eight columns 16 k3 + gb as instruction offsets: indexed as s_y[c][16 * k3 + gb] hipcc built every address from scratch)
+            const char *const pa = sy_bytes + 8u * (unsigned)(c * SY_PITCH + gb);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int k3 = ((k & 1) << 2) | (k & 2) | ((k >> 2) & 1);
-                e[k] = s_y[c][16 * k3 + gb];
+                e[k] = CWSLG_SPEC_TIGHT ? *reinterpret_cast<const float2 *>(pa + 128 * k3) : s_y[c][16 * k3 + gb];
             }
         }
         // No workgroup barrier here, nor between pass A and pass B: row c is gathered, rewritten and read again by the SAME sixteen
@@ -708,8 +716,13 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
             bfly_one(e[0], e[1]); bfly_one(e[2], e[3]); bfly_one(e[4], e[5]); bfly_one(e[6], e[7]);
             bfly_one(e[0], e[2]); bfly_mj(e[1], e[3]); bfly_one(e[4], e[6]); bfly_mj(e[5], e[7]);
             bfly_one(e[0], e[4]); bfly(e[1], e[5], s_w128[16]); bfly_mj(e[2], e[6]); bfly(e[3], e[7], s_w128[48]);
+            // sy_col(8 g + k) = sy_col(8 g) ^ k for k < 8 (the swizzle's low three bits are g's, the row starts at a multiple of 128 bytes): one address, seven XORs
+            const unsigned a0 = 8u * (unsigned)(c * SY_PITCH + sy_col(8 * g));
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s_y[c][sy_col(8 * g + k)] = e[k];
+            for (int k = 0; k < 8; ++k) {
+                if (CWSLG_SPEC_TIGHT) *reinterpret_cast<float2 *>(sy_bytes + (a0 ^ (8u * k))) = e[k];
+                else s_y[c][sy_col(8 * g + k)] = e[k];
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
