@@ -470,7 +470,7 @@ def main():
             mfma_cyc, valu_insts = 16 * 64, 603
             vp = {"bound": "fp32 lanes: K = 1 MFMA products + un-fused one-lane sums (one pipe: the times add, profiles/r5_mfma_k1.txt)",
                   "mfma_per_tile": 16, "cycles_per_mfma": 64, "valu_insts_per_tile": valu_insts, "cycles_per_valu_inst": 2, "of_which_issued_as_packed_pairs": 480,
-                  "clock_mhz": clk_mhz or None, "clock_source": f"in-kernel s_memtime / s_memrealtime over {int(st_.get('demod_clock_launches', 0))} timed launches",
+                  "clock_mhz": clk_mhz or None, "clock_source": f"in-kernel s_memtime / s_memrealtime of the launch's middle workgroup over {int(st_.get('demod_clock_launches', 0))} timed launches",
                   "bound_ms": None, "frac": None}
             if clk_mhz > 0 and avg_ms > 0:
                 vp["bound_ms"] = tiles * (mfma_cyc + 2 * valu_insts) / (clk_mhz * 1e3)
