@@ -9,6 +9,8 @@ order: acc = x0; acc = acc + x1; ... (0 + x0 = x0 exactly: the powers are never 
 
     python scripts/gen_sync2d_asm.py > cwsl_digi_amd/csrc/sync2d_asm.inc
 """
+import os
+HOIST = os.environ.get("X2D_HOIST", "1") == "1"   # 0: the third-column address of the c0 build recomputed for each of its seven rows (round 3's form; A/B: scripts/gpu_r5_x2d.sh)
 RB = 378 * 4                      # bytes per row of the band image (S2_PITCH floats)
 ICOS = [3, 1, 4, 0, 6, 5, 2]
 RING0 = 104                       # v104..v127: 12 ring temporaries (v2f each)
@@ -71,6 +73,7 @@ def build(with_search, with_c0):
     g.emit("v_add_u32 %s, %%[sC], %%[vU]" % XC)
     units = (search_units() if with_search else []) + ([("K", k, "") for k in range(7)] if with_c0 else [])
     ring = 0
+    XL = [None]
     pending = []                  # (unit, [(read index, temp reg)]) issued, adds not yet emitted
     acc = {"t": ["%[ta]", "%[tb]", "%[tc]"], "u": ["%[ua]", "%[ub]", "%[uc]"]}
 
@@ -112,7 +115,9 @@ def build(with_search, with_c0):
                 if col < 2:
                     a = XN; off = 2 * k * RB + 512 * col
                 else:
-                    a = g.clamped("%[sN]", "%[vL2]"); off = 2 * k * RB
+                    if k == 0 or not HOIST:                             # one address for the third column of all seven rows (no search unit is issued after this:
+                        XL[0] = g.clamped("%[sN]", "%[vL2]")            # the rotating temporary stays untouched until the stream's last write)
+                    a = XL[0]; off = 2 * k * RB
                 regs.append((g.read(dst, a, off), dst))
         pending.append((u, regs))
 
