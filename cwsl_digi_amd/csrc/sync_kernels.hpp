@@ -1013,6 +1013,9 @@ __device__ __forceinline__ void wave_first_max(float v, int lag, float &best, in
 // wave_first_max is a move, a DPP move and two v_max (one to canonicalise) per step plus four v_readlane and three more maxima: ~36 issue slots per
 // reduction, 72 of a bin's ~340; here 2 x 13.  The two chains interleave (a DPP read of a register wants two wait states behind its VALU write).  No
 // NaN reaches this (sync_finish returns 0 for 0 / 0), a maximum is exact: the same values, the same first lane.
+#ifndef CWSLG_SEARCH_HOISTPTR
+#define CWSLG_SEARCH_HOISTPTR 1          // the four result pointers fetched once per band (0: inside the bin loop, where the statement's memory clobber makes them a scalar load and a wait per bin)
+#endif
 #ifndef CWSLG_SEARCH_DPPMAX
 #define CWSLG_SEARCH_DPPMAX 1          // 0: hipcc's wave_first_max twice (the A/B partner: scripts/gpu_r5_dppmax.sh)
 #endif
@@ -1246,6 +1249,10 @@ __device__ __forceinline__ void sync2d_search_band(const SyncWork *w, unsigned s
 #pragma unroll
     for (int n = 4; n < 7; ++n) { const int p = lane + 120 + 2 * n; vC[n - 4] = 8u * (unsigned)(p > PP - 1 ? PP - 1 : p); }
     const unsigned vU = 8u * (unsigned)lane, vL2 = 8u * (unsigned)(lane + 128 > PP - 1 ? PP - 1 : lane + 128);
+#if CWSLG_SEARCH_HOISTPTR
+    float *const p_red = w->red, *const p_red2 = w->red2;
+    int *const p_jpeak = w->jpeak, *const p_jpeak2 = w->jpeak2;
+#endif
     int rr = wvu;
     while (rr < SYNC_BAND && i0 + rr < ia) rr += NW;       // (a band may start below the first searched bin)
     bool live = rr < SYNC_BAND && i0 + rr <= ib;           // wave-uniform
@@ -1299,8 +1306,13 @@ __device__ __forceinline__ void sync2d_search_band(const SyncWork *w, unsigned s
         wave_first_max(b1 ? nb : na, b1 ? j + 1 : j, r1, l1);
 #endif
         if (lane == 0) {
+#if CWSLG_SEARCH_HOISTPTR
+            as_global_rw(p_red)[bin] = r1;  as_global_rw(p_jpeak)[bin] = l1;
+            as_global_rw(p_red2)[bin] = r2; as_global_rw(p_jpeak2)[bin] = l2;
+#else
             as_global_rw(w->red)[bin] = r1;  as_global_rw(w->jpeak)[bin] = l1;       // (HBM addresses: global_store, not flat_store)
             as_global_rw(w->red2)[bin] = r2; as_global_rw(w->jpeak2)[bin] = l2;
+#endif
         }
         if (rr == rr0) SSTAMP(5);
         rr = rn;
