@@ -498,6 +498,9 @@ __device__ __forceinline__ void spectra_stage1_regs(const float2 (&z)[AMAX], flo
 #ifndef CWSLG_SPEC_WAVES
 #define CWSLG_SPEC_WAVES 4
 #endif
+#ifndef CWSLG_SPEC_HOISTPTR
+#define CWSLG_SPEC_HOISTPTR 1
+#endif
 #ifndef CWSLG_SPEC_TIGHT
 #define CWSLG_SPEC_TIGHT 1             // 0: the addressing / prefetch forms of round 4 (the A/B partner: scripts/gpu_r5_dppmax.sh with SWITCH=CWSLG_SPEC_TIGHT)
 #endif
@@ -569,6 +572,7 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     // (6 resident workgroups per CU, lifetime = latency + arithmetic: VALU 65 % busy); now only the first step of a
     // workgroup does.
     const CWSLG_GLOBAL unsigned *d32 = as_global(reinterpret_cast<const unsigned *>(w->frame)) + b_;
+    float *const plane = w->spectra;                      // (fetched here: behind the loop's barriers -- memory clobbers -- it was a scalar load and a wait per transform)
     unsigned raw[AMAX];
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) raw[a] = (128 * a + b_ < NPACK) ? d32[(STEP / 2) * j0 + 128 * a] : 0u;
@@ -671,7 +675,7 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     // the PREVIOUS step's power row leaves now (16 B per lane): issued ahead of the prefetch, its stores have a whole
     // transform to retire before the top of the next iteration waits for vmcnt(0)
     if (j > j0) {
-        CWSLG_GLOBAL v4f *out4 = reinterpret_cast<CWSLG_GLOBAL v4f *>(as_global_rw(w->spectra) + (size_t)(j - 1) * nbins);
+        CWSLG_GLOBAL v4f *out4 = reinterpret_cast<CWSLG_GLOBAL v4f *>(as_global_rw(CWSLG_SPEC_HOISTPTR ? plane : w->spectra) + (size_t)(j - 1) * nbins);
         // by waves 2-3 only when stage 1 is the prime-factor form: their half of it is 32 instructions shorter than waves 0-1's (stamps: they
         // waited ~430 cycles at the barrier behind stage 1)
         if (NA == 15) { if (tid >= 128) for (int k4 = tid - 128; 4 * k4 < nbins; k4 += 128) plane_store(out4 + k4, *reinterpret_cast<const v4f *>(s_pw + 4 * k4)); }
