@@ -980,6 +980,9 @@ __global__ __launch_bounds__(64) void demod_transition_kernel(const TransWork *_
 //   factor = 32767.0f / (peak + 1.0f); factor *= scale;  buf[k] *= factor;  (int16)(buf[k] + 0.5f)
 // The peak is max|audio| (max(maxVal, |minVal|) == max|x| for every frame).
 // Samples at and beyond n_valid are the reference's zero tail.
+#ifndef CWSLG_FIN_NT
+#define CWSLG_FIN_NT 0                 // bit 0: non-temporal loads of the float frame, bit 1: non-temporal stores of the int16 frame (A/B: profiles/r5_experiments.txt)
+#endif
 constexpr int kFinChunks = 4;          // 8-sample chunks per thread of finalize_kernel: four 32-byte reads in flight per lane
 template <int NT>
 __global__ __launch_bounds__(NT) void finalize_kernel(const FinWork *__restrict__ works)
@@ -1002,8 +1005,13 @@ __global__ __launch_bounds__(NT) void finalize_kernel(const FinWork *__restrict_
     for (int c = 0; c < kFinChunks; ++c) {
         const unsigned i0 = base + (unsigned)c * (NT * 8);
         if (i0 + 8 <= nv) {
-            a[c] = *reinterpret_cast<const CWSLG_GLOBAL v4f *>(frame + i0);
-            b[c] = *reinterpret_cast<const CWSLG_GLOBAL v4f *>(frame + i0 + 4);
+            if (CWSLG_FIN_NT & 1) {                              // the float frame is read once
+                a[c] = __builtin_nontemporal_load(reinterpret_cast<const CWSLG_GLOBAL v4f *>(frame + i0));
+                b[c] = __builtin_nontemporal_load(reinterpret_cast<const CWSLG_GLOBAL v4f *>(frame + i0 + 4));
+            } else {
+                a[c] = *reinterpret_cast<const CWSLG_GLOBAL v4f *>(frame + i0);
+                b[c] = *reinterpret_cast<const CWSLG_GLOBAL v4f *>(frame + i0 + 4);
+            }
         } else {
             float v[8];
 #pragma unroll
@@ -1036,7 +1044,8 @@ __global__ __launch_bounds__(NT) void finalize_kernel(const FinWork *__restrict_
         pk.w = ((unsigned)q[6] & 0xFFFFu) | ((unsigned)q[7] << 16);
         const unsigned rem = flen - i0;
         if (rem >= 8) {
-            *reinterpret_cast<CWSLG_GLOBAL v4u *>(out + i0) = pk;
+            if (CWSLG_FIN_NT & 2) __builtin_nontemporal_store(pk, reinterpret_cast<CWSLG_GLOBAL v4u *>(out + i0));
+            else *reinterpret_cast<CWSLG_GLOBAL v4u *>(out + i0) = pk;
         } else {
             for (unsigned k = 0; k < rem; ++k) out[i0 + k] = (int16_t)q[k];
         }
