@@ -806,7 +806,10 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
 //   Requires q_first, n_blocks, seg_len multiples of 4, lo_mod and the ring's length multiples of 4 D samples (the push granularity) and the ring
 //   shorter than 4 GiB (host-checked).  At 96 / 48 kHz a block is 64 / 32 bytes: the wave still moves 128-byte rows (two / four tiles per row).
 #include "exact5_asm.inc"
-constexpr int kExact5Waves = 4;
+#ifndef CWSLG_EXACT5_WAVES
+#define CWSLG_EXACT5_WAVES 4
+#endif
+constexpr int kExact5Waves = CWSLG_EXACT5_WAVES;       // waves per workgroup (no barrier anywhere: any count works; A/B in profiles/r5_experiments.txt)
 template <int D>
 __global__ __launch_bounds__(64 * kExact5Waves, 2) void demod_exact5_kernel(const ChanWork *__restrict__ works, const float *__restrict__ taps, int chunks_x,
                                                                               int n_ch, int seg_len, unsigned long long *__restrict__ clk)
