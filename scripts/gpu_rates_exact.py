@@ -1,6 +1,7 @@
-"""Demod launch time at 48 / 96 / 192 kHz in both arithmetic modes (512 FT8 slots, no sync stage), with the in-kernel clock: one JSON line.
-Usage: python scripts/gpu_rates_exact.py  (set CWSLG_LIB / CWSLG_DEMOD_VARIANT to pick a measured alternative from the lab library)."""
+"""Demod launch time at 48 / 96 / 192 kHz in both arithmetic modes (512 FT8 slots unless --slots N, no sync stage), with the in-kernel clock: one JSON line.
+Usage: python scripts/gpu_rates_exact.py [--slots N] (set CWSLG_LIB / CWSLG_DEMOD_VARIANT to pick a measured alternative from the lab library)."""
 import json, os, sys
+SLOTS = int(sys.argv[sys.argv.index("--slots") + 1]) if "--slots" in sys.argv else 512
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: F401
@@ -10,7 +11,7 @@ for fs in (48000, 96000, 192000):
     for exact in (True, False):
         ctx = P.Context(0)
         ctx.set_exact(exact)
-        S, BLK = 512, 2048
+        S, BLK = SLOTS, 2048
         N = 15 * fs
         rb = N // BLK + 3
         for s in range(S):

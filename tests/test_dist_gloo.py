@@ -84,3 +84,31 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     assert p.returncode == 2 and "WORLD_SIZE=4 but --gpus 2" in p.stderr
     p = _bench("--gpus", "1", "--dry-run", env_extra={"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
     assert p.returncode == 2
+
+
+def test_bench_at_the_drivers_world_size_of_eight():
+    """N = 8 first contact on the CPU: (1) `python bench.py --gpus 8 --dry-run` through bench.py's own launcher and (2) the command the driver
+    runs at round end, word for word (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus 8 --steps K --warmup W`) plus --dry-run: eight gloo ranks join, rank 0 alone prints the line, 4096 slots per rank
+    (weak scaling: configs[3]'s 512 per GPU is `--slots 512`)."""
+    import json
+    import subprocess
+    import sys
+    p = _bench("--gpus", "8", "--dry-run", timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "--nproc-per-node=8" in p.stderr
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                           # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["dry_run"] is True and line["scaling"] == "weak"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1", "--slots", "512", "--dry-run"]
+    q = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert q.returncode == 0, q.stderr[-2000:]
+    lines = [l for l in q.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["ranks_seen"] == 8 and line["steps"] == 3 and line["warmup"] == 1
+    assert "512 FT8 slots/GPU x 8 ranks" in line["config"]["workload"]

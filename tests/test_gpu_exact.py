@@ -55,7 +55,7 @@ def test_exact_other_rates(ctx, oracle, fs, block, mode):
     assert np.array_equal(g["i16"], r["i16"])
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "slot_ft*.npz"))), ids=os.path.basename)
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "slot_*.npz"))), ids=os.path.basename)
 def test_exact_golden_bitwise(ctx, oracle, path):
     """Against fixtures made from the compiled reference itself: audio bits, factor bits, int16 CRC32."""
     g = np.load(path)
