@@ -98,6 +98,11 @@ class Fst4wCandidate(C.Structure):
     _fields_ = [("freq_hz", C.c_float), ("snr", C.c_float), ("bin", C.c_int32), ("pad_", C.c_int32)]
 
 
+class SlotResult(C.Structure):
+    _fields_ = [("start_epoch", C.c_uint64), ("n_valid", C.c_uint64), ("factor", C.c_float), ("list_kind", C.c_int32),
+                ("n_list", C.c_int32), ("n_ft4_sync", C.c_int32)]
+
+
 class Stats(C.Structure):
     _fields_ = [("demod_launches", C.c_uint64), ("demod_samples", C.c_uint64),
                 ("finalize_launches", C.c_uint64), ("sync_launches", C.c_uint64), ("frames_emitted", C.c_uint64),
@@ -106,7 +111,8 @@ class Stats(C.Structure):
                 ("sync_ms", C.c_double), ("phasor_regrows", C.c_uint64), ("rendezvous_calls", C.c_uint64),
                 ("rendezvous_frames", C.c_uint64), ("rccl_world", C.c_uint64), ("rendezvous_flags_and", C.c_uint64),
                 ("demod_clock_mhz", C.c_double), ("demod_clock_launches", C.c_uint64), ("push_calls", C.c_uint64),
-                ("push_batches", C.c_uint64), ("push_host_ms", C.c_double), ("sync_spectra_ms", C.c_double), ("sync_search_ms", C.c_double)]
+                ("push_batches", C.c_uint64), ("push_host_ms", C.c_double), ("sync_spectra_ms", C.c_double), ("sync_search_ms", C.c_double),
+                ("demod_blocks_read", C.c_uint64), ("process_deferred", C.c_uint64)]
 
 
 # int (*)(void *user, int group, uint64_t epoch_s, uint64_t frames_local, uint64_t *frames_total)
@@ -119,11 +125,11 @@ ABI_SYMBOLS = [
     "cwslg_abi_version", "cwslg_create", "cwslg_destroy", "cwslg_strerror", "cwslg_last_error",
     "cwslg_set_scale_factors", "cwslg_set_exact", "cwslg_receiver_open", "cwslg_receiver_close", "cwslg_push_iq", "cwslg_push_iq_many",
     "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_parse_decoder_line", "cwslg_channel_open_line", "cwslg_channel_open", "cwslg_channel_close", "cwslg_channel_tune", "cwslg_channel_tune_ex",
-    "cwslg_channel_info", "cwslg_process", "cwslg_slot_boundary", "cwslg_slot_boundary_begin", "cwslg_slot_boundary_end", "cwslg_slot_boundary_channel",
+    "cwslg_channel_info", "cwslg_process", "cwslg_set_process_threshold", "cwslg_slot_boundary", "cwslg_slot_boundary_begin", "cwslg_slot_boundary_end", "cwslg_slot_boundary_channel",
     "cwslg_set_boundary_rendezvous", "cwslg_set_rendezvous_flag", "cwslg_rccl_unique_id", "cwslg_rccl_init",
     "cwslg_enable_long_sync", "cwslg_fetch_wspr_candidates", "cwslg_fetch_fst4w_candidates", "cwslg_long_sync_debug_fetch",
-    "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_write_wav", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
-    "cwslg_enable_sync", "cwslg_fetch_candidates", "cwslg_set_ft4_syncmin", "cwslg_enable_ft4_coherent", "cwslg_fetch_ft4_sync", "cwslg_sync_debug_fetch", "cwslg_get_stats", "cwslg_reset_stats",
+    "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_fetch_slot", "cwslg_write_wav", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
+    "cwslg_enable_sync", "cwslg_set_candidate_order", "cwslg_fetch_candidates", "cwslg_set_ft4_syncmin", "cwslg_enable_ft4_coherent", "cwslg_fetch_ft4_sync", "cwslg_sync_debug_fetch", "cwslg_get_stats", "cwslg_reset_stats",
     "cwslg_set_timing", "cwslg_demod_kernel_name", "cwslg_stream", "cwslg_channel_constants", "cwslg_phasor_checkpoint_stride", "cwslg_channel_phasor_checkpoints",
     "cwslg_slot_clock_next", "cwslg_pool_sizing", "cwslg_find_band", "cwslg_parse_decode_line",
     "cwslg_decoder_block_bytes", "cwslg_decoder_block_field", "cwslg_fill_decoder_block", "cwslg_decoder_route", "cwslg_decoder_command",
@@ -170,8 +176,9 @@ def load_library(build_if_missing=True):
     L.cwslg_rccl_unique_id.argtypes = [vp]
     L.cwslg_rccl_init.argtypes = [vp, vp, i32, i32]
     L.cwslg_enable_long_sync.argtypes = [vp, i32, i32, i32, f32]
-    L.cwslg_fetch_wspr_candidates.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
-    L.cwslg_fetch_fst4w_candidates.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
+    L.cwslg_fetch_wspr_candidates.argtypes = [vp, i32, vp, i32, C.POINTER(i32), C.POINTER(u64)]
+    L.cwslg_fetch_fst4w_candidates.argtypes = [vp, i32, vp, i32, C.POINTER(i32), C.POINTER(u64)]
+    L.cwslg_fetch_slot.argtypes = [vp, i32, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(Ft4Sync), i32, C.POINTER(SlotResult)]
     L.cwslg_long_sync_debug_fetch.argtypes = [vp, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.cwslg_receiver_open.argtypes = [vp, u32, u32, C.c_int32, u32, C.POINTER(i32)]
     L.cwslg_receiver_close.argtypes = [vp, i32]
@@ -190,6 +197,7 @@ def load_library(build_if_missing=True):
     L.cwslg_channel_tune_ex.argtypes = [vp, i32, C.c_int32, i32, i32]
     L.cwslg_channel_info.argtypes = [vp, i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_size_t)]
     L.cwslg_process.argtypes = [vp]
+    L.cwslg_set_process_threshold.argtypes = [vp, i32]
     L.cwslg_slot_boundary.argtypes = [vp, i32, u64]
     L.cwslg_slot_boundary_begin.argtypes = [vp, i32, u64]
     L.cwslg_slot_boundary_end.argtypes = [vp]
@@ -200,10 +208,11 @@ def load_library(build_if_missing=True):
     L.cwslg_fetch_audio_f32.argtypes = [vp, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.cwslg_frame_device_ptrs.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
     L.cwslg_enable_sync.argtypes = [vp, i32, f32, i32, i32, i32]
-    L.cwslg_fetch_candidates.argtypes = [vp, i32, C.POINTER(Candidate), i32, C.POINTER(i32)]
+    L.cwslg_fetch_candidates.argtypes = [vp, i32, C.POINTER(Candidate), i32, C.POINTER(i32), C.POINTER(u64)]
+    L.cwslg_set_candidate_order.argtypes = [vp, i32]
     L.cwslg_set_ft4_syncmin.argtypes = [vp, f32]
     L.cwslg_enable_ft4_coherent.argtypes = [vp, i32]
-    L.cwslg_fetch_ft4_sync.argtypes = [vp, i32, C.POINTER(Ft4Sync), i32, C.POINTER(i32)]
+    L.cwslg_fetch_ft4_sync.argtypes = [vp, i32, C.POINTER(Ft4Sync), i32, C.POINTER(i32), C.POINTER(u64)]
     L.cwslg_sync_debug_fetch.argtypes = [vp, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(i32)]
     L.cwslg_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.cwslg_reset_stats.argtypes = [vp]
@@ -405,6 +414,10 @@ class Context:
     def process(self):
         self._chk(self.L.cwslg_process(self.h))
 
+    def set_process_threshold(self, min_outputs=-1):
+        """cwslg_set_process_threshold: 0 every process() launches; > 0 only once a channel has that many outputs pending; < 0 the library's own."""
+        self._chk(self.L.cwslg_set_process_threshold(self.h, int(min_outputs)))
+
     def slot_boundary(self, group, epoch_s):
         if isinstance(group, str):                       # a group name ("S120") or a mode name ("WSPR" -> its group)
             g = GROUPS[group] if group in GROUPS else _MODE_GROUP[group]
@@ -503,11 +516,46 @@ class Context:
     def enable_sync(self, enable=True, syncmin=1.5, max_cand=200, f_lo_hz=200, f_hi_hz=3000):
         self._chk(self.L.cwslg_enable_sync(self.h, 1 if enable else 0, syncmin, max_cand, f_lo_hz, f_hi_hz))
 
-    def fetch_candidates(self, ch, max_cand=600):
+    def set_candidate_order(self, order="sync"):
+        """'sync' (default): strongest first, cut at max_cand in that order; 'freq': ascending frequency, cut in THAT order."""
+        self._chk(self.L.cwslg_set_candidate_order(self.h, {"sync": 0, "freq": 1}[order]))
+
+    def fetch_candidates(self, ch, max_cand=600, with_epoch=False):
+        """[(freq_bin, time_step, sync, freq_hz, dt_s)]; with_epoch: (list, start epoch of the frame the list was computed from)."""
         buf = (Candidate * max_cand)()
         n = C.c_int()
-        self._chk(self.L.cwslg_fetch_candidates(self.h, ch, buf, max_cand, C.byref(n)))
-        return [(buf[k].freq_bin, buf[k].time_step, buf[k].sync, buf[k].freq_hz, buf[k].dt_s) for k in range(n.value)]
+        t0 = C.c_uint64()
+        self._chk(self.L.cwslg_fetch_candidates(self.h, ch, buf, max_cand, C.byref(n), C.byref(t0)))
+        out = [(buf[k].freq_bin, buf[k].time_step, buf[k].sync, buf[k].freq_hz, buf[k].dt_s) for k in range(n.value)]
+        return (out, t0.value) if with_epoch else out
+
+    def fetch_slot(self, ch, max_list=1000, max_ft4=3000, want_frame=True):
+        """cwslg_fetch_slot: frame + candidate list(s) of ONE epoch under one ticket.  -> None before the first frame, else a dict with
+        i16 (or None), t_start, n_valid, factor, list_kind ('none' / 'FT8' / 'FT4' / 'WSPR' / 'FST4W'), list (tuples in the layout of the
+        matching fetch_*_candidates call) and ft4_sync (dicts as fetch_ft4_sync)."""
+        n = frame_len(self._modes[ch])
+        out = np.empty(n, np.int16) if want_frame else None
+        item = max(C.sizeof(Candidate), C.sizeof(WsprCandidate), C.sizeof(Fst4wCandidate))
+        raw = (C.c_char * (item * max_list))()
+        ft4 = (Ft4Sync * max_ft4)()
+        res = SlotResult()
+        rc = self.L.cwslg_fetch_slot(self.h, ch, out.ctypes.data if want_frame else None, n if want_frame else 0, raw, len(raw), ft4, max_ft4, C.byref(res))
+        if rc == ERR_NO_FRAME:
+            return None
+        self._chk(rc)
+        kind = ("none", "FT8", "FT4", "WSPR", "FST4W")[res.list_kind]
+        lst = []
+        if kind in ("FT8", "FT4"):
+            b = C.cast(raw, C.POINTER(Candidate))
+            lst = [(b[k].freq_bin, b[k].time_step, b[k].sync, b[k].freq_hz, b[k].dt_s) for k in range(res.n_list)]
+        elif kind == "WSPR":
+            b = C.cast(raw, C.POINTER(WsprCandidate))
+            lst = [(b[k].freq_hz, b[k].snr_db, b[k].drift, b[k].sync, b[k].shift) for k in range(res.n_list)]
+        elif kind == "FST4W":
+            b = C.cast(raw, C.POINTER(Fst4wCandidate))
+            lst = [(b[k].freq_hz, b[k].snr, b[k].bin) for k in range(res.n_list)]
+        f4 = [dict(f0_hz=b.f0_hz, f1_hz=b.f1_hz, dt_s=b.dt_s, sync=b.sync, ibest=b.ibest, idf=b.idf, seg=b.seg, cand=b.cand) for b in ft4[:res.n_ft4_sync]]
+        return dict(i16=out, t_start=res.start_epoch, n_valid=res.n_valid, factor=res.factor, list_kind=kind, list=lst, ft4_sync=f4)
 
     def enable_ft4_coherent(self, enable=True):
         self._chk(self.L.cwslg_enable_ft4_coherent(self.h, int(enable)))
@@ -516,7 +564,7 @@ class Context:
         """Refined FT4 candidates (ft4_downsample + sync4d search): list of dicts, candidate order then segment order."""
         buf = (Ft4Sync * max_rec)()
         n = C.c_int()
-        rc = self.L.cwslg_fetch_ft4_sync(self.h, ch, buf, max_rec, C.byref(n))
+        rc = self.L.cwslg_fetch_ft4_sync(self.h, ch, buf, max_rec, C.byref(n), None)
         if rc == ERR_NO_FRAME:
             return None
         self._chk(rc)
@@ -527,25 +575,29 @@ class Context:
         """Candidate search of the 120 s modes (WSPR: wsprd's front end; FST4W-120: get_candidates_fst4 over nfa..nfb)."""
         self._chk(self.L.cwslg_enable_long_sync(self.h, 1 if on else 0, nfa_hz, nfb_hz, minsync))
 
-    def fetch_wspr_candidates(self, ch, max_cand=200):
-        """-> None until a frame was searched, else [(freq_hz, snr_db, drift, sync, shift)]."""
+    def fetch_wspr_candidates(self, ch, max_cand=200, with_epoch=False):
+        """-> None until a frame was searched, else [(freq_hz, snr_db, drift, sync, shift)] (with_epoch: (list, frame start epoch))."""
         buf = (WsprCandidate * max_cand)()
         n = C.c_int()
-        rc = self.L.cwslg_fetch_wspr_candidates(self.h, ch, buf, max_cand, C.byref(n))
+        t0 = C.c_uint64()
+        rc = self.L.cwslg_fetch_wspr_candidates(self.h, ch, buf, max_cand, C.byref(n), C.byref(t0))
         if rc == ERR_NO_FRAME:
             return None
         self._chk(rc)
-        return [(b.freq_hz, b.snr_db, b.drift, b.sync, b.shift) for b in buf[:n.value]]
+        out = [(b.freq_hz, b.snr_db, b.drift, b.sync, b.shift) for b in buf[:n.value]]
+        return (out, t0.value) if with_epoch else out
 
-    def fetch_fst4w_candidates(self, ch, max_cand=100):
-        """-> None until a frame was searched, else [(freq_hz, snr, bin)]."""
+    def fetch_fst4w_candidates(self, ch, max_cand=100, with_epoch=False):
+        """-> None until a frame was searched, else [(freq_hz, snr, bin)] (with_epoch: (list, frame start epoch))."""
         buf = (Fst4wCandidate * max_cand)()
         n = C.c_int()
-        rc = self.L.cwslg_fetch_fst4w_candidates(self.h, ch, buf, max_cand, C.byref(n))
+        t0 = C.c_uint64()
+        rc = self.L.cwslg_fetch_fst4w_candidates(self.h, ch, buf, max_cand, C.byref(n), C.byref(t0))
         if rc == ERR_NO_FRAME:
             return None
         self._chk(rc)
-        return [(b.freq_hz, b.snr, b.bin) for b in buf[:n.value]]
+        out = [(b.freq_hz, b.snr, b.bin) for b in buf[:n.value]]
+        return (out, t0.value) if with_epoch else out
 
     def long_sync_debug(self, ch, what):
         """what: 'iq' complex64[46080], 'ps' float32[512, 359] (wsprd's ps[j][i]), 'smspec' float32[411] (WSPR);

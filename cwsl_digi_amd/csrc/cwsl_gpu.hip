@@ -194,7 +194,7 @@ struct Channel {
     uint64_t frame_t0 = 0;
     size_t frame_valid = 0;
     // sync results
-    int n_cand = 0;
+    uint64_t cand_t0 = 0;              // start epoch of the frame the candidate lists on the device were computed from (0: none yet)
     SyncChannelBuffers syncbuf;
 };
 
@@ -250,16 +250,17 @@ struct cwslg_ctx {
     // frames out: D2H copies of finalised frames run on their own streams behind ONE event recorded after the boundary's kernels (at the
     // first fetch of a frame generation), with the context mutex released -- 4096 fetches do not serialise pushes, launches or each other
     hipStream_t fetch_stream[kFetchStreams] = {};
-    hipEvent_t fetch_ev = nullptr;
-    bool fetch_ev_valid = false;
+    hipEvent_t fetch_ev[CWSLG_NUM_GROUPS] = {};          // one per slot-clock group: a group's boundary concerns that group's readers only
+    bool fetch_ev_valid[CWSLG_NUM_GROUPS] = {};
     unsigned fetch_rr = 0;
-    // Frames are handed out whole (Instance.cpp:238-245 copies the frame into the ItemToDecode it pushes, DecoderPool.hpp:174-210): a fetch
-    // registers here under `mu` before it releases it; the next boundary -- the only writer of d_i16 / d_factor -- waits, under `mu`, until
-    // every registered copy has finished before it queues its finalise.  A fetch therefore returns the frame of the start_epoch it reports,
-    // never the next slot's samples under it, and the shared fetch_ev is never re-recorded under a waiter.
+    // Results are handed out whole (Instance.cpp:238-245 copies the frame into the ItemToDecode it pushes, DecoderPool.hpp:174-210): a fetch of
+    // a frame or of a candidate list registers here under `mu` before it releases it; the next boundary OF THAT GROUP -- the only writer of the
+    // group's d_i16 / d_factor / candidate buffers -- waits, under `mu`, until every registered copy has finished before it queues its kernels.
+    // A fetch therefore returns the results of the start_epoch it reports, never the next slot's under it, and a group's fetch_ev is never
+    // re-recorded under a waiter.  (Round 6: per group -- an FT8 consumer no longer delays an FT4 boundary -- and candidate lists included.)
     std::mutex fetch_mu;
     std::condition_variable fetch_cv;
-    int fetch_inflight = 0;            // guarded by fetch_mu (incremented with mu held, decremented without)
+    int fetch_inflight[CWSLG_NUM_GROUPS] = {};           // guarded by fetch_mu (incremented with mu held, decremented without)
     std::shared_mutex life_mu;         // shared: a fetch's copy is in flight; exclusive: a close frees device buffers (order: mu, then life_mu)
     BatchStage batch[kBatchStages];
     std::atomic<unsigned> batch_next{0};
@@ -269,6 +270,7 @@ struct cwslg_ctx {
     unsigned long long *clk_h = nullptr, *clk_dev = nullptr;
     unsigned clk_head = 0, clk_tail = 0;
     unsigned exact5_seg_cap = kExact5SegCap, exact5_seg_force = 0;
+    int process_min_outputs = 0;       // cwslg_set_process_threshold: 0 every cwslg_process() launches, < 0 the library's own threshold, > 0 that many outputs
     bool use_exact5 = true;            // exact mode: demod_exact5_kernel<D> (lab build: a non-zero CWSLG_DEMOD_VARIANT selects round 3/4's tile kernels instead)
     unsigned stat_gen = 0;             // bumped by cwslg_reset_stats: work timed before a reset is not folded into the figures read after it
     double clk_sum_mhz = 0.0;
@@ -583,8 +585,14 @@ int restore_open_tuning(cwslg_ctx *c, Channel &ch, const Receiver &rx)
 
 // demod_exact5_kernel (192 kHz, exact mode): one wave per (channel, chunk of 32 streams x seg_len outputs).  seg_len trades the 32-block warm-up
 // of every stream (32 / seg_len of extra work) against waves to fill the chip with: at least two rounds of resident waves where the work allows.
+// Round 6: that choice is the LATENCY policy -- right at a slot boundary, where frames are waited for (with few pending blocks it goes down to 4
+// outputs per stream: 36 tiles for 4 outputs, nine times the arithmetic, but every wave slot of the chip busy and the launch as short as it can be).
+// A launch that nobody waits for -- cwslg_process() in the middle of a slot, or ring pressure -- takes the THROUGHPUT policy instead: streams as
+// long as the channel with the most pending blocks allows with all 32 lanes of its wave busy (max_blocks / 32), i.e. one wave per channel and
+// warm-up share 32 / seg, unless the latency policy's streams are longer still (bench scale).  stats.demod_blocks_read counts the blocks a
+// launch actually fetches and puts through the arithmetic, warm-up included: demod_blocks_read x D / demod_samples is the redundancy.
 template <int D>
-int launch_exact5(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_blocks, uint32_t fs, bool chunk_major)
+int launch_exact5(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_blocks, uint32_t fs, bool chunk_major, bool latency)
 {
     if (works.empty()) return CWSLG_OK;
     uint64_t total_blocks = 0;
@@ -592,8 +600,13 @@ int launch_exact5(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max
     const uint64_t waves_min = (uint64_t)c->cu_count * 8 * 2;
     unsigned seg = (unsigned)std::min<uint64_t>(c->exact5_seg_cap, (total_blocks + 32 * waves_min - 1) / (32 * waves_min));
     seg = std::max(4u, (seg + 3) / 4 * 4);
+    if (!latency) seg = std::max(seg, std::min(c->exact5_seg_cap, max_blocks / 32 / 4 * 4));
     if (c->exact5_seg_force) seg = c->exact5_seg_force;
     const int chunks = (int)((max_blocks + 32 * seg - 1) / (32 * seg));
+    for (const ChanWork &w : works) {                   // streams of seg outputs (the last one shorter), each 32 blocks of warm-up
+        const uint64_t streams = ((uint64_t)w.n_blocks + seg - 1) / seg;
+        c->stats.demod_blocks_read += w.n_blocks + 32 * streams;
+    }
     WorkBuf *w = acquire_workbuf(c, works.size() * sizeof(ChanWork));
     if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
     std::memcpy(w->h, works.data(), works.size() * sizeof(ChanWork));
@@ -619,7 +632,7 @@ int launch_exact5(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max
 }
 
 template <int D>
-int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_blocks, uint32_t fs, bool tile_major)
+int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_blocks, uint32_t fs, bool tile_major, bool latency)
 {
     if (works.empty()) return CWSLG_OK;
     if (c->exact && c->use_exact5) {
@@ -629,7 +642,7 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
         for (const ChanWork &w : works)
             aligned = aligned && w.q_first >= 0 && w.q_first % 4 == 0 && w.n_blocks % 4 == 0 && w.lo_mod % (4 * D) == 0 && w.ring_cap % (4 * D) == 0 &&
                       (uint64_t)w.ring_cap * 8 < (1ull << 32) - 4096;      // (32-bit byte offsets into the ring, advanced by up to 512 before the wrap test)
-        if (aligned) return launch_exact5<D>(c, works, max_blocks, fs, tile_major);
+        if (aligned) return launch_exact5<D>(c, works, max_blocks, fs, tile_major, latency);
     }
     // the descriptors, then (64-byte aligned) eight per-XCD work counters (the lab library's persistent tile kernels draw from them), zero at launch
     const size_t ctr_off = (works.size() * sizeof(ChanWork) + 63) & ~size_t(63);
@@ -651,6 +664,8 @@ int launch_demod(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_
     if (small_tile) tile = 192;
 #endif
     const int tiles_n = (int)((max_blocks + tile - 1) / tile);
+    for (const ChanWork &cw : works)                            // a tile of T outputs reads T + 31 blocks (the filter's history)
+        c->stats.demod_blocks_read += cw.n_blocks + 31 * (((uint64_t)cw.n_blocks + tile - 1) / tile);
     const int tiles_x = tile_major ? -tiles_n : tiles_n;        // sign selects the work-item order (demod_kernels.hpp)
     const long long total = (long long)tiles_n * (long long)works.size();
     const long long per_xcd = (total + 7) / 8;
@@ -724,8 +739,9 @@ inline size_t ckpt_need(long long q_first, unsigned n_blocks)
     return (size_t)(last / kCkptStride) + 4;
 }
 
-// Demodulate everything pending.  Caller holds the mutex.
-int process_locked(cwslg_ctx *c)
+// Demodulate everything pending.  Caller holds the mutex.  latency: somebody waits for the result (a slot boundary, a retune, a mode switch) --
+// see launch_exact5 for what that selects; cwslg_process() and ring pressure pass false.
+int process_locked(cwslg_ctx *c, bool latency = true)
 {
     int rc = CWSLG_OK;
     // The phasor recurrence restarts only when a frame is EMITTED (Instance.cpp:251).  A channel whose boundaries keep
@@ -828,9 +844,9 @@ int process_locked(cwslg_ctx *c)
         const uint32_t D = fs / kWaveSR;
         // receivers shared by several channels: tile-major order (the IQ tile is fetched once, then served from L2)
         const bool tile_major = c->order_override ? (c->order_override == 2) : (max_share[fs] >= 2);
-        if (D == 16) rc = launch_demod<16>(c, kv.second, max_blocks[fs], fs, tile_major);
-        else if (D == 8) rc = launch_demod<8>(c, kv.second, max_blocks[fs], fs, tile_major);
-        else if (D == 4) rc = launch_demod<4>(c, kv.second, max_blocks[fs], fs, tile_major);
+        if (D == 16) rc = launch_demod<16>(c, kv.second, max_blocks[fs], fs, tile_major, latency);
+        else if (D == 8) rc = launch_demod<8>(c, kv.second, max_blocks[fs], fs, tile_major, latency);
+        else if (D == 4) rc = launch_demod<4>(c, kv.second, max_blocks[fs], fs, tile_major, latency);
         else rc = fail(c, CWSLG_ERR_UNSUPPORTED, "sample rate %u unsupported", fs);
         if (rc) return rc;
     }
@@ -916,23 +932,54 @@ int reserve_ring(cwslg_ctx *c, Receiver &rx, uint32_t n)
         if (ch.open) max_pend = std::max(max_pend, ch.pend_n);
     }
     if ((uint64_t)max_pend + n + hist > rx.cap) {
-        int rc = process_locked(c);      // the reference logs "I/Q buffer is full!" and stalls (Receiver.hpp:222-229)
+        int rc = process_locked(c, false);      // the reference logs "I/Q buffer is full!" and stalls (Receiver.hpp:222-229)
         if (rc) return rc;
     }
     return CWSLG_OK;
 }
 
-// One in-flight cwslg_fetch_frame copy (see cwslg_ctx::fetch_inflight).
+// One in-flight copy of a channel's results (see cwslg_ctx::fetch_inflight).
 struct FetchTicket {
     cwslg_ctx *c = nullptr;
-    void take(cwslg_ctx *ctx) { std::lock_guard<std::mutex> g(ctx->fetch_mu); ++ctx->fetch_inflight; c = ctx; }
+    int group = 0;
+    void take(cwslg_ctx *ctx, int g_) { std::lock_guard<std::mutex> g(ctx->fetch_mu); ++ctx->fetch_inflight[g_]; c = ctx; group = g_; }
     ~FetchTicket()
     {
         if (!c) return;
-        { std::lock_guard<std::mutex> g(c->fetch_mu); --c->fetch_inflight; }
+        { std::lock_guard<std::mutex> g(c->fetch_mu); --c->fetch_inflight[group]; }
         c->fetch_cv.notify_all();
     }
 };
+
+// What a reader of one channel's results holds while it copies them out WITHOUT the context mutex: a ticket of the channel's group (the group's
+// next boundary waits for it), the buffers' lifetime, and a fetch stream ordered behind the group's generation event.  Declaration order
+// matters: members are destroyed in reverse, so the ticket is released BEFORE `life` -- safe, because the context itself outlives both
+// (cwslg_destroy takes life_mu exclusively before it frees anything), and notify_all touches only the context.
+struct ResultFetch {
+    std::shared_lock<std::shared_mutex> life;
+    FetchTicket ticket;
+    hipStream_t fs = nullptr;
+    hipEvent_t ev = nullptr;
+};
+// Caller holds c->mu.  ONE event per group and generation of results, recorded behind everything queued so far (the boundary's finalise and
+// sync kernels); every fetch of the generation waits for it on a fetch stream, not for the compute stream.
+int begin_result_fetch(cwslg_ctx *c, const Channel &ch, ResultFetch &rf)
+{
+    const int g = ch.group;
+    if (!c->fetch_ev_valid[g]) {
+        if (c->cand_pending) {                  // (lab variants only) candidate kernels queued on the side stream: the event follows them
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->cand_done, 0));
+            c->cand_pending = false;
+        }
+        HIPCHK(c, hipEventRecord(c->fetch_ev[g], c->stream));
+        c->fetch_ev_valid[g] = true;
+    }
+    rf.fs = c->fetch_stream[c->fetch_rr++ % kFetchStreams];
+    rf.ev = c->fetch_ev[g];
+    rf.ticket.take(c, g);
+    rf.life = std::shared_lock<std::shared_mutex>(c->life_mu);      // the buffers stay allocated until the copy is done
+    return CWSLG_OK;
+}
 
 int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s, uint64_t *n_emitted = nullptr)
 {
@@ -984,10 +1031,15 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s,
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->cand_done, 0));
         c->cand_pending = false;
     }
-    {   // the finalise below rewrites d_i16 / d_factor: let the copies of the previous generation finish first (each is one frame's D2H copy;
-        // new fetches wait for `mu`, which this thread holds)
+    bool in_group[CWSLG_NUM_GROUPS] = {};
+    for (int id : ids) in_group[c->chans[id].group] = true;
+    {   // the kernels below rewrite d_i16 / d_factor / the candidate buffers of these groups: let the copies of the previous generation finish
+        // first (each is one frame's or one list's D2H copy; new fetches wait for `mu`, which this thread holds)
         std::unique_lock<std::mutex> lk(c->fetch_mu);
-        c->fetch_cv.wait(lk, [&] { return c->fetch_inflight == 0; });
+        c->fetch_cv.wait(lk, [&] {
+            for (int g = 0; g < CWSLG_NUM_GROUPS; ++g) if (in_group[g] && c->fetch_inflight[g] != 0) return false;
+            return true;
+        });
     }
     WorkBuf *w = acquire_workbuf(c, fin.size() * sizeof(FinWork));
     if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
@@ -1004,7 +1056,8 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s,
     w->in_flight = true;
     c->stats.finalize_launches++;
     if (n_emitted) *n_emitted = emitted.size();
-    c->fetch_ev_valid = false;             // a new generation of frames: the next fetch records its event behind this boundary's kernels
+    for (int g = 0; g < CWSLG_NUM_GROUPS; ++g)      // a new generation of results: the next fetch records the group's event behind this boundary's kernels
+        if (in_group[g]) c->fetch_ev_valid[g] = false;
     // optional sync stage on the freshly finalised int16 frames
     if (c->sync_cfg.enabled && !emitted.empty()) {
         rc = sync_launch(c, emitted);
@@ -1113,7 +1166,7 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
     hipEventCreateWithFlags(&c->demod_done, kOrderEvent);
     for (int k = 0; k < kFetchStreams; ++k)
         if (hipStreamCreateWithFlags(&c->fetch_stream[k], hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
-    hipEventCreateWithFlags(&c->fetch_ev, hipEventDisableTiming);      // WITH a system-scope fence: the copy engines read what the kernels wrote
+    for (hipEvent_t &e : c->fetch_ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);      // WITH a system-scope fence: the copy engines read what the kernels wrote
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
     hipEventCreateWithFlags(&c->sync2d_done, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->cand_done, hipEventDisableTiming);
@@ -1162,7 +1215,7 @@ void cwslg_destroy(cwslg_ctx *c)
     if (c->d_sincos) hipFree(c->d_sincos);
     if (c->clk_h) (void)hipHostFree(c->clk_h);
     for (hipStream_t fs : c->fetch_stream) if (fs) { (void)hipStreamSynchronize(fs); (void)hipStreamDestroy(fs); }
-    if (c->fetch_ev) (void)hipEventDestroy(c->fetch_ev);
+    for (hipEvent_t e : c->fetch_ev) if (e) (void)hipEventDestroy(e);
     for (BatchStage &b : c->batch) {
         if (b.h) (void)hipHostFree(b.h);
         if (b.ev) (void)hipEventDestroy(b.ev);
@@ -1340,6 +1393,7 @@ static int push_iq_piece(cwslg_ctx *c, int rx_id, const float *iq, uint32_t n)
     struct Seg { size_t stage_off; uint32_t ring_pos, count; int leaves_half; };
     std::vector<Seg> segs;
     uint32_t done = 0;
+    const size_t pos0 = st.pos;                 // where this piece's staging starts (restored if the piece is refused below)
     while (done < n) {
         const size_t half_samples = kStageHalf / sizeof(float2);
         const int half = (int)(st.pos / kStageHalf);
@@ -1370,7 +1424,12 @@ static int push_iq_piece(cwslg_ctx *c, int rx_id, const float *iq, uint32_t n)
         Receiver &rx = c->rxs[rx_id];
         // the write position was read in step 1: another push on this receiver (a cwslg_push_iq_many batch, or a second thread -- the contract
         // is one pusher per receiver, Receiver.hpp:167) has moved it since, so the staged block would land on top of that push's samples
-        if (rx.total != total0) return fail(c, CWSLG_ERR_ARG, "receiver %d was pushed from two threads at once; nothing accounted", rx_id);
+        if (rx.total != total0) {
+            // nothing of THIS piece was enqueued: give its staging bytes back, so that no half counts as "left" without its fence event having
+            // been recorded (the halves' reuse discipline stays intact); earlier pieces of the same call are already in the ring and accounted
+            st.pos = pos0;
+            return fail(c, CWSLG_ERR_ARG, "receiver %d was pushed from two threads at once; this piece of the call was not accounted (earlier pieces of the same call may be)", rx_id);
+        }
         // ring history that a queued demod launch still reads must not be overwritten under it
         const int cs = rx_id % kCopyStreams;
         hipStream_t cstr = c->copy_on_main ? c->stream : c->copy_stream[cs];
@@ -1871,7 +1930,29 @@ int cwslg_process(cwslg_ctx *c)
     if (!c) return CWSLG_ERR_ARG;
     std::lock_guard<std::mutex> g(c->mu);
     hipSetDevice(c->device);
-    return process_locked(c);
+    if (c->process_min_outputs != 0) {              // cwslg_set_process_threshold: not worth a launch yet?
+        // auto (< 0): exact mode 32 streams x 640 outputs per wave (warm-up share 32 / 640), fast mode eight 256-output tiles (history share 31 / 256)
+        const uint64_t need = c->process_min_outputs > 0 ? (uint64_t)c->process_min_outputs : (c->exact ? 32u * 640u : 8u * 256u);
+        bool due = false;
+        for (const Receiver &rx : c->rxs) {
+            if (!rx.open) continue;
+            for (int id : rx.channels) {
+                const Channel &ch = c->chans[id];
+                if (ch.open && ch.pend_n / rx.D >= need) { due = true; break; }
+            }
+            if (due) break;
+        }
+        if (!due) { c->stats.process_deferred++; return CWSLG_OK; }
+    }
+    return process_locked(c, false);
+}
+
+int cwslg_set_process_threshold(cwslg_ctx *c, int min_outputs)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->process_min_outputs = min_outputs;
+    return CWSLG_OK;
 }
 
 int cwslg_slot_boundary(cwslg_ctx *c, int group, uint64_t epoch_s)
@@ -1983,12 +2064,10 @@ int cwslg_synchronize(cwslg_ctx *c)
 int cwslg_fetch_frame(cwslg_ctx *c, int ch_id, int16_t *dst, size_t cap, uint64_t *start_epoch, size_t *n_valid, float *factor)
 {
     if (!c) return CWSLG_ERR_ARG;
-    hipStream_t fs = nullptr;
     const int16_t *src = nullptr;
     const float *fac_src = nullptr;
     size_t flen = 0;
-    std::shared_lock<std::shared_mutex> life;
-    FetchTicket ticket;                                              // released (after `life`) when the copy is done or the call fails
+    ResultFetch rf;                                                  // ticket + lifetime, released when the copy is done or the call fails
     {
         std::lock_guard<std::mutex> g(c->mu);
         if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
@@ -1999,22 +2078,83 @@ int cwslg_fetch_frame(cwslg_ctx *c, int ch_id, int16_t *dst, size_t cap, uint64_
         if (start_epoch) *start_epoch = ch.frame_t0;
         if (n_valid) *n_valid = ch.frame_valid;
         if (!dst && !factor) return CWSLG_OK;
-        // ONE event per generation of frames, recorded behind everything queued so far (the boundary's finalise and sync kernels); every
-        // fetch of the generation waits for it on a fetch stream of its own, not for the compute stream
-        if (!c->fetch_ev_valid) {
-            HIPCHK(c, hipEventRecord(c->fetch_ev, c->stream));
-            c->fetch_ev_valid = true;
-        }
-        fs = c->fetch_stream[c->fetch_rr++ % kFetchStreams];
         src = ch.d_i16; fac_src = ch.d_factor; flen = ch.frame_len;
-        ticket.take(c);
-        life = std::shared_lock<std::shared_mutex>(c->life_mu);      // the buffers stay allocated until the copy below is done
+        int rc = begin_result_fetch(c, ch, rf);
+        if (rc) return rc;
     }
     // no context lock from here on: pushes, launches and other fetches proceed
-    HIPCHK(c, hipStreamWaitEvent(fs, c->fetch_ev, 0));
-    if (dst) HIPCHK(c, hipMemcpyAsync(dst, src, flen * sizeof(int16_t), hipMemcpyDeviceToHost, fs));
-    if (factor) HIPCHK(c, hipMemcpyAsync(factor, fac_src, sizeof(float), hipMemcpyDeviceToHost, fs));
-    HIPCHK(c, hipStreamSynchronize(fs));
+    HIPCHK(c, hipStreamWaitEvent(rf.fs, rf.ev, 0));
+    if (dst) HIPCHK(c, hipMemcpyAsync(dst, src, flen * sizeof(int16_t), hipMemcpyDeviceToHost, rf.fs));
+    if (factor) HIPCHK(c, hipMemcpyAsync(factor, fac_src, sizeof(float), hipMemcpyDeviceToHost, rf.fs));
+    HIPCHK(c, hipStreamSynchronize(rf.fs));
+    return CWSLG_OK;
+}
+
+// Everything one slot of one channel produced, under ONE ticket: the int16 frame, the scale factor and the candidate list(s) computed from
+// that frame -- what Instance.cpp:238-245 packs into one ItemToDecode (audio + startEpochTime), plus the lists a candidate-aware decoder
+// would take with it.  A list is returned only if it belongs to the frame's epoch (list_kind = CWSLG_LIST_NONE otherwise: sync stage off for
+// that boundary).
+int cwslg_fetch_slot(cwslg_ctx *c, int ch_id, int16_t *frame, size_t cap, void *list, size_t list_bytes,
+                     cwslg_ft4_sync *ft4, int max_ft4, cwslg_slot_result *out)
+{
+    if (!c || !out || (list_bytes > 0 && !list) || (max_ft4 > 0 && !ft4)) return CWSLG_ERR_ARG;
+    std::memset(out, 0, sizeof(*out));
+    const int16_t *src = nullptr; const float *fac_src = nullptr; size_t flen = 0;
+    const void *lsrc = nullptr; const int *lcnt = nullptr; size_t item = 0; int lim = 0, kind = CWSLG_LIST_NONE;
+    const int *nrec_src = nullptr; const char *rec_src = nullptr; int max_cand = 0;
+    ResultFetch rf;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
+        Channel &ch = c->chans[ch_id];
+        if (!ch.have_frame) return CWSLG_ERR_NO_FRAME;
+        if (frame && cap < ch.frame_len) return fail(c, CWSLG_ERR_ARG, "destination holds %zu samples, frame has %zu", cap, ch.frame_len);
+        hipSetDevice(c->device);
+        out->start_epoch = ch.frame_t0;
+        out->n_valid = ch.frame_valid;
+        src = ch.d_i16; fac_src = ch.d_factor; flen = ch.frame_len;
+        if (ch.cand_t0 == ch.frame_t0 && ch.cand_t0 != 0) {
+            if ((ch.sync_ft8 || ch.sync_ft4) && ch.syncbuf.d_block) {
+                kind = ch.sync_ft8 ? CWSLG_LIST_FT8 : CWSLG_LIST_FT4;
+                lsrc = ch.syncbuf.d_cand; lcnt = ch.syncbuf.d_ncand; item = sizeof(cwslg_candidate); max_cand = ch.syncbuf.max_cand;
+                if (ch.sync_ft4 && ch.syncbuf.d_ft4c) { nrec_src = ch.syncbuf.d_nrec; rec_src = (const char *)ch.syncbuf.d_rec; }
+            } else if ((ch.sync_wspr || ch.sync_fst4w) && ch.longbuf.d_block) {
+                kind = ch.sync_wspr ? CWSLG_LIST_WSPR : CWSLG_LIST_FST4W;
+                lsrc = ch.longbuf.w.cand; lcnt = ch.longbuf.w.ncand;
+                item = ch.sync_wspr ? sizeof(cwslg_wspr_candidate) : sizeof(cwslg_fst4w_candidate);
+                max_cand = ch.sync_wspr ? (int)WSPR_MAXCAND : (int)F4W_MAXCAND;
+            }
+            if (item) lim = (int)std::min<size_t>(list_bytes / item, (size_t)max_cand);
+        }
+        int rc = begin_result_fetch(c, ch, rf);
+        if (rc) return rc;
+    }
+    int cnt = 0;
+    std::vector<char> tmp((size_t)lim * item);
+    HIPCHK(c, hipStreamWaitEvent(rf.fs, rf.ev, 0));
+    if (frame) HIPCHK(c, hipMemcpyAsync(frame, src, flen * sizeof(int16_t), hipMemcpyDeviceToHost, rf.fs));
+    HIPCHK(c, hipMemcpyAsync(&out->factor, fac_src, sizeof(float), hipMemcpyDeviceToHost, rf.fs));
+    if (lcnt) HIPCHK(c, hipMemcpyAsync(&cnt, lcnt, sizeof(int), hipMemcpyDeviceToHost, rf.fs));
+    if (lim > 0) HIPCHK(c, hipMemcpyAsync(tmp.data(), lsrc, tmp.size(), hipMemcpyDeviceToHost, rf.fs));
+    HIPCHK(c, hipStreamSynchronize(rf.fs));
+    out->list_kind = kind;
+    const int total = std::max(0, std::min(cnt, max_cand));
+    out->n_list = std::min(total, lim);
+    if (out->n_list > 0) std::memcpy(list, tmp.data(), (size_t)out->n_list * item);
+    if (nrec_src && total > 0) {                       // FT4: the coherent refinement of every candidate, candidate order then segment order
+        std::vector<int> nrec((size_t)total);
+        std::vector<Ft4Rec> rec((size_t)total * 3);
+        HIPCHK(c, hipMemcpyAsync(nrec.data(), nrec_src, nrec.size() * sizeof(int), hipMemcpyDeviceToHost, rf.fs));
+        HIPCHK(c, hipMemcpyAsync(rec.data(), rec_src, rec.size() * sizeof(Ft4Rec), hipMemcpyDeviceToHost, rf.fs));
+        HIPCHK(c, hipStreamSynchronize(rf.fs));
+        int k_out = 0;
+        for (int k = 0; k < total; ++k)
+            for (int q = 0; q < nrec[k] && q < 3; ++q) {
+                if (k_out < max_ft4) std::memcpy(&ft4[k_out], &rec[(size_t)k * 3 + q], sizeof(Ft4Rec));
+                ++k_out;
+            }
+        out->n_ft4_sync = std::min(k_out, max_ft4);
+    }
     return CWSLG_OK;
 }
 
@@ -2097,7 +2237,7 @@ int cwslg_fill_decoder_block(cwslg_ctx *c, int ch_id, void *block, size_t block_
 {
     if (!c || !block) return CWSLG_ERR_ARG;
     const cwslg::handoff::BlockLayout L = cwslg::handoff::block_layout(js8 != 0);
-    std::lock_guard<std::mutex> g(c->mu);
+    std::unique_lock<std::mutex> lk(c->mu);
     if (ch_id < 0 || ch_id >= (int)c->chans.size() || !c->chans[ch_id].open) return fail(c, CWSLG_ERR_ARG, "bad channel id");
     Channel &ch = c->chans[ch_id];
     if (block_bytes < L.total) return fail(c, CWSLG_ERR_ARG, "decoder block holds %zu bytes, layout needs %zu", block_bytes, L.total);
@@ -2111,10 +2251,15 @@ int cwslg_fill_decoder_block(cwslg_ctx *c, int ch_id, void *block, size_t block_
     }
     const size_t nel = ch.frame_len < cwslg::handoff::kD2Samples ? ch.frame_len : cwslg::handoff::kD2Samples;   // :576-579
     hipSetDevice(c->device);
-    HIPCHK(c, hipMemcpyAsync(blk + L.d2, ch.d_i16, nel * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));   // :588
-    HIPCHK(c, sync_streams(c));
-    drain_spans(c);
     if (start_epoch) *start_epoch = ch.frame_t0;
+    const int16_t *src = ch.d_i16;
+    ResultFetch rf;                       // the copy runs like cwslg_fetch_frame's: ticket taken here, context mutex released for its duration
+    int rc = begin_result_fetch(c, ch, rf);
+    if (rc) return rc;
+    lk.unlock();
+    HIPCHK(c, hipStreamWaitEvent(rf.fs, rf.ev, 0));
+    HIPCHK(c, hipMemcpyAsync(blk + L.d2, src, nel * sizeof(int16_t), hipMemcpyDeviceToHost, rf.fs));   // :588
+    HIPCHK(c, hipStreamSynchronize(rf.fs));
     return CWSLG_OK;
 }
 

@@ -512,7 +512,12 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
     const int mt = tid;
     const int k = lane % GL;                    // this lane's branch pair (2k, 2k+1)
     int item = xcd * per_xcd + slot;
-    if (item >= hi_item) return;
+    if (item >= hi_item) {
+        // the launch's clock slot must not stay open when its stamping workgroup has no work (drain_spans waits for end stamps while spans are
+        // queued: a real-time host always has some): a sentinel pair -- non-zero end, zero start -- that the host reads as "nothing to fold in"
+        if (clk != nullptr && blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0) { as_global_rw(clk)[2] = 1ull; as_global_rw(clk)[3] = 1ull; }
+        return;
+    }
     // The shader clock in the middle of a timed launch (cwslg_set_timing): ONE workgroup, the one in the middle of the grid, reads s_memtime and
     // s_memrealtime when it starts and when it ends (see demod_exact5_kernel); untimed launches pass clk = nullptr and execute none of it.
     const bool clk_wg = clk != nullptr && blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0;
@@ -810,6 +815,7 @@ __global__ __launch_bounds__(NT, (T <= 192 ? 5 : 4)) void demod_kernel(const Cha
 #define CWSLG_EXACT5_WAVES 4
 #endif
 constexpr int kExact5Waves = CWSLG_EXACT5_WAVES;       // waves per workgroup (no barrier anywhere: any count works; A/B in profiles/r5_experiments.txt)
+static_assert(kExact5Waves * EXACT5_ASM_NBUF * EXACT5_ASM_BUF_BYTES <= 65536, "a workgroup's row buffers (waves x buffers x 4 KB) exceed the 64 KB static LDS limit");
 template <int D>
 __global__ __launch_bounds__(64 * kExact5Waves, 2) void demod_exact5_kernel(const ChanWork *__restrict__ works, const float *__restrict__ taps, int chunks_x,
                                                                               int n_ch, int seg_len, unsigned long long *__restrict__ clk)
@@ -820,7 +826,12 @@ __global__ __launch_bounds__(64 * kExact5Waves, 2) void demod_exact5_kernel(cons
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int item = (int)blockIdx.x * kExact5Waves + wv;
     const int n_items = (chunks_x < 0 ? -chunks_x : chunks_x) * n_ch;
-    if (item >= n_items) return;
+    // (the clock of the launch's MIDDLE workgroup: the first ones run in the boost the package allows a launch's first millisecond or two)
+    const bool stamp = clk != nullptr && blockIdx.x == (gridDim.x >> 1) && wv == 0;
+    // With ragged n_blocks per channel the stamping wave can have no work: it then closes the launch's clock slot with a sentinel (non-zero end
+    // stamps, zero start stamps: drain_spans skips it) instead of leaving it open, which would hold every later slot back (statistics only).
+    auto close_clock_slot = [&]() { if (stamp && lane == 0) { as_global_rw(clk)[2] = 1ull; as_global_rw(clk)[3] = 1ull; } };
+    if (item >= n_items) { close_clock_slot(); return; }
     int ch, chunk;
     item_to_ch_tile(item, chunks_x, n_ch, ch, chunk);
     ch = (int)uni((unsigned)ch); chunk = (int)uni((unsigned)chunk);
@@ -828,7 +839,7 @@ __global__ __launch_bounds__(64 * kExact5Waves, 2) void demod_exact5_kernel(cons
     const unsigned n_blocks = cw->n_blocks, cap = cw->ring_cap, lo_mod = cw->lo_mod;
     const long long q_first = cw->q_first;
     const long long first_seg = (long long)chunk * 32;
-    if (first_seg * seg_len >= (long long)n_blocks) return;                           // a chunk past this channel's pending blocks
+    if (first_seg * seg_len >= (long long)n_blocks) { close_clock_slot(); return; }   // a chunk past this channel's pending blocks
     const unsigned most = (unsigned)min((long long)seg_len, (long long)n_blocks - first_seg * seg_len);   // outputs of the wave's first (fullest) stream
     // ring byte offset of the first sample of stream s (its 32-block warm-up included): lo_mod + 16 (first output - 32), modulo the ring
     auto stream_pos = [&](int s) -> unsigned {
@@ -883,8 +894,6 @@ __global__ __launch_bounds__(64 * kExact5Waves, 2) void demod_exact5_kernel(cons
     const unsigned long long hmask = 0xFFFFFFFF00000000ull;
     unsigned long long esave;
     float peak;
-    // (the clock of the launch's MIDDLE workgroup: the first ones run in the boost the package allows a launch's first millisecond or two)
-    const bool stamp = clk != nullptr && blockIdx.x == (gridDim.x >> 1) && wv == 0;
     if (stamp && lane == 0) {
         unsigned long long t_, r_;
         asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "=s"(r_)::"memory");

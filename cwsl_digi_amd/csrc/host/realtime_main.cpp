@@ -51,6 +51,7 @@ struct Options {
     std::string mode = "threads";  // threads | batch
     int exact = 1, sync = 1;
     double process_ms = 0;         // stream time between explicit cwslg_process calls (0: the library demodulates when a ring fills or at the boundary)
+    int process_threshold = 0;     // cwslg_set_process_threshold: 0 every cwslg_process() launches, -1 the library's own threshold, > 0 outputs
     std::string iq_path, out_dir;
     int iq_stride = 7;
     int dump = 0, fetch_threads = 4;
@@ -106,6 +107,7 @@ int main(int argc, char **argv)
         else if (a == "--exact") o.exact = std::atoi(val());
         else if (a == "--sync") o.sync = std::atoi(val());
         else if (a == "--process-ms") o.process_ms = std::atof(val());
+        else if (a == "--process-threshold") o.process_threshold = std::atoi(val());
         else if (a == "--iq") o.iq_path = val();
         else if (a == "--iq-stride") o.iq_stride = std::atoi(val());
         else if (a == "--out") o.out_dir = val();
@@ -153,6 +155,7 @@ int main(int argc, char **argv)
     CHK(cwslg_create(&g_ctx, o.device));
     cwslg_ctx *ctx = g_ctx;
     CHK(cwslg_set_exact(ctx, o.exact));
+    CHK(cwslg_set_process_threshold(ctx, o.process_threshold));
     if (o.sync) CHK(cwslg_enable_sync(ctx, 1, 1.5f, 200, 200, 3000));
     std::vector<int> rx_ids(R), ch_ids;
     const Clock::time_point t_setup = Clock::now();
@@ -277,7 +280,9 @@ int main(int argc, char **argv)
             if (o.sync) {
                 std::vector<cwslg_candidate> cand(600);
                 int n = 0;
-                CHK(cwslg_fetch_candidates(ctx, ch_ids[k], cand.data(), 600, &n));
+                uint64_t t_list = 0;
+                CHK(cwslg_fetch_candidates(ctx, ch_ids[k], cand.data(), 600, &n, &t_list));
+                if (t_list != t_start) die("candidate list of another epoch than the frame");
                 FILE *cf = std::fopen((o.out_dir + "/ch" + std::to_string(k) + ".cand").c_str(), "w");
                 for (int q = 0; q < n; ++q) std::fprintf(cf, "%d %d %.9g\n", cand[q].freq_bin, cand[q].time_step, cand[q].sync);
                 std::fclose(cf);
@@ -299,13 +304,14 @@ int main(int argc, char **argv)
                 "\"h2d_gbytes_per_s\": %.4f, \"push_calls\": %llu, \"push_batches\": %llu, \"push_host_ms_total\": %.1f, \"push_call_ms_worst\": %.3f, "
                 "\"push_late_ms_worst\": %.3f, \"push_late_ms_mean\": %.4f, \"host_cpu_seconds_per_second\": %.4f, "
                 "\"gpu_busy_fraction\": %.5f, \"demod_launches\": %llu, \"demod_ms\": %.2f, \"finalize_ms\": %.2f, \"sync_ms\": %.2f, "
-                "\"process_every_ms\": %.1f, \"boundaries\": [",
+                "\"process_every_ms\": %.1f, \"process_threshold\": %d, \"process_deferred\": %llu, \"demod_redundancy\": %.4f, \"boundaries\": [",
                 o.mode.c_str(), o.exact, o.sync, R, C, NCH, o.fs, o.block, o.speed, o.pre_blocks, o.slot_blocks, o.slots, stream_s, wall_ms / 1e3,
                 push_wall_ms / 1e3, setup_ms / 1e3, (double)R * total_blocks, (unsigned long long)st.blocks_dropped,
                 (unsigned long long)st.frames_emitted, (unsigned long long)st.frames_discarded, frames_fetched.load(),
                 (double)st.h2d_bytes / 1e9 / (push_wall_ms / 1e3), (unsigned long long)st.push_calls, (unsigned long long)st.push_batches, st.push_host_ms, wp,
                 wl, sl / std::max(1.0, n_push), cpu_s / (wall_ms / 1e3), (st.demod_ms + st.finalize_ms + st.sync_ms) / wall_ms,
-                (unsigned long long)st.demod_launches, st.demod_ms, st.finalize_ms, st.sync_ms, o.process_ms);
+                (unsigned long long)st.demod_launches, st.demod_ms, st.finalize_ms, st.sync_ms, o.process_ms, o.process_threshold,
+                (unsigned long long)st.process_deferred, st.demod_samples ? (double)st.demod_blocks_read * (o.fs / 12000.0) / (double)st.demod_samples : 0.0);
     for (size_t k = 0; k < recs.size(); ++k)
         std::printf("%s{\"after_block\": %ld, \"boundary_call_ms\": %.3f, \"frames_ready_ms\": %.3f, \"all_frames_fetched_ms\": %.3f}", k ? ", " : "",
                     recs[k].at_block, recs[k].call_ms, recs[k].ready_ms, recs[k].fetch_ms);

@@ -269,10 +269,15 @@ int main(int argc, char **argv)
         for (Chan &c : chans) {
             if (c.spec.group != group) continue;
             pcm.resize(c.spec.frame_len);
-            uint64_t t0 = 0; size_t nv = 0; float factor = 0;
-            rc = cwslg_fetch_frame(ctx, c.id, pcm.data(), pcm.size(), &t0, &nv, &factor);
+            // the slot's results in ONE call (cwslg_fetch_slot): frame, scale factor, candidate list and FT4 refinements of the same epoch --
+            // the ItemToDecode of Instance.cpp:238-245 with the lists a candidate-aware decoder would take beside it
+            const bool ft = !std::strcmp(c.spec.mode, "FT8") || !std::strcmp(c.spec.mode, "FT4");
+            cwslg_slot_result sr;
+            rc = cwslg_fetch_slot(ctx, c.id, pcm.data(), pcm.size(), (sync && ft) ? cand.data() : nullptr,
+                                  (sync && ft) ? cand.size() * sizeof(cwslg_candidate) : 0, ref4.data(), (int)ref4.size(), &sr);
             if (rc == CWSLG_ERR_NO_FRAME) continue;             // first (partial) slot: nothing to decode
-            if (rc != CWSLG_OK) die("fetch_frame", rc);
+            if (rc != CWSLG_OK) die("fetch_slot", rc);
+            const uint64_t t0 = sr.start_epoch; const size_t nv = (size_t)sr.n_valid; const float factor = sr.factor;
             const int route = cwslg_decoder_route(c.spec.mode, cfg.transfer_shmem);
             char stem[512];
             std::snprintf(stem, sizeof stem, "%s/%" PRIu64 "_%u_%s", out_dir.c_str(), t0, c.spec.freq_hz, c.spec.mode);
@@ -280,8 +285,8 @@ int main(int argc, char **argv)
             const bool write_wav = wav_mode == "always" || (wav_mode == "route" && route == 0);
             if (write_wav && (rc = cwslg_write_wav(ctx, c.id, wav.c_str())) != CWSLG_OK) die("write_wav", rc);
             int ncand = -1;
-            if (sync && (!std::strcmp(c.spec.mode, "FT8") || !std::strcmp(c.spec.mode, "FT4"))) {
-                if ((rc = cwslg_fetch_candidates(ctx, c.id, cand.data(), (int)cand.size(), &ncand)) != CWSLG_OK) die("fetch_candidates", rc);
+            if (sync && ft && (sr.list_kind == CWSLG_LIST_FT8 || sr.list_kind == CWSLG_LIST_FT4)) {
+                ncand = sr.n_list;
                 FILE *cf = std::fopen((std::string(stem) + ".cand").c_str(), "w");
                 if (cf) {
                     for (int q = 0; q < ncand; ++q) std::fprintf(cf, "%.9g %.9g %.9g\n", cand[q].freq_hz, cand[q].dt_s, cand[q].sync);
@@ -289,17 +294,15 @@ int main(int argc, char **argv)
                 }
             }
             int nref = -1;
-            if (sync && !std::strcmp(c.spec.mode, "FT4")) {              // FT4: coherent refinement of every candidate
-                rc = cwslg_fetch_ft4_sync(ctx, c.id, ref4.data(), (int)ref4.size(), &nref);
-                if (rc == CWSLG_OK) {
-                    FILE *rf = std::fopen((std::string(stem) + ".sync4").c_str(), "w");
-                    if (rf) {
-                        for (int q = 0; q < nref; ++q)
-                            std::fprintf(rf, "%.9g %.9g %.9g %.9g %d %d %d %d\n", ref4[q].f0_hz, ref4[q].f1_hz, ref4[q].dt_s, ref4[q].sync,
-                                         ref4[q].ibest, ref4[q].idf, ref4[q].seg, ref4[q].cand);
-                        std::fclose(rf);
-                    }
-                } else if (rc != CWSLG_ERR_NO_FRAME) die("fetch_ft4_sync", rc);
+            if (sync && sr.list_kind == CWSLG_LIST_FT4) {                // FT4: coherent refinement of every candidate
+                nref = sr.n_ft4_sync;
+                FILE *rf = std::fopen((std::string(stem) + ".sync4").c_str(), "w");
+                if (rf) {
+                    for (int q = 0; q < nref; ++q)
+                        std::fprintf(rf, "%.9g %.9g %.9g %.9g %d %d %d %d\n", ref4[q].f0_hz, ref4[q].f1_hz, ref4[q].dt_s, ref4[q].sync,
+                                     ref4[q].ibest, ref4[q].idf, ref4[q].seg, ref4[q].cand);
+                    std::fclose(rf);
+                }
             }
             char app[64] = "", opts[1024] = "";
             const std::string target = route == 1 ? std::string("<shmem-key>") : wav;

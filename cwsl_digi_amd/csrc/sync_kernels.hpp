@@ -40,6 +40,7 @@ struct SyncConfig {
     float syncmin_ft4 = 1.2f;             // ft4_decode's threshold for getcandidates4
     bool ft4_coherent = true;             // run ft4_downsample + sync4d on every FT4 candidate (ft4sync_kernels.hpp)
     int max_cand = 200;
+    int order = 0;                        // cwslg_set_candidate_order: 0 strongest first (cut at max_cand in that order), 1 ascending frequency (cut in THAT order)
     int f_lo_hz = 200, f_hi_hz = 3000;
     int ia = 64, ib = 960, nbins = 976;   // derived: bin range and stored row length (ib+13 rounded up to 16)
 };
@@ -1414,7 +1415,7 @@ struct CandLds {
 // The candidate selection of one channel by the NT threads of a workgroup: red / jpeak come from global memory (written by this
 // workgroup or by an earlier kernel), `lds` holds CandLds<NT>::bytes bytes (16-byte aligned).
 template <int NT>
-__device__ void ft8_candidates_body(const SyncWork *w, int ia, int ib, float syncmin, int maxcand, char *lds)
+__device__ void ft8_candidates_body(const SyncWork *w, int ia, int ib, float syncmin, int maxcand, int order, char *lds)
 {
     using L = CandLds<NT>;
     float *s_kv = reinterpret_cast<float *>(lds + L::kv);
@@ -1570,8 +1571,9 @@ __device__ void ft8_candidates_body(const SyncWork *w, int ia, int ib, float syn
         __syncthreads();
     }
     __syncthreads();
-    // --- final order: descending sync, ties ascending bin, then lag; first maxcand kept.
-    // Bitonic sort of 64-bit keys (inverted order-preserving sync bits | bin | lag | index) in the two sort buffers.
+    // --- final order: descending sync, ties ascending bin, then lag (order 0); or ascending bin, entries of one bin in their order of discovery
+    // (order 1: sync8.f90's "Sort by frequency" as recalled); first maxcand kept IN THAT ORDER.
+    // Bitonic sort of 64-bit keys (inverted order-preserving sync bits | bin | lag | index, or bin | index) in the two sort buffers.
     unsigned *s_hi = reinterpret_cast<unsigned *>(s_kv);
     unsigned *s_lo = reinterpret_cast<unsigned *>(s_scan_lo);
     for (int i = tid; i < 1024; i += NT) {
@@ -1581,6 +1583,7 @@ __device__ void ft8_candidates_body(const SyncWork *w, int ia, int ib, float syn
             u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
             hi = ~u;                                              // descending sync
             lo = ((unsigned)s_cbin[i] << 20) | ((unsigned)(s_clag[i] + FT8_JZ) << 12) | (unsigned)i;
+            if (order) { hi = (unsigned)s_cbin[i]; lo = (unsigned)i; }
         }
         s_hi[i] = hi; s_lo[i] = lo;
     }
@@ -1619,10 +1622,10 @@ __device__ void ft8_candidates_body(const SyncWork *w, int ia, int ib, float syn
 // grid (n_channels), NT threads: the candidate selection as its own launch (behind ft8_sync2d_v3_kernel; ft8_sync_chan_kernel runs the same body itself).
 template <int NT>
 __global__ __launch_bounds__(NT) void ft8_candidates_kernel(const SyncWork *__restrict__ works, int ia, int ib,
-                                                              float syncmin, int maxcand)
+                                                              float syncmin, int maxcand, int order)
 {
     __shared__ __attribute__((aligned(16))) char s_pool[CandLds<NT>::bytes];
-    ft8_candidates_body<NT>(works + blockIdx.x, ia, ib, syncmin, maxcand, s_pool);
+    ft8_candidates_body<NT>(works + blockIdx.x, ia, ib, syncmin, maxcand, order, s_pool);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1645,7 +1648,7 @@ __global__ __launch_bounds__(NT) void ft8_candidates_kernel(const SyncWork *__re
 // Measured (4096 slots, same box, scripts/gpu_r3_sync2d.sh): 3.02 ms against 2.74 + 0.57 (v3 + candidates) and 2.92 + 0.55 (round 2).
 constexpr int SYNCC_NT = 512;
 __global__ __launch_bounds__(SYNCC_NT, 4) void ft8_sync_chan_kernel(const SyncWork *__restrict__ works, int ia, int ib, int nbins,
-                                                                     float syncmin, int maxcand)
+                                                                     float syncmin, int maxcand, int order)
 {
     constexpr int ROWS = SYNC_BAND + 12, NW = SYNCC_NT / 64;
     constexpr int UN = (FT8_NHSYM + NW - 1) / NW;                              // symbol steps per wave when one step = one load: 47
@@ -1741,7 +1744,7 @@ __global__ __launch_bounds__(SYNCC_NT, 4) void ft8_sync_chan_kernel(const SyncWo
     // ---- candidate selection on the values this workgroup has just written (global memory, same CU: visible once the stores have
     // retired, which the barrier's vmcnt(0) ensures)
     __syncthreads();
-    ft8_candidates_body<SYNCC_NT>(w, ia, ib, syncmin, maxcand, s_pool);
+    ft8_candidates_body<SYNCC_NT>(w, ia, ib, syncmin, maxcand, order, s_pool);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1778,7 +1781,7 @@ __device__ __forceinline__ double exp10_fixed(double y)
 }
 
 __global__ __launch_bounds__(256) void ft4_candidates_kernel(const SyncWork *__restrict__ works, int nfa, int nfb,
-                                                              float syncmin, int maxcand)
+                                                              float syncmin, int maxcand, int order)
 {
     constexpr int NB1 = FT4_NH1 + 1;
     __shared__ float s_savg[NB1], s_savsm[NB1], s_sdb[NB1], s_sbase[NB1];
@@ -1947,7 +1950,7 @@ __global__ __launch_bounds__(256) void ft4_candidates_kernel(const SyncWork *__r
     }
     const int ncand = min(s_scan[255], keep);
     __syncthreads();
-    // descending height, ties by ascending bin
+    // descending height, ties by ascending bin (order 0); or as found = ascending bin (order 1)
     for (int i = tid; i < 1024; i += 256) {
         unsigned hi = 0xFFFFFFFFu, lo = 0xFFFFFFFFu;
         if (i < ncand) {
@@ -1955,6 +1958,7 @@ __global__ __launch_bounds__(256) void ft4_candidates_kernel(const SyncWork *__r
             u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
             hi = ~u;
             lo = ((unsigned)s_cbin[i] << 12) | (unsigned)i;
+            if (order) hi = 0u;
         }
         s_hi[i] = hi; s_lo[i] = lo;
     }

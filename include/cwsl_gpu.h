@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define CWSLG_ABI_VERSION 4
+#define CWSLG_ABI_VERSION 5
 
 /* ---- status codes ---- */
 #define CWSLG_OK                  0
@@ -55,8 +55,8 @@ extern "C" {
 typedef struct cwslg_ctx cwslg_ctx;
 
 /* One sync candidate (row a13 of SURVEY.md 8a: no reference counterpart; the layout is
- * builder-defined and the ordering is deterministic: descending sync, ties by ascending
- * freq_bin then ascending time_step). */
+ * builder-defined and the ordering is deterministic: by default descending sync, ties by ascending
+ * freq_bin then ascending time_step; see cwslg_set_candidate_order). */
 typedef struct {
     int32_t freq_bin;     /* FT8: 3.125 Hz bins of the 3840-point symbol spectrum               */
     int32_t time_step;    /* FT8: lag in quarter-symbol steps (40 ms), -62..+62                 */
@@ -181,6 +181,16 @@ int cwslg_channel_open_line(cwslg_ctx *ctx, int rx_id, const char *line, double 
  * Demodulate everything pushed so far for every channel (enqueued on the context stream; returns
  * without waiting).  push/slot_boundary/fetch call it implicitly when they have to. */
 int cwslg_process(cwslg_ctx *ctx);
+/* When is a cwslg_process() call worth a launch (ABI 5)?  The reference wakes every Instance once per block (Instance.cpp:260-276); a host
+ * that mirrors this calls cwslg_process() after every push.  The bit-identical kernel starts every stream of outputs 32 blocks early (the
+ * workspace of SSBD::ProcessBlock needs an output's 32 blocks), so a launch over 128 pending outputs per channel fetches and multiplies several
+ * times what it delivers.  min_outputs = 0 (default): every call launches, as documented above.  min_outputs > 0: a call returns at once until
+ * some channel has that many 12 kHz outputs pending.  min_outputs < 0: the library's own threshold (exact mode 20480 outputs = 1.7 s: one wave
+ * per channel, 32 streams of 640 outputs, 5 % warm-up; fast mode 2048).  A slot boundary, a retune, a mode switch and ring pressure
+ * (Receiver.hpp:222-229, "I/Q buffer is full!") always demodulate everything pending, whatever the threshold -- no sample is ever late for
+ * its frame.  stats.demod_blocks_read x D / stats.demod_samples is the redundancy actually paid; stats.process_deferred counts the calls
+ * that returned without a launch. */
+int cwslg_set_process_threshold(cwslg_ctx *ctx, int min_outputs);
 /* Replaces SyncPredicate::store(true) for every predicate of one group (CWSL_DIGI.cpp:247-251) and the
  * per-Instance reaction to it (Instance.cpp:203-253): swap frames, stamp the new frame with epoch_s,
  * finalise (peak-normalise + int16) the finished one unless its start time is 0, restart the demodulator. */
@@ -233,6 +243,32 @@ int cwslg_rccl_init(cwslg_ctx *ctx, const void *id, int rank, int world);
  * than one slot late therefore sees only the newest frame (the reference's pool would drop the stale item by age, DecoderPool.hpp:358-374). */
 int cwslg_fetch_frame(cwslg_ctx *ctx, int ch_id, int16_t *dst, size_t cap,
                       uint64_t *start_epoch, size_t *n_valid, float *factor);
+/* Fetches and boundaries (ABI 5).  Every fetch of a result -- cwslg_fetch_frame, cwslg_fetch_slot, cwslg_fill_decoder_block and the four
+ * candidate-list fetches -- reads only pointers under the context mutex, takes a ticket of the channel's slot-clock GROUP and copies with the
+ * mutex released, on a fetch stream behind an event recorded after the boundary's kernels.  The next boundary of THAT group is the only writer
+ * of those buffers and waits for the group's tickets before it queues its kernels, holding the context mutex.  Stall bound: a boundary of group
+ * g can hold the context (pushes, cwslg_process, stats) for at most the longest copy of group g still in flight -- one frame + lists, i.e.
+ * 0.36 MB (FT8) ... 3 MB (120 s modes) at PCIe speed, plus, for a fetch issued while kernels were still queued, the wait for those kernels
+ * (at most the previous boundary's finalise + sync, or a demod launch: <= 40 ms at 4096 slots, ~0.1 ms in real-time operation).  Fetches of
+ * OTHER groups never delay it.  A consumer that fetches within its slot period (the reference's pool drops items older than that,
+ * DecoderPool.hpp:358-374) never meets the wait at all. */
+#define CWSLG_LIST_NONE   0
+#define CWSLG_LIST_FT8    1   /* cwslg_candidate records                                            */
+#define CWSLG_LIST_FT4    2   /* cwslg_candidate records (+ cwslg_ft4_sync refinements)             */
+#define CWSLG_LIST_WSPR   3   /* cwslg_wspr_candidate records                                       */
+#define CWSLG_LIST_FST4W  4   /* cwslg_fst4w_candidate records                                      */
+typedef struct {
+    uint64_t start_epoch;     /* the frame's startEpochTime (Instance.cpp:215); every list below was computed from THIS frame */
+    uint64_t n_valid;         /* samples demodulated in the slot                                                            */
+    float    factor;          /* prepareAudio's scale factor                                                                */
+    int32_t  list_kind;       /* CWSLG_LIST_*: record type written to `list`; NONE if no list of this epoch exists           */
+    int32_t  n_list;          /* records written to `list`                                                                  */
+    int32_t  n_ft4_sync;      /* records written to `ft4` (FT4 channels with the coherent stage on)                          */
+} cwslg_slot_result;
+/* The results of ONE epoch of one channel in one call and under one ticket -- the GPU-side counterpart of the ItemToDecode that carries
+ * audio + startEpochTime together (DecoderPool.hpp:174-210, Instance.cpp:238-245): the int16 frame (frame may be NULL), the scale factor,
+ * the channel's candidate list in its own record type (list_bytes = capacity of `list` in bytes; 0 / NULL to skip) and, for FT4 channels, the
+ * coherent refinements.  Frame and lists can never belong to different slots. */
 /* The last finalised frame as the reference's .wav (WaveFile.hpp:19-35,87-135: 46-byte RIFF/WAVE/fmt(18-byte
  * WAVEFORMATEX, PCM, mono, 12 kHz, 16 bit)/data header + the whole int16 frame) -- the file jt9/wsprd are given in
  * transfermethod=wavefile mode (DecoderPool.hpp:966-1046).  For the shared-memory mode pass &dec_data->d2[0]
@@ -302,7 +338,26 @@ int cwslg_fetch_audio_f32(cwslg_ctx *ctx, int ch_id, float *dst, size_t cap, siz
 int cwslg_frame_device_ptrs(cwslg_ctx *ctx, int ch_id, const int16_t **d_i16, const float **d_f32);
 /* Sync candidates of the last finalised frame (FT8/FT4 channels with sync enabled). */
 int cwslg_enable_sync(cwslg_ctx *ctx, int enable, float syncmin, int max_cand, int f_lo_hz, int f_hi_hz);
-int cwslg_fetch_candidates(cwslg_ctx *ctx, int ch_id, cwslg_candidate *dst, int max, int *n);
+/* Final ORDER and CUT of the FT8 / FT4 candidate lists (ABI 5).  Upstream's source is not in the reference tree, so which of the two a given
+ * jt9 build does cannot be verified here (PARITY UNPINNED); both are implemented -- oracle, kernels and tests/indep_sync.py -- bit-identically:
+ *   CWSLG_ORDER_SYNC_DESC (default): strongest first, the first max_cand kept.  Believed to mirror sync8.f90's "Sort by sync" lines (commented
+ *       out in WSJT-X 2.x, live in 1.x) and getcandidates4.f90's list by height.
+ *   CWSLG_ORDER_FREQ_ASC: ascending frequency, the first max_cand IN THAT ORDER kept -- believed to mirror WSJT-X 2.x sync8.f90 ("Sort by
+ *       frequency": indexx on the frequency column, copy while k <= maxcand); entries of one bin stay in their order of discovery (the builder's
+ *       tie rule: upstream's indexx is not stable).  FT4: the peaks as getcandidates4 finds them scanning upwards.  (Upstream's "nfqso first"
+ *       promotion has no counterpart: the skimmer has no QSO frequency.)
+ * The two lists hold the same entries unless the list is cut at max_cand; FT4's hold the same entries always (its scan stops at max_cand before
+ * any ordering).  Applies from the next boundary on.
+ * sync8's near-duplicate rule on the time axis is evaluated in single precision exactly as
+ *       tdiff = fabsf(((float)lag_i - 0.5f) * tstep - ((float)lag_j - 0.5f) * tstep) < 0.04f,   tstep = 480 / 12000.0f,
+ * under which 77 of the 124 lag pairs exactly one step apart count as duplicates and 47 do not (0.04 is not a binary fraction; the table is pinned
+ * in tests/test_sync_oracle.py); a double-precision evaluation would make none of them duplicates.  Also unverifiable here. */
+#define CWSLG_ORDER_SYNC_DESC 0
+#define CWSLG_ORDER_FREQ_ASC  1
+int cwslg_set_candidate_order(cwslg_ctx *ctx, int order);
+/* *start_epoch (may be NULL) = start epoch of the frame the list was computed from: compare it with cwslg_fetch_frame's, or use
+ * cwslg_fetch_slot, which returns both under one ticket (ABI 5; ItemToDecode carries epochTime with its audio, DecoderPool.hpp:174-210). */
+int cwslg_fetch_candidates(cwslg_ctx *ctx, int ch_id, cwslg_candidate *dst, int max, int *n, uint64_t *start_epoch);
 /* FT4 channels run getcandidates4's spectral-peak search instead (freq_hz = interpolated peak - 1.5 tone spacings,
  * sync = normalised peak height, time_step/dt_s = 0); its threshold defaults to upstream's 1.2. */
 /* FT4 coherent sync (row a13; PARITY UNPINNED, restated from upstream ft4_decode / ft4_downsample / sync4d): every
@@ -321,7 +376,9 @@ typedef struct {
     int32_t cand;         /* index into the cwslg_fetch_candidates list                              */
 } cwslg_ft4_sync;
 int cwslg_enable_ft4_coherent(cwslg_ctx *ctx, int enable);
-int cwslg_fetch_ft4_sync(cwslg_ctx *ctx, int ch_id, cwslg_ft4_sync *dst, int max, int *n);
+int cwslg_fetch_ft4_sync(cwslg_ctx *ctx, int ch_id, cwslg_ft4_sync *dst, int max, int *n, uint64_t *start_epoch);
+int cwslg_fetch_slot(cwslg_ctx *ctx, int ch_id, int16_t *frame, size_t cap, void *list, size_t list_bytes,
+                     cwslg_ft4_sync *ft4, int max_ft4, cwslg_slot_result *out);
 int cwslg_set_ft4_syncmin(cwslg_ctx *ctx, float syncmin);
 
 /* Intermediate products of the sync stage for parity tests: what = 0 symbol spectra [372][nbins] float,
@@ -355,8 +412,8 @@ typedef struct {
     int32_t pad_;
 } cwslg_fst4w_candidate;
 int cwslg_enable_long_sync(cwslg_ctx *ctx, int enable, int fst4w_nfa_hz, int fst4w_nfb_hz, float fst4w_minsync);
-int cwslg_fetch_wspr_candidates(cwslg_ctx *ctx, int ch_id, cwslg_wspr_candidate *dst, int max, int *n);
-int cwslg_fetch_fst4w_candidates(cwslg_ctx *ctx, int ch_id, cwslg_fst4w_candidate *dst, int max, int *n);
+int cwslg_fetch_wspr_candidates(cwslg_ctx *ctx, int ch_id, cwslg_wspr_candidate *dst, int max, int *n, uint64_t *start_epoch);
+int cwslg_fetch_fst4w_candidates(cwslg_ctx *ctx, int ch_id, cwslg_fst4w_candidate *dst, int max, int *n, uint64_t *start_epoch);
 /* Intermediate results for parity tests.  WSPR channels: what = 0 the 375 Hz baseband (complex float[46080]), 1 the spectra
  * (float[359][512], time-major: wsprd's ps[j][i] is element [i][j]), 2 the normalised smoothed spectrum (float[411]).
  * FST4W channels: 3 the normalised comb spectrum s2 (float, indexed by the baud/2 bin), 4 the band of the long transform
@@ -392,6 +449,11 @@ typedef struct {
     double   push_host_ms;         /* wall time spent inside host pushes (staging copy + enqueue), summed over the calling threads      */
     double   sync_spectra_ms;      /* of sync_ms: the FT8 symbol-spectra kernel ...                                                     */
     double   sync_search_ms;       /* ... and the FT8 Costas search + candidate selection                                                */
+    /* ABI 5 */
+    uint64_t demod_blocks_read;    /* blocks (D input samples = one 12 kHz output each) the demod launches fetched and put through the arithmetic,
+                                    * summed over channels: the pending blocks plus every stream's 32-block warm-up (exact) / every tile's
+                                    * 31-block history (fast).  x D / demod_samples = redundancy.                                          */
+    uint64_t process_deferred;     /* cwslg_process() calls that returned without a launch (cwslg_set_process_threshold)                    */
 } cwslg_stats;
 int cwslg_get_stats(cwslg_ctx *ctx, cwslg_stats *out);
 int cwslg_reset_stats(cwslg_ctx *ctx);

@@ -137,20 +137,36 @@ public:
         check(ctx_.raw(), rc);
         return true;
     }
-    int candidates(std::vector<cwslg_candidate> &out, int max = 600)
+    // startEpoch (optional): the start epoch of the frame the list was computed from -- pair it with fetch()'s, or use fetchSlot()
+    int candidates(std::vector<cwslg_candidate> &out, int max = 600, std::uint64_t *startEpoch = nullptr)
     {
         out.resize(max);
         int n = 0;
-        check(ctx_.raw(), cwslg_fetch_candidates(ctx_.raw(), id_, out.data(), max, &n));
+        check(ctx_.raw(), cwslg_fetch_candidates(ctx_.raw(), id_, out.data(), max, &n, startEpoch));
         out.resize(n);
         return n;
+    }
+    // The ItemToDecode of one slot (DecoderPool.hpp:174-210: audio + epochTime travel together) with the candidate list of the SAME epoch,
+    // in one call and under one ticket (cwslg_fetch_slot): false while no frame is ready.  FT8 / FT4 channels.
+    bool fetchSlot(std::vector<std::int16_t> &audio, std::uint64_t &startEpoch, std::vector<cwslg_candidate> &cands, int max = 600)
+    {
+        audio.resize(frame_);
+        cands.resize(max);
+        cwslg_slot_result r;
+        const int rc = cwslg_fetch_slot(ctx_.raw(), id_, audio.data(), audio.size(), cands.data(), cands.size() * sizeof(cwslg_candidate),
+                                        nullptr, 0, &r);
+        if (rc == CWSLG_ERR_NO_FRAME) { cands.clear(); return false; }
+        check(ctx_.raw(), rc);
+        startEpoch = r.start_epoch;
+        cands.resize((r.list_kind == CWSLG_LIST_FT8 || r.list_kind == CWSLG_LIST_FT4) ? r.n_list : 0);
+        return true;
     }
     // FT4 channels: every candidate refined coherently (start sample, frequency tweak, sync) -- cwslg_fetch_ft4_sync
     int ft4Sync(std::vector<cwslg_ft4_sync> &out, int max = 1800)
     {
         out.resize(max);
         int n = 0;
-        const int rc = cwslg_fetch_ft4_sync(ctx_.raw(), id_, out.data(), max, &n);
+        const int rc = cwslg_fetch_ft4_sync(ctx_.raw(), id_, out.data(), max, &n, nullptr);
         if (rc == CWSLG_ERR_NO_FRAME) { out.clear(); return 0; }
         check(ctx_.raw(), rc);
         out.resize(n);

@@ -83,6 +83,9 @@ def lib():
         L.orc_ft8_spectra.argtypes = [_i16p, _f32p, C.c_int]
         L.orc_ft8_sync.argtypes = [_i16p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ft8_sync_ordered.argtypes = [_i16p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ft4_candidates_ordered.argtypes = [_i16p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_ft4_spectra.argtypes = [_i16p, _f32p]
         L.orc_ft4_candidates.argtypes = [_i16p, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_log10_fixed.argtypes = [C.c_double]; L.orc_log10_fixed.restype = C.c_double
@@ -559,15 +562,23 @@ def ft8_spectra(frame_i16, nbins):
     return out.reshape(372, nbins)
 
 
-def ft8_sync(frame_i16, f_lo_hz=200, f_hi_hz=3000, syncmin=1.5, maxcand=200, want_arrays=False):
+ORDER = {"sync": 0, "freq": 1, 0: 0, 1: 1}          # cwslg_set_candidate_order: strongest first (default) / ascending frequency, cut in that order
+
+
+def ft8_tdiff_close(lag_i, lag_j):
+    """sync8's `tdiff < 0.04` in the float32 expression the restatement and the kernel use."""
+    return bool(lib().orc_ft8_tdiff_close(int(lag_i), int(lag_j)))
+
+
+def ft8_sync(frame_i16, f_lo_hz=200, f_hi_hz=3000, syncmin=1.5, maxcand=200, want_arrays=False, order="sync"):
     """PARITY UNPINNED.  -> list of (freq_bin, time_step, sync, freq_hz, dt_s) [, dict of red/jpeak arrays]."""
     fr = np.ascontiguousarray(frame_i16, dtype=np.int16)
     assert fr.shape[0] >= 180000
     buf = (_Cand * maxcand)()
     red = np.zeros(1921, np.float32); red2 = np.zeros(1921, np.float32)
     jp = np.zeros(1921, np.int32); jp2 = np.zeros(1921, np.int32)
-    n = lib().orc_ft8_sync(fr, f_lo_hz, f_hi_hz, syncmin, maxcand, C.addressof(buf), maxcand,
-                           red.ctypes.data, jp.ctypes.data, red2.ctypes.data, jp2.ctypes.data)
+    n = lib().orc_ft8_sync_ordered(fr, f_lo_hz, f_hi_hz, syncmin, maxcand, ORDER[order], C.addressof(buf), maxcand,
+                                   red.ctypes.data, jp.ctypes.data, red2.ctypes.data, jp2.ctypes.data)
     assert n >= 0
     cands = [(buf[k].freq_bin, buf[k].time_step, buf[k].sync, buf[k].freq_hz, buf[k].dt_s) for k in range(n)]
     if want_arrays:
@@ -584,13 +595,13 @@ def ft4_spectra(frame_i16):
     return out.reshape(122, 1153)
 
 
-def ft4_candidates(frame_i16, fa_hz=200.0, fb_hz=4000.0, syncmin=1.2, maxcand=200, want_arrays=False):
+def ft4_candidates(frame_i16, fa_hz=200.0, fb_hz=4000.0, syncmin=1.2, maxcand=200, want_arrays=False, order="sync"):
     """PARITY UNPINNED.  -> list of (freq_bin, 0, height, freq_hz, 0.0) [, dict(savsm, sbase)]."""
     fr = np.ascontiguousarray(frame_i16, dtype=np.int16)
     assert fr.shape[0] >= 72576
     buf = (_Cand * maxcand)()
     sm = np.zeros(1153, np.float32); sb = np.zeros(1153, np.float32)
-    n = lib().orc_ft4_candidates(fr, fa_hz, fb_hz, syncmin, maxcand, C.addressof(buf), maxcand, sm.ctypes.data, sb.ctypes.data)
+    n = lib().orc_ft4_candidates_ordered(fr, fa_hz, fb_hz, syncmin, maxcand, ORDER[order], C.addressof(buf), maxcand, sm.ctypes.data, sb.ctypes.data)
     assert n >= 0
     cands = [(buf[k].freq_bin, buf[k].time_step, buf[k].sync, buf[k].freq_hz, buf[k].dt_s) for k in range(n)]
     return (cands, dict(savsm=sm, sbase=sb)) if want_arrays else cands

@@ -233,9 +233,34 @@ static int cmp_keyed(const void *a, const void *b)
 
 static const int icos7[7] = {3, 1, 4, 0, 6, 5, 2};
 
+/* sync8's near-duplicate test on the time axis, "abs(candidate0(2,i)-candidate0(2,j)) .lt. 0.04" in single precision: candidate0(2,.) =
+ * (jpeak - 0.5) * tstep with tstep = NSTEP / 12000.0 = fl(0.04).  0.04 is not a binary fraction, so for two entries EXACTLY ONE STEP apart the
+ * outcome depends on how the two products round: of the 124 pairs (l, l + 1), l = -62 .. 61, 77 compare as closer than 0.04 s and 47 do not
+ * (tests/test_sync_oracle.py pins the table); two steps apart never do.  The expression, in this order, is the spec: kernel and oracle use it,
+ * tests/indep_sync.py restates it in numpy float32.  Whether upstream's compiler evaluates it the same way is not verifiable here (PARITY
+ * UNPINNED); a double-precision reading would make NO one-step pair close. */
+int orc_ft8_tdiff_close(int lag_i, int lag_j)
+{
+    const float tstep = FT8_NSTEP / 12000.0f;
+    const float ti = ((float)lag_i - 0.5f) * tstep, tj = ((float)lag_j - 0.5f) * tstep;
+    const float tdiff = fabsf(ti - tj);
+    return tdiff < 0.04f;
+}
+
 int orc_ft8_sync(const int16_t *frame, int nfa_hz, int nfb_hz, float syncmin, int maxcand,
                  orc_candidate_t *out, int max_out,
                  float *red_o, int32_t *jpeak_o, float *red2_o, int32_t *jpeak2_o)
+{
+    return orc_ft8_sync_ordered(frame, nfa_hz, nfb_hz, syncmin, maxcand, ORC_ORDER_SYNC_DESC, out, max_out, red_o, jpeak_o, red2_o, jpeak2_o);
+}
+
+/* order: ORC_ORDER_SYNC_DESC -- the list strongest first and cut at maxcand in that order (the order of sync8.f90's commented-out "Sort by sync"
+ * lines and of WSJT-X 1.x); ORC_ORDER_FREQ_ASC -- ascending frequency with the cut taken in THAT order (sync8.f90's live "Sort by frequency"
+ * as recalled: indexx on the frequency column, copy while k <= maxcand); entries of one bin keep their order of discovery (the +-10 lag peak
+ * before the +-62 one: upstream's indexx is not stable, so this tie rule is the builder's).  Neither is verifiable here: PARITY UNPINNED. */
+int orc_ft8_sync_ordered(const int16_t *frame, int nfa_hz, int nfb_hz, float syncmin, int maxcand, int order,
+                         orc_candidate_t *out, int max_out,
+                         float *red_o, int32_t *jpeak_o, float *red2_o, int32_t *jpeak2_o)
 {
     const float df = 12000.0f / FT8_NFFT1;              /* 3.125 */
     const float tstep = FT8_NSTEP / 12000.0f;           /* 0.04  */
@@ -332,14 +357,13 @@ int orc_ft8_sync(const int16_t *frame, int nfa_hz, int nfb_hz, float syncmin, in
     for (int i = 1; i < ncand; ++i) {
         for (int j = 0; j < i; ++j) {
             const float fdiff = fabsf(c0[i].freq_hz) - fabsf(c0[j].freq_hz);
-            const float tdiff = fabsf(c0[i].dt_s - c0[j].dt_s);
-            if (fabsf(fdiff) < 4.0f && tdiff < 0.04f) {
+            if (fabsf(fdiff) < 4.0f && orc_ft8_tdiff_close(c0[i].time_step, c0[j].time_step)) {      /* dt_s = (time_step - 0.5) * tstep, as above */
                 if (c0[i].sync >= c0[j].sync) c0[j].sync = 0.0f;
                 if (c0[i].sync < c0[j].sync) c0[i].sync = 0.0f;
             }
         }
     }
-    /* final list: descending sync, ties by ascending bin then lag; survivors only */
+    /* final list, survivors only: descending sync (ties by ascending bin then lag), or ascending bin (ties by order of discovery) */
     int nout = 0;
     for (int pass = 0; pass < ncand && nout < max_out && nout < maxcand; ++pass) {
         int bi = -1;
@@ -347,6 +371,7 @@ int orc_ft8_sync(const int16_t *frame, int nfa_hz, int nfb_hz, float syncmin, in
             if (!(c0[i].sync >= syncmin)) continue;
             if (bi < 0) { bi = i; continue; }
             const orc_candidate_t *a = &c0[i], *b = &c0[bi];
+            if (order == ORC_ORDER_FREQ_ASC) { if (a->freq_bin < b->freq_bin) bi = i; continue; }
             if (a->sync > b->sync || (a->sync == b->sync && (a->freq_bin < b->freq_bin ||
                 (a->freq_bin == b->freq_bin && a->time_step < b->time_step)))) bi = i;
         }
@@ -447,6 +472,14 @@ static void shell_sort(float *a, int n)
 /* out arrays (optional): savsm_norm[1153], sbase[1153].  Returns candidate count (<= max_out). */
 int orc_ft4_candidates(const int16_t *frame, float fa_hz, float fb_hz, float syncmin, int maxcand,
                        orc_candidate_t *out, int max_out, float *savsm_o, float *sbase_o)
+{
+    return orc_ft4_candidates_ordered(frame, fa_hz, fb_hz, syncmin, maxcand, ORC_ORDER_SYNC_DESC, out, max_out, savsm_o, sbase_o);
+}
+
+/* order: the peaks are FOUND scanning upwards and the scan stops at maxcand either way (getcandidates4.f90); ORC_ORDER_SYNC_DESC then lists them
+ * by height (its indexx on the height column, read backwards), ORC_ORDER_FREQ_ASC leaves them as found.  Same entries in both. */
+int orc_ft4_candidates_ordered(const int16_t *frame, float fa_hz, float fb_hz, float syncmin, int maxcand, int order,
+                               orc_candidate_t *out, int max_out, float *savsm_o, float *sbase_o)
 {
     const int NB1 = F4_NH1 + 1;
     float *s = (float *)malloc(sizeof(float) * (size_t)NB1 * F4_NHSYM);
@@ -550,6 +583,7 @@ int orc_ft4_candidates(const int16_t *frame, float fa_hz, float fb_hz, float syn
         int bi = -1;
         for (int i = 0; i < ncand; ++i) {
             if (c0[i].time_step) continue;
+            if (order == ORC_ORDER_FREQ_ASC) { if (bi < 0) bi = i; continue; }          /* as found: ascending bin */
             if (bi < 0 || c0[i].sync > c0[bi].sync || (c0[i].sync == c0[bi].sync && c0[i].freq_bin < c0[bi].freq_bin)) bi = i;
         }
         if (bi < 0) break;

@@ -55,6 +55,13 @@ int orc_ft8_spectra(const int16_t *frame, float *s_out, int nbins);
 int orc_ft8_sync(const int16_t *frame, int nfa_hz, int nfb_hz, float syncmin, int maxcand,
                  orc_candidate_t *out, int max_out,
                  float *red, int32_t *jpeak, float *red2, int32_t *jpeak2);
+int orc_ft8_tdiff_close(int lag_i, int lag_j);   /* the float32 near-duplicate test on the time axis (see sync_oracle.c) */
+/* final order and cut of the FT8 / FT4 lists (cwslg_set_candidate_order): see sync_oracle.c */
+#define ORC_ORDER_SYNC_DESC 0
+#define ORC_ORDER_FREQ_ASC  1
+int orc_ft8_sync_ordered(const int16_t *frame, int nfa_hz, int nfb_hz, float syncmin, int maxcand, int order,
+                         orc_candidate_t *out, int max_out,
+                         float *red, int32_t *jpeak, float *red2, int32_t *jpeak2);
 
 /* ---- FT4 (getcandidates4): PARITY UNPINNED, see sync_oracle.c ---- */
 #define FT4_NFFT1 2304
@@ -65,6 +72,8 @@ int orc_ft8_sync(const int16_t *frame, int nfa_hz, int nfb_hz, float syncmin, in
 int orc_ft4_spectra(const int16_t *frame, float *s_out /* [122][1153] */);
 int orc_ft4_candidates(const int16_t *frame, float fa_hz, float fb_hz, float syncmin, int maxcand,
                        orc_candidate_t *out, int max_out, float *savsm_norm /*[1153]*/, float *sbase /*[1153]*/);
+int orc_ft4_candidates_ordered(const int16_t *frame, float fa_hz, float fb_hz, float syncmin, int maxcand, int order,
+                               orc_candidate_t *out, int max_out, float *savsm_norm /*[1153]*/, float *sbase /*[1153]*/);
 double orc_log10_fixed(double x);
 double orc_exp10_fixed(double y);
 

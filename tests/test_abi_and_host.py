@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), f"{n} declared in cwsl_gpu.h but not exported"
     assert sorted(api.ABI_SYMBOLS) == names, set(api.ABI_SYMBOLS) ^ set(names)
-    assert L.cwslg_abi_version() == 4
+    assert L.cwslg_abi_version() == 5
 
 
 def test_fails_loudly_without_gpu():

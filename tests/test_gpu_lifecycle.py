@@ -4,6 +4,7 @@ import threading
 import numpy as np
 import pytest
 
+import cwsl_digi_amd as P
 from conftest import assert_frames_match
 
 pytestmark = pytest.mark.gpu
@@ -230,3 +231,83 @@ def test_fetch_is_atomic_against_the_next_boundary(ctx, oracle):
         t.join()
     assert not errors, errors[:3]
     assert {e for _, e in seen} >= {n_epochs} and len({e for _, e in seen}) >= 3     # the consumers overlapped several generations
+
+
+def test_candidate_lists_are_atomic_against_the_next_boundary(ctx, oracle):
+    """ABI 5: the results of one epoch, atomically.  ItemToDecode carries epochTime with its audio (DecoderPool.hpp:174-210); here the candidate
+    lists travel the same way.  A clock thread pushes whole 48 kHz FT8 slots of distinct noise + tones and fires the boundary, back to back, while
+    three consumers loop over (a) cwslg_fetch_slot -- the frame must be the oracle's frame of the start epoch it is returned with AND the list
+    must be the restated search of exactly that frame -- and (b) cwslg_fetch_candidates with its start_epoch: in exact mode the list must be the
+    oracle's list of the oracle's frame of that epoch.  (ABI 4 returned lists without an epoch and copied them under the context mutex on the
+    compute stream; a consumer one boundary late paired frame N with list N + 1 and could not tell.)"""
+    fs, blk = 48000, 512
+    n_ch, n_epochs, n_blk = 6, 9, 1400                     # 1400 x 512 / 48000 = 14.9 s of signal per slot
+    ctx.enable_sync(True, 1.5, 100, 200, 3000)
+    rx = ctx.receiver_open(fs, blk, 0)
+    freqs = [-18000 + 6000 * k for k in range(n_ch)]
+    chans = [ctx.channel_open(rx, f, "FT8") for f in freqs]
+    segs = {e: oracle.synth_iq(7000 + e, n_blk * blk, fs, tones_hz=[freqs[e % n_ch] + 700.0 + 13.0 * e, freqs[(3 * e + 1) % n_ch] + 1500.0], amp=1.5e4)
+            for e in range(1, n_epochs + 1)}
+    want, want_list = {}, {}
+    for k, f in enumerate(freqs):
+        oc = oracle.Channel("FT8", fs, blk, f)
+        assert oc.boundary(1) is None
+        for e in range(1, n_epochs + 1):
+            oc.push_many(segs[e])
+            r = oc.boundary(e + 1)
+            want[(k, e)] = r["i16"].copy()
+            want_list[(k, e)] = oracle.ft8_sync(r["i16"], 200, 3000, 1.5, 100)
+        oc.close()
+    key = lambda lst: [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in lst]
+    for k in range(n_ch):                                  # the lists really differ from epoch to epoch
+        assert len({tuple(key(want_list[(k, e)])) for e in range(1, n_epochs + 1)}) >= n_epochs - 1
+    exact = ctx.mode == "exact"
+    errors, seen = [], set()
+    stop = threading.Event()
+
+    def clock():
+        try:
+            ctx.slot_boundary("FT8", 1)
+            for e in range(1, n_epochs + 1):
+                ctx.push_iq(rx, segs[e])
+                ctx.slot_boundary("FT8", e + 1)
+        except Exception as ex:       # pragma: no cover
+            errors.append(ex)
+        finally:
+            stop.set()
+
+    def consumer(first):
+        try:
+            k = first
+            while True:
+                done = stop.is_set()
+                for _ in range(n_ch):
+                    r = ctx.fetch_slot(chans[k], max_list=100)
+                    if r is not None:
+                        e = int(r["t_start"])
+                        if np.abs(r["i16"].astype(np.int32) - want[(k, e)].astype(np.int32)).max() > (0 if exact else 1):
+                            errors.append(AssertionError(f"fetch_slot, channel {k}: frame returned with start epoch {e} is not that slot's frame")); return
+                        if r["list_kind"] != "FT8" or key(r["list"]) != key(oracle.ft8_sync(r["i16"], 200, 3000, 1.5, 100)):
+                            errors.append(AssertionError(f"fetch_slot, channel {k}, epoch {e}: the list is not the search of the frame it came with")); return
+                        seen.add((k, e))
+                    try:
+                        lst, e = ctx.fetch_candidates(chans[k], 100, with_epoch=True)
+                    except P.CwslGpuError as ex:
+                        if ex.status != -9:                    # CWSLG_ERR_NO_FRAME
+                            raise
+                        lst = None                          # no list yet (first, discarded slot)
+                    if lst is not None and exact and key(lst) != key(want_list[(k, int(e))]):
+                        errors.append(AssertionError(f"fetch_candidates, channel {k}: list returned with start epoch {e} is not that slot's list")); return
+                    k = (k + 1) % n_ch
+                if done:
+                    return
+        except Exception as ex:       # pragma: no cover
+            errors.append(ex)
+
+    th = [threading.Thread(target=clock)] + [threading.Thread(target=consumer, args=(2 * j,)) for j in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+    assert {e for _, e in seen} >= {n_epochs} and len({e for _, e in seen}) >= 3

@@ -97,3 +97,47 @@ def test_realtime_harness_zero_drops_and_bit_identical_frames(tmp_path, oracle, 
         assert len(got) == len(want)
         for g_, w_ in zip(got, want):
             assert (int(g_[0]), int(g_[1])) == (w_[0], w_[1]) and np.float32(g_[2]) == np.float32(w_[2])
+
+
+def test_single_block_wakeups_at_1024_channels_low_redundancy(tmp_path, oracle):
+    """a host that mirrors the reference's one wake-up per block (Instance.cpp:260-276; Receiver.hpp:132 gives it a
+    3 s ring) -- 1024 channels on 32 receivers, cwslg_process() after EVERY block period -- with the library's own launch threshold
+    (cwslg_set_process_threshold(ctx, -1)).  The bit-identical kernel pays a 32-block warm-up per stream of outputs, so WHEN it launches
+    decides how much it fetches and multiplies per output delivered: here frames and candidate lists must be bit-identical to the oracle driven
+    with the same blocks AND the blocks put through the arithmetic (stats.demod_blocks_read) stay within 1.1x of the blocks delivered.
+    Without the threshold the same run launches 1300+ times at a redundancy above 3 (asserted, so that the knob's effect is on record)."""
+    from cwsl_digi_amd import build as B
+    B.build()
+    R, C, pre, slot, slots, stride, nfile = 32, 32, 8, 1406, 1, 3, 128
+    tones = [-90000 + ((k * 1373) % 176000) + 1500.0 for k in range(0, R * C, 97)][:8]
+    iq = oracle.synth_iq(777, nfile * BLK, FS, tones_hz=tones, amp=1.5e4).astype(np.complex64)
+    path = tmp_path / "iq.c64"
+    iq.tofile(path)
+    lines = {}
+    for thr in (-1, 0):
+        out = tmp_path / f"out{thr}"; out.mkdir()
+        p = subprocess.run([B.REALTIME, "--receivers", str(R), "--channels-per-rx", str(C), "--pre", str(pre), "--slot-blocks", str(slot),
+                            "--slots", str(slots), "--speed", "0", "--mode", "batch", "--exact", "1", "--sync", "1", "--iq", str(path),
+                            "--iq-stride", str(stride), "--dump", "5", "--out", str(out), "--process-ms", "10.6", "--process-threshold", str(thr)],
+                           capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines[thr] = line = json.loads(p.stdout.strip().splitlines()[-1])
+        assert line["blocks_dropped"] == 0 and line["frames_emitted"] == R * C * slots and line["exact"] == 1
+        if thr == 0:
+            continue                                                            # (frames of the unthresholded run: covered by the tests above)
+        blocks = iq.reshape(nfile, BLK)
+        for row in open(out / "dump.txt"):
+            k, r, f, t_start, nv, wav = row.split()
+            k, r, f = int(k), int(r), int(f)
+            oc = oracle.Channel("FT8", FS, BLK, f)
+            oc.push_many(np.concatenate([blocks[(r * stride + j) % nfile] for j in range(pre)])); assert oc.boundary(1000) is None
+            oc.push_many(np.concatenate([blocks[(r * stride + pre + j) % nfile] for j in range(slot)])); ref = oc.boundary(1015)
+            assert int(t_start) == ref["t_start"] == 1000 and int(nv) == slot * BLK // 16
+            assert np.array_equal(_read_wav(wav), ref["i16"]), (k, r, f)
+            want = oracle.ft8_sync(ref["i16"], 200, 3000, 1.5, 200)
+            got = [l.split() for l in open(out / f"ch{k}.cand")]
+            assert [(int(g_[0]), int(g_[1]), np.float32(g_[2])) for g_ in got] == [(w_[0], w_[1], np.float32(w_[2])) for w_ in want]
+    a, b = lines[-1], lines[0]
+    assert a["process_threshold"] == -1 and a["process_deferred"] > 1000 and a["demod_launches"] <= 20
+    assert 1.0 < a["demod_redundancy"] <= 1.1, a["demod_redundancy"]
+    assert b["demod_launches"] >= 1300 and b["demod_redundancy"] > 3.0, (b["demod_launches"], b["demod_redundancy"])

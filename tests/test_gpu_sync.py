@@ -225,3 +225,49 @@ def test_mixed_ft8_ft4_sync_in_one_context(ctx, oracle):
     assert [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in got8] == [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in ref8]
     assert any(abs(c[3] - 900.0) <= 40 for c in got4a[:4]) and any(abs(c[3] - 2100.0) <= 40 for c in got4b[:4])
     assert any(abs(c[3] - 1200.0) <= 4 for c in got8[:3])
+
+
+def test_candidate_order_option_and_dense_lists(ctx, oracle):
+    """cwslg_set_candidate_order (ABI 5) and the near-duplicate rule on dense lists.  One receiver, an FT8 channel carrying 16 signals and an FT4
+    channel carrying 6; the same slot is searched in both orders with a list that is cut (maxcand 40) and one that is not (600): every list
+    equals the restatement's bit for bit, 'freq' keeps the lowest 40 in frequency where 'sync' keeps the strongest 40, and uncut they hold the
+    same entries.  With 16 signals the FT8 list has hundreds of entries whose survival is decided by the float32 `tdiff < 0.04` test
+    (tests/test_sync_oracle.py::test_tdiff_boundary_decides_real_lists shows the alternatives differ by dozens of entries on such frames)."""
+    n8 = 2880000 // BLK * BLK
+    rng = np.random.default_rng(77)
+    iq = oracle.synth_iq(77, n8, FS)
+    for _ in range(16):
+        iq = iq + ft8_iq(FS, n8, 10000, rng.uniform(250, 2900), rng.uniform(0.1, 1.9), rng.uniform(600, 2500), rng)
+    for _ in range(6):
+        iq = iq + ft4_iq(FS, n8, -30000, rng.uniform(300, 2800), rng.uniform(0.2, 1.0), rng.uniform(800, 2500), rng)
+    iq = iq.astype(np.complex64)
+    rx = ctx.receiver_open(FS, BLK, 0)
+    c8 = ctx.channel_open(rx, 10000, "FT8")
+    c4 = ctx.channel_open(rx, -30000, "FT4")
+    key = lambda lst: [(c[0], c[1], np.float32(c[2]).view(np.uint32), np.float32(c[3]).view(np.uint32)) for c in lst]
+    lists = {}
+    epoch = 100
+    for order in ("sync", "freq"):
+        for maxcand in (40, 600):
+            ctx.enable_sync(True, 1.2, maxcand, 200, 3000)
+            ctx.set_candidate_order(order)
+            ctx.slot_boundary("FT8", epoch); ctx.slot_boundary("FT4", epoch)
+            for k in range(0, n8, 128 * BLK):
+                ctx.push_iq(rx, iq[k:k + 128 * BLK])
+            epoch += 15
+            ctx.slot_boundary("FT8", epoch); ctx.slot_boundary("FT4", epoch)
+            fr8, fr4 = ctx.fetch_frame(c8)["i16"], ctx.fetch_frame(c4)["i16"]
+            g8, g4 = ctx.fetch_candidates(c8, 600), ctx.fetch_candidates(c4, 600)
+            assert key(g8) == key(oracle.ft8_sync(fr8, 200, 3000, 1.2, maxcand, order=order)), (order, maxcand)
+            assert key(g4) == key(oracle.ft4_candidates(fr4, 200.0, 3000.0, 1.2, maxcand, order=order)), (order, maxcand)
+            lists[(order, maxcand)] = (g8, g4)
+            epoch += 15
+    s40, s600 = lists[("sync", 40)][0], lists[("sync", 600)][0]
+    f40, f600 = lists[("freq", 40)][0], lists[("freq", 600)][0]
+    assert len(s600) > 100 and len(s40) == len(f40) == 40
+    assert sorted(key(s600)) == sorted(key(f600))                                       # uncut: the same entries
+    assert key(s40) == key(s600[:40]) and key(f40) == key(f600[:40])
+    assert [c[0] for c in f600] == sorted(c[0] for c in f600) and [c[2] for c in s600] == sorted((c[2] for c in s600), reverse=True)
+    assert {c[:2] for c in s40} != {c[:2] for c in f40}                                 # cut: different entries
+    g4s, g4f = lists[("sync", 600)][1], lists[("freq", 600)][1]
+    assert sorted(key(g4s)) == sorted(key(g4f)) and [c[0] for c in g4f] == sorted(c[0] for c in g4f) and len(g4f) >= 4

