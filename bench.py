@@ -458,6 +458,8 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_source, "bytes_per_sample": bps, "samples_per_launch": spl,
                 "avg_launch_ms": avg_ms, "launches": st_["demod_launches"],
                 "finalize_avg_ms": st_["finalize_ms"] / max(1, st_["finalize_launches"]),
+                # round 6: FT8 channels with the sync stage on are finalised INSIDE symbol_spectra_v2_kernel (no separate launch: 0 here, its cost is in sync_avg_ms)
+                "finalize_launches": st_["finalize_launches"],
                 "sync_avg_ms": st_["sync_ms"] / max(1, st_["sync_launches"]),
                 "whole_path_frac": BYTES_PER_SAMPLE_PATH * spl * args.steps / dt_ / 1e9 / HBM_PEAK_GBS}
         if exact and "exact5" in kname:

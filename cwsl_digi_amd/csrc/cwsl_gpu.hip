@@ -193,6 +193,9 @@ struct Channel {
     int frame_idx = 0;
     uint64_t frame_t0 = 0;
     size_t frame_valid = 0;
+    // this boundary's finalise rides in the FT8 spectra kernel (boundary_locked -> sync_launch)
+    bool fin_fused = false;
+    FinWork fused_fin{};
     // sync results
     uint64_t cand_t0 = 0;              // start epoch of the frame the candidate lists on the device were computed from (0: none yet)
     SyncChannelBuffers syncbuf;
@@ -270,6 +273,10 @@ struct cwslg_ctx {
     unsigned long long *clk_h = nullptr, *clk_dev = nullptr;
     unsigned clk_head = 0, clk_tail = 0;
     unsigned exact5_seg_cap = kExact5SegCap, exact5_seg_force = 0;
+#ifndef CWSLG_FUSE_FIN_DEFAULT
+#define CWSLG_FUSE_FIN_DEFAULT 1       // (-DCWSLG_FUSE_FIN_DEFAULT=0: a measurement build with round 5's separate finalise pass, scripts/gpu_r6_sync_ab.sh)
+#endif
+    bool fuse_finalize = CWSLG_FUSE_FIN_DEFAULT != 0;         // FT8 + sync: the slot's finalise inside symbol_spectra_v2_kernel (lab build: CWSLG_FUSE_FIN=0 keeps the separate pass, for A/B)
     int process_min_outputs = 0;       // cwslg_set_process_threshold: 0 every cwslg_process() launches, < 0 the library's own threshold, > 0 that many outputs
     bool use_exact5 = true;            // exact mode: demod_exact5_kernel<D> (lab build: a non-zero CWSLG_DEMOD_VARIANT selects round 3/4's tile kernels instead)
     unsigned stat_gen = 0;             // bumped by cwslg_reset_stats: work timed before a reset is not folded into the figures read after it
@@ -1024,6 +1031,11 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s,
             c->stats.frames_discarded++;                // NOTE: no demodulator restart on this path (:226 `continue`)
         }
         ch.pend_fill0 = 0;
+        // FT8 channels whose frame goes through the sync stage: symbol_spectra_v2_kernel converts the frame itself (sync_kernels.hpp,
+        // spectra_finalize_span) -- no separate memory pass; everything else (no sync, FT4, the 120 s modes, discarded frames) is finalised here
+        ch.fin_fused = c->fuse_finalize && f.emit && c->sync_cfg.enabled && ch.sync_ft8 && c->sync_variant == 0 &&
+                       ch.frame_len >= (size_t)(FT8_NSTEP * (FT8_NHSYM - 1) + FT8_NSPS);
+        if (ch.fin_fused) { ch.fused_fin = f; continue; }
         fin.push_back(f);
         max_len = std::max(max_len, ch.frame_len);
     }
@@ -1041,20 +1053,22 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s,
             return true;
         });
     }
-    WorkBuf *w = acquire_workbuf(c, fin.size() * sizeof(FinWork));
-    if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
-    std::memcpy(w->h, fin.data(), fin.size() * sizeof(FinWork));
-    HIPCHK(c, upload_workbuf(c, w, fin.size() * sizeof(FinWork)));
-    const unsigned gx = (unsigned)((max_len + kFinThreads * 8 * kFinChunks - 1) / (kFinThreads * 8 * kFinChunks));
-    hipEvent_t ea, eb;
-    span_begin(c, 1, &ea, &eb);
-    hipLaunchKernelGGL((finalize_kernel<kFinThreads>), dim3(gx, (unsigned)fin.size()), dim3(kFinThreads), 0, c->stream,
-                       (const FinWork *)w->d);
-    span_end(c, eb);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(w->done, c->stream));
-    w->in_flight = true;
-    c->stats.finalize_launches++;
+    if (!fin.empty()) {
+        WorkBuf *w = acquire_workbuf(c, fin.size() * sizeof(FinWork));
+        if (!w) return fail(c, CWSLG_ERR_NOMEM, "work buffer allocation failed");
+        std::memcpy(w->h, fin.data(), fin.size() * sizeof(FinWork));
+        HIPCHK(c, upload_workbuf(c, w, fin.size() * sizeof(FinWork)));
+        const unsigned gx = (unsigned)((max_len + kFinThreads * 8 * kFinChunks - 1) / (kFinThreads * 8 * kFinChunks));
+        hipEvent_t ea, eb;
+        span_begin(c, 1, &ea, &eb);
+        hipLaunchKernelGGL((finalize_kernel<kFinThreads>), dim3(gx, (unsigned)fin.size()), dim3(kFinThreads), 0, c->stream,
+                           (const FinWork *)w->d);
+        span_end(c, eb);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipEventRecord(w->done, c->stream));
+        w->in_flight = true;
+        c->stats.finalize_launches++;
+    }
     if (n_emitted) *n_emitted = emitted.size();
     for (int g = 0; g < CWSLG_NUM_GROUPS; ++g)      // a new generation of results: the next fetch records the group's event behind this boundary's kernels
         if (in_group[g]) c->fetch_ev_valid[g] = false;
@@ -1157,6 +1171,7 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
     if (const char *v = std::getenv("CWSLG_SYNC_VARIANT")) c->sync_variant = std::atoi(v);
     if (const char *v = std::getenv("CWSLG_LONG_VARIANT")) c->long_variant = std::atoi(v);
     if (const char *v = std::getenv("CWSLG_COPY_ON_MAIN")) c->copy_on_main = std::atoi(v) != 0;
+    if (const char *v = std::getenv("CWSLG_FUSE_FIN")) c->fuse_finalize = std::atoi(v) != 0;
 #endif
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
     for (int k = 0; k < kCopyStreams; ++k) {

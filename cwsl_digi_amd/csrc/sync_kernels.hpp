@@ -82,6 +82,9 @@ struct alignas(16) SyncWork {
     int *jpeak, *jpeak2;
     SyncChannelBuffers::Cand *cand;
     int *ncand;
+    // Round 6: the slot's finalise (prepareAudio + int16, Instance.cpp:294-338, 238-241) done by the FT8 spectra kernel itself -- fin.frame != nullptr:
+    // `frame` has NOT been written yet; every workgroup of symbol_spectra_v2_kernel first converts the samples its own windows cover (fin.out == frame).
+    FinWork fin;
 };
 
 inline void sync_free_channel(SyncChannelBuffers &b)
@@ -546,6 +549,81 @@ inline int spectra_jper(int nsteps, size_t channels)
 #else
 #define PSTAMP(slot) do { } while (0)
 #endif
+// Round 6: the slot's finalise fused into the spectra kernel (FT8 channels with the sync stage on).  finalize_kernel was a separate memory pass
+// -- 4.4 GB per 4096-slot boundary, 0.87 ms -- whose int16 output this kernel then read back from HBM; here every workgroup converts, before its
+// first transform, exactly the samples its own windows cover ([STEP j0, STEP (jend - 1) + NIN): its jper steps plus the NIN - STEP samples the last
+// windows reach into the next workgroup's share -- those are converted by both, to the same bits, so no workgroup waits for another) plus its
+// share of the frame's tail beyond the last window (FT8: samples 180000 .. 239999 of the 20 s frame, Instance.cpp:149), writes them as the int16
+// frame and then reads its windows back through the cache.  The traffic (2.95 GB of float reads, 1.5 GB of int16 writes) now runs under the
+// transforms of the CU's other workgroups -- this kernel is bound by instruction issue, not by memory.  Arithmetic per sample = finalize_kernel's,
+// in its order: factor = 32767 / (peak + 1) * scale; (int16)(x * factor + 0.5f); zeros at and beyond n_valid.
+// Visibility: the stores are write-through to the XCD's L2; s_waitcnt vmcnt(0) + the workgroup barrier order them before the window loads of every
+// wave of the workgroup (same CU: one L1, which a store updates or bypasses, never leaves stale).
+template <int STEP, int NIN>
+__device__ __forceinline__ void spectra_finalize_span(const FinWork &f, int j0, int jend, int nsteps)
+{
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const CWSLG_GLOBAL float *frame = as_global(f.frame);
+    CWSLG_GLOBAL int16_t *out = as_global_rw(f.out);
+    const unsigned nv = f.n_valid, flen = f.frame_len;
+    const float peak = __uint_as_float(*as_global(f.peak));
+    float factor = 32767.0f / (peak + 1.0f);
+    factor = factor * f.scale;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (f.peak_next) *as_global_rw(f.peak_next) = 0u;
+        if (f.factor_out) *as_global_rw(f.factor_out) = factor;
+    }
+    const unsigned cover = min((unsigned)(STEP * (nsteps - 1) + NIN), flen);       // what the windows of all workgroups cover
+    const unsigned tail_per = ((flen - cover + gridDim.x - 1) / gridDim.x + 7u) & ~7u;
+    // two runs: the windows' span, then this workgroup's share of the tail
+    for (int run = 0; run < 2; ++run) {
+        // (run 0 widened to whole 128-byte lines of the int16 frame: every line a window load of this workgroup can bring into the CU's L1 then holds
+        // only samples THIS workgroup has written -- final values -- and no half-old line can be met there by the neighbour that owns its other half)
+        const unsigned s0 = run == 0 ? ((unsigned)(STEP * j0) & ~63u) : min(cover + tail_per * blockIdx.x, flen);
+        const unsigned s1 = run == 0 ? min(((unsigned)(STEP * (jend - 1) + NIN) + 63u) & ~63u, flen) : min(cover + tail_per * (blockIdx.x + 1), flen);
+        for (unsigned base = s0 + threadIdx.x * 8u; base < s1; base += 256u * 8u * 4u) {
+            v4f a[4], b[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                       // all loads of the round first (eight 16-byte reads in flight per lane)
+                const unsigned i0 = base + (unsigned)c * (256u * 8u);
+                if (i0 + 8 <= nv && i0 < s1) {
+                    a[c] = *reinterpret_cast<const CWSLG_GLOBAL v4f *>(frame + i0);
+                    b[c] = *reinterpret_cast<const CWSLG_GLOBAL v4f *>(frame + i0 + 4);
+                } else {
+                    float v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = (i0 + k < nv && i0 < s1) ? frame[i0 + k] : 0.0f;
+                    a[c] = v4f{v[0], v[1], v[2], v[3]};
+                    b[c] = v4f{v[4], v[5], v[6], v[7]};
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned i0 = base + (unsigned)c * (256u * 8u);
+                if (i0 >= s1) break;
+                const float v[8] = {a[c].x, a[c].y, a[c].z, a[c].w, b[c].x, b[c].y, b[c].z, b[c].w};
+                int q[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float scaled = v[k] * factor;                 // buf[k] *= factor
+                    const float biased = scaled + 0.5f;                 // + 0.5f
+                    q[k] = (int)biased;                                 // C truncation toward zero, then narrowed to int16
+                }
+                v4u pk;
+                pk.x = ((unsigned)q[0] & 0xFFFFu) | ((unsigned)q[1] << 16);
+                pk.y = ((unsigned)q[2] & 0xFFFFu) | ((unsigned)q[3] << 16);
+                pk.z = ((unsigned)q[4] & 0xFFFFu) | ((unsigned)q[5] << 16);
+                pk.w = ((unsigned)q[6] & 0xFFFFu) | ((unsigned)q[7] << 16);
+                const unsigned rem = s1 - i0;
+                if (rem >= 8) *reinterpret_cast<CWSLG_GLOBAL v4u *>(out + i0) = pk;
+                else for (unsigned k = 0; k < rem; ++k) out[i0 + k] = (int16_t)q[k];
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): this wave's stores have reached the L2 ...
+    __syncthreads();                                      // ... and so have every other wave's, before any window is read back
+}
+
 template <int NA, int NIN, int STEP, bool WINDOW>
 __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kernel(const SyncWork *__restrict__ works, SyncTables tb, int nbins, int nsteps, int jper)
 {
@@ -574,6 +652,7 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     // workgroup does.
     const CWSLG_GLOBAL unsigned *d32 = as_global(reinterpret_cast<const unsigned *>(w->frame)) + b_;
     float *const plane = w->spectra;                      // (fetched here: behind the loop's barriers -- memory clobbers -- it was a scalar load and a wait per transform)
+    if (w->fin.frame != nullptr) spectra_finalize_span<STEP, NIN>(w->fin, j0, jend, nsteps);
     unsigned raw[AMAX];
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) raw[a] = (128 * a + b_ < NPACK) ? d32[(STEP / 2) * j0 + 128 * a] : 0u;

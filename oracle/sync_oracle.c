@@ -134,7 +134,7 @@ static void dft15_pfa8(const float *zr, const float *zi, float *outr, float *out
 /* x[0 .. 2*npack) real (implicitly zero padded to 2*NZ); pw[k] = |X[k]|^2 for k in [0, nbins), nbins <= NZ + 1 */
 static void spectrum_packed(const fft_plan *P, const float *x, float *pw, int nbins)
 {
-    static float yr[16][NB], yi[16][NB];
+    float yr[16][NB], yi[16][NB];                         /* (automatic: the restatement is called from several test threads at once) */
     const int na = P->na, nz = P->nz;
     for (int b = 0; b < NB; ++b) {
         int amax = 0;

@@ -1,5 +1,6 @@
 """GPU: runtime open/close (band rotation, CWSL_DIGI.cpp:1217-1226), concurrent callers, long-running slots."""
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -271,6 +272,7 @@ def test_candidate_lists_are_atomic_against_the_next_boundary(ctx, oracle):
             for e in range(1, n_epochs + 1):
                 ctx.push_iq(rx, segs[e])
                 ctx.slot_boundary("FT8", e + 1)
+                time.sleep(0.35)                            # (a consumer's round costs six runs of the restatement: let it meet several generations)
         except Exception as ex:       # pragma: no cover
             errors.append(ex)
         finally:
