@@ -196,6 +196,7 @@ struct Channel {
     // this boundary's finalise rides in the FT8 spectra kernel (boundary_locked -> sync_launch)
     bool fin_fused = false;
     FinWork fused_fin{};
+    size_t i16_end = ~size_t(0);       // d_i16 holds zeros at and beyond this index (the n_valid of the frame it holds); unknown until the first finalise
     // sync results
     uint64_t cand_t0 = 0;              // start epoch of the frame the candidate lists on the device were computed from (0: none yet)
     SyncChannelBuffers syncbuf;
@@ -1017,6 +1018,8 @@ int boundary_locked(cwslg_ctx *c, const std::vector<int> &ids, uint64_t epoch_s,
         f.n_valid = (unsigned)ch.fill[cur];
         f.frame_len = (unsigned)ch.frame_len;
         f.emit = (ch.t0[cur] != 0) ? 1 : 0;             // :224-227
+        f.tail_end = (unsigned)std::min<size_t>(ch.frame_len, std::max<size_t>(ch.i16_end, ch.fill[cur]));
+        if (f.emit) ch.i16_end = ch.fill[cur];          // (either form of the finalise leaves zeros from n_valid on)
         if (f.emit) {
             ch.have_frame = true;
             ch.frame_idx = cur;

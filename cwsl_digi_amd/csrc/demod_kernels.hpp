@@ -119,6 +119,9 @@ struct alignas(16) FinWork {
     unsigned     n_valid;     // samples demodulated into the frame
     unsigned     frame_len;   // 12000*(period+5)
     int          emit;        // 0: discarded frame (startEpochTime == 0) -> only the reset
+    unsigned     tail_end;    // (the fused finalise of symbol_spectra_v2_kernel) samples at and beyond this index are zero in `out` ALREADY and in this
+                              // frame: max(n_valid of this slot, n_valid of the slot `out` held before), so the tail beyond the last window is
+                              // rewritten only where one of the two put samples there; frame_len when unknown
 };
 
 struct alignas(16) PhasorJob {

@@ -550,78 +550,65 @@ inline int spectra_jper(int nsteps, size_t channels)
 #define PSTAMP(slot) do { } while (0)
 #endif
 // Round 6: the slot's finalise fused into the spectra kernel (FT8 channels with the sync stage on).  finalize_kernel was a separate memory pass
-// -- 4.4 GB per 4096-slot boundary, 0.87 ms -- whose int16 output this kernel then read back from HBM; here every workgroup converts, before its
-// first transform, exactly the samples its own windows cover ([STEP j0, STEP (jend - 1) + NIN): its jper steps plus the NIN - STEP samples the last
-// windows reach into the next workgroup's share -- those are converted by both, to the same bits, so no workgroup waits for another) plus its
-// share of the frame's tail beyond the last window (FT8: samples 180000 .. 239999 of the 20 s frame, Instance.cpp:149), writes them as the int16
-// frame and then reads its windows back through the cache.  The traffic (2.95 GB of float reads, 1.5 GB of int16 writes) now runs under the
-// transforms of the CU's other workgroups -- this kernel is bound by instruction issue, not by memory.  Arithmetic per sample = finalize_kernel's,
-// in its order: factor = 32767 / (peak + 1) * scale; (int16)(x * factor + 0.5f); zeros at and beyond n_valid.
-// Visibility: the stores are write-through to the XCD's L2; s_waitcnt vmcnt(0) + the workgroup barrier order them before the window loads of every
-// wave of the workgroup (same CU: one L1, which a store updates or bypasses, never leaves stale).
-template <int STEP, int NIN>
-__device__ __forceinline__ void spectra_finalize_span(const FinWork &f, int j0, int jend, int nsteps)
+// -- 4.4 GB per 4096-slot boundary, 0.87 ms -- whose int16 output this kernel then read back from HBM.  Here the workgroup converts the samples its
+// own windows cover itself, writes them as the int16 frame and reads its windows back through the cache:
+//   * before its first transform, the first three windows ([STEP j0, STEP (j0 + 2) + NIN), widened to whole 128-byte lines) and -- rarely, see
+//     FinWork::tail_end -- its share of the frame's tail beyond the last window;
+//   * then, at the top of every transform j, ONE pair of samples per lane: the next 448 / 512 samples, up to the (line-rounded) end of window j + 3.
+//     The transform loop is bound by each wave's dependent chains (VALU issue 56 % busy at four waves per SIMD), so these dozen independent
+//     instructions, one 8-byte load and one 4-byte store per lane ride in its idle issue slots; as a prologue over the whole span (this round's
+//     first form) the conversion cost 18 us per workgroup life of 207 us -- +0.43 ms of the 0.87 ms it saved (profiles/r6_sync_ab.txt).
+// The NIN - STEP samples by which a workgroup's last windows reach into its successor's share are converted by both, to the same bits: no
+// workgroup waits for another.  Arithmetic per sample = finalize_kernel's, in its order: factor = 32767 / (peak + 1) * scale;
+// (int16)(x * factor + 0.5f); zeros at and beyond n_valid.
+// Visibility.  A store issued at the top of transform j has reached the L2 when its wave passes the top of j + 1 (the wait for that transform's
+// window; the vector-memory counter retires in order), every wave of the workgroup has passed it before anyone gets through j + 1's barriers, and
+// the window loaded at the top of j + 2 is window j + 3: final up to the end of its last 128-byte line (the rounding above) -- so no line is ever
+// brought into the CU's L1 while a part of it is still to be written by this workgroup or holds the previous slot's samples.
+struct SpectraFin {
+    const CWSLG_GLOBAL float *frame;
+    CWSLG_GLOBAL int16_t *out;
+    unsigned nv, s_end;
+    float factor;
+};
+__device__ __forceinline__ unsigned fin_pack2(float x0, float x1, float factor)
+{
+    const float s0 = x0 * factor, s1 = x1 * factor;          // buf[k] *= factor
+    const float b0 = s0 + 0.5f, b1 = s1 + 0.5f;              // + 0.5f
+    const int q0 = (int)b0, q1 = (int)b1;                    // C truncation toward zero, then narrowed to int16
+    return ((unsigned)q0 & 0xFFFFu) | ((unsigned)q1 << 16);
+}
+// the range [s0, s1) (multiples of 8 samples) by all 256 lanes, 8 samples per lane and round; every load of a round before its first conversion
+__device__ __forceinline__ void spectra_finalize_range(const SpectraFin &F, unsigned s0, unsigned s1)
 {
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    const CWSLG_GLOBAL float *frame = as_global(f.frame);
-    CWSLG_GLOBAL int16_t *out = as_global_rw(f.out);
-    const unsigned nv = f.n_valid, flen = f.frame_len;
-    const float peak = __uint_as_float(*as_global(f.peak));
-    float factor = 32767.0f / (peak + 1.0f);
-    factor = factor * f.scale;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (f.peak_next) *as_global_rw(f.peak_next) = 0u;
-        if (f.factor_out) *as_global_rw(f.factor_out) = factor;
-    }
-    const unsigned cover = min((unsigned)(STEP * (nsteps - 1) + NIN), flen);       // what the windows of all workgroups cover
-    const unsigned tail_per = ((flen - cover + gridDim.x - 1) / gridDim.x + 7u) & ~7u;
-    // two runs: the windows' span, then this workgroup's share of the tail
-    for (int run = 0; run < 2; ++run) {
-        // (run 0 widened to whole 128-byte lines of the int16 frame: every line a window load of this workgroup can bring into the CU's L1 then holds
-        // only samples THIS workgroup has written -- final values -- and no half-old line can be met there by the neighbour that owns its other half)
-        const unsigned s0 = run == 0 ? ((unsigned)(STEP * j0) & ~63u) : min(cover + tail_per * blockIdx.x, flen);
-        const unsigned s1 = run == 0 ? min(((unsigned)(STEP * (jend - 1) + NIN) + 63u) & ~63u, flen) : min(cover + tail_per * (blockIdx.x + 1), flen);
-        for (unsigned base = s0 + threadIdx.x * 8u; base < s1; base += 256u * 8u * 4u) {
-            v4f a[4], b[4];
+    constexpr int NC = 4;
+    for (unsigned base = s0 + threadIdx.x * 8u; base < s1; base += 256u * 8u * (unsigned)NC) {
+        v4f a[NC], b[NC];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {                       // all loads of the round first (eight 16-byte reads in flight per lane)
-                const unsigned i0 = base + (unsigned)c * (256u * 8u);
-                if (i0 + 8 <= nv && i0 < s1) {
-                    a[c] = *reinterpret_cast<const CWSLG_GLOBAL v4f *>(frame + i0);
-                    b[c] = *reinterpret_cast<const CWSLG_GLOBAL v4f *>(frame + i0 + 4);
-                } else {
-                    float v[8];
+        for (int c = 0; c < NC; ++c) {
+            const unsigned i0 = base + (unsigned)c * (256u * 8u);
+            if (i0 + 8 <= F.nv && i0 < s1) {
+                a[c] = *reinterpret_cast<const CWSLG_GLOBAL v4f *>(F.frame + i0);
+                b[c] = *reinterpret_cast<const CWSLG_GLOBAL v4f *>(F.frame + i0 + 4);
+            } else {
+                float v[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = (i0 + k < nv && i0 < s1) ? frame[i0 + k] : 0.0f;
-                    a[c] = v4f{v[0], v[1], v[2], v[3]};
-                    b[c] = v4f{v[4], v[5], v[6], v[7]};
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const unsigned i0 = base + (unsigned)c * (256u * 8u);
-                if (i0 >= s1) break;
-                const float v[8] = {a[c].x, a[c].y, a[c].z, a[c].w, b[c].x, b[c].y, b[c].z, b[c].w};
-                int q[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float scaled = v[k] * factor;                 // buf[k] *= factor
-                    const float biased = scaled + 0.5f;                 // + 0.5f
-                    q[k] = (int)biased;                                 // C truncation toward zero, then narrowed to int16
-                }
-                v4u pk;
-                pk.x = ((unsigned)q[0] & 0xFFFFu) | ((unsigned)q[1] << 16);
-                pk.y = ((unsigned)q[2] & 0xFFFFu) | ((unsigned)q[3] << 16);
-                pk.z = ((unsigned)q[4] & 0xFFFFu) | ((unsigned)q[5] << 16);
-                pk.w = ((unsigned)q[6] & 0xFFFFu) | ((unsigned)q[7] << 16);
-                const unsigned rem = s1 - i0;
-                if (rem >= 8) *reinterpret_cast<CWSLG_GLOBAL v4u *>(out + i0) = pk;
-                else for (unsigned k = 0; k < rem; ++k) out[i0 + k] = (int16_t)q[k];
+                for (int k = 0; k < 8; ++k) v[k] = (i0 + k < F.nv && i0 < s1) ? F.frame[i0 + k] : 0.0f;
+                a[c] = v4f{v[0], v[1], v[2], v[3]};
+                b[c] = v4f{v[4], v[5], v[6], v[7]};
             }
         }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const unsigned i0 = base + (unsigned)c * (256u * 8u);
+            if (i0 >= s1) break;
+            v4u pk;
+            pk.x = fin_pack2(a[c].x, a[c].y, F.factor); pk.y = fin_pack2(a[c].z, a[c].w, F.factor);
+            pk.z = fin_pack2(b[c].x, b[c].y, F.factor); pk.w = fin_pack2(b[c].z, b[c].w, F.factor);
+            *reinterpret_cast<CWSLG_GLOBAL v4u *>(F.out + i0) = pk;
+        }
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): this wave's stores have reached the L2 ...
-    __syncthreads();                                      // ... and so have every other wave's, before any window is read back
 }
 
 template <int NA, int NIN, int STEP, bool WINDOW>
@@ -652,7 +639,42 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     // workgroup does.
     const CWSLG_GLOBAL unsigned *d32 = as_global(reinterpret_cast<const unsigned *>(w->frame)) + b_;
     float *const plane = w->spectra;                      // (fetched here: behind the loop's barriers -- memory clobbers -- it was a scalar load and a wait per transform)
-    if (w->fin.frame != nullptr) spectra_finalize_span<STEP, NIN>(w->fin, j0, jend, nsteps);
+    // ---- the slot's finalise, fused (see SpectraFin above): FT8 channels whose frame this boundary has not converted yet
+    const bool fuse = !WINDOW && w->fin.frame != nullptr;                         // workgroup-uniform
+    SpectraFin F{};
+    float cv0 = 0.0f, cv1 = 0.0f;                                                  // the pair of samples this lane converts at the top of the next transform
+    constexpr int LOOK = 3;
+    // the int16 frame is final up to fin_end(j) once the conversion at the top of transform j has landed: the line-rounded end of window j + LOOK
+    auto fin_end = [&](int j) -> unsigned { return min(((unsigned)(STEP * (j + LOOK) + NIN) + 63u) & ~63u, F.s_end); };
+    if (fuse) {
+        const FinWork &f = w->fin;
+        F.frame = as_global(f.frame); F.out = as_global_rw(f.out); F.nv = f.n_valid;
+        const unsigned flen = f.frame_len;
+        const float peak = __uint_as_float(*as_global(f.peak));
+        float factor = 32767.0f / (peak + 1.0f);
+        factor = factor * f.scale;
+        F.factor = factor;
+        if (blockIdx.x == 0 && tid_ == 0) {
+            if (f.peak_next) *as_global_rw(f.peak_next) = 0u;
+            if (f.factor_out) *as_global_rw(f.factor_out) = factor;
+        }
+        F.s_end = min(((unsigned)(STEP * (jend - 1) + NIN) + 63u) & ~63u, flen);
+        spectra_finalize_range(F, (unsigned)(STEP * j0) & ~63u, fin_end(j0 - 1));    // windows j0 .. j0 + LOOK - 1
+        // the frame beyond the last window (FT8: samples 180000 .. 239999 of the 20 s frame): only as far as this slot or the previous one put
+        // non-zero samples there (FinWork::tail_end; the int16 buffer keeps its zeros otherwise) -- an even share per workgroup of the channel
+        const unsigned cover = min((unsigned)(STEP * (nsteps - 1) + NIN), flen), tail_end = min(max(f.tail_end, cover), flen);
+        if (tail_end > cover) {
+            const unsigned per = ((tail_end - cover + gridDim.x - 1) / gridDim.x + 7u) & ~7u;
+            spectra_finalize_range(F, min(cover + per * blockIdx.x, tail_end), min(cover + per * (blockIdx.x + 1), tail_end));
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): this wave's stores have reached the L2 ...
+        __syncthreads();                                  // ... and so have every other wave's, before any window is read back
+        const unsigned i = fin_end(j0 - 1) + 2u * (unsigned)tid_;                    // the pair transform j0 converts
+        if (i < fin_end(j0)) {
+            if (i + 2 <= F.nv) { const v2f p = *reinterpret_cast<const CWSLG_GLOBAL v2f *>(F.frame + i); cv0 = p.x; cv1 = p.y; }
+            else cv0 = i < F.nv ? F.frame[i] : 0.0f;
+        }
+    }
     unsigned raw[AMAX];
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) raw[a] = (128 * a + b_ < NPACK) ? d32[(STEP / 2) * j0 + 128 * a] : 0u;
@@ -752,14 +774,43 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         if (WINDOW) { lo = lo * wn[WINDOW ? a : 0].x; hi = hi * wn[WINDOW ? a : 0].y; }
         z[a] = live ? make_float2(lo, hi) : make_float2(0.f, 0.f);
     }
-    // the PREVIOUS step's power row leaves now (16 B per lane): issued ahead of the prefetch, its stores have a whole
-    // transform to retire before the top of the next iteration waits for vmcnt(0)
-    if (j > j0) {
-        CWSLG_GLOBAL v4f *out4 = reinterpret_cast<CWSLG_GLOBAL v4f *>(as_global_rw(CWSLG_SPEC_HOISTPTR ? plane : w->spectra) + (size_t)(j - 1) * nbins);
-        // by waves 2-3 only when stage 1 is the prime-factor form: their half of it is 32 instructions shorter than waves 0-1's (stamps: they
-        // waited ~430 cycles at the barrier behind stage 1)
-        if (NA == 15) { if (tid >= 128) for (int k4 = tid - 128; 4 * k4 < nbins; k4 += 128) plane_store(out4 + k4, *reinterpret_cast<const v4f *>(s_pw + 4 * k4)); }
-        else for (int k4 = tid; 4 * k4 < nbins; k4 += 256) plane_store(out4 + k4, *reinterpret_cast<const v4f *>(s_pw + 4 * k4));
+    // Memory operations of the iteration.  Order of rounds 2-5: the previous step's power row (16 B per lane) leaves first -- its stores have a whole
+    // transform to retire before the top of the next iteration waits for vmcnt(0) -- then the next window is requested.  Round 6 measured the other
+    // order (loads first, so that in principle only they are waited for; CWSLG_SPEC_LOADS_FIRST=1): hipcc still emits vmcnt(0) at the window's first
+    // use (the stores sit behind branches it cannot count), the stores are then the YOUNGEST operations it waits for, and the kernel takes 5.07
+    // against 4.53 ms (profiles/r6_sync_ab.txt).  The fused finalise's 4-byte store per lane is what costs: with it compiled out (wrong frames, timing
+    // only) the kernel runs at 4.00 ms, the float loads alone cost nothing; non-temporal stores change nothing.
+#ifndef CWSLG_SPEC_LOADS_FIRST
+#define CWSLG_SPEC_LOADS_FIRST 0
+#endif
+#ifndef CWSLG_FUSE_STORE_NT
+#define CWSLG_FUSE_STORE_NT 0
+#endif
+    auto store_prev_row = [&]() {
+        if (j > j0) {
+            CWSLG_GLOBAL v4f *out4 = reinterpret_cast<CWSLG_GLOBAL v4f *>(as_global_rw(CWSLG_SPEC_HOISTPTR ? plane : w->spectra) + (size_t)(j - 1) * nbins);
+            // by waves 2-3 only when stage 1 is the prime-factor form: their half of it is 32 instructions shorter than waves 0-1's (stamps: they
+            // waited ~430 cycles at the barrier behind stage 1)
+            if (NA == 15) { if (tid >= 128) for (int k4 = tid - 128; 4 * k4 < nbins; k4 += 128) plane_store(out4 + k4, *reinterpret_cast<const v4f *>(s_pw + 4 * k4)); }
+            else for (int k4 = tid; 4 * k4 < nbins; k4 += 256) plane_store(out4 + k4, *reinterpret_cast<const v4f *>(s_pw + 4 * k4));
+        }
+    };
+    if (!CWSLG_SPEC_LOADS_FIRST) store_prev_row();
+    unsigned fin_word = 0u, fin_at = ~0u;
+    if (fuse) {       // this transform's share of the finalise: the pair fetched during the previous transform, then the fetch of the next one
+        const unsigned e0 = fin_end(j - 1), e1 = fin_end(j), e2 = fin_end(j + 1);
+        const unsigned i = e0 + 2u * (unsigned)tid;
+        if (i < e1) { fin_word = fin_pack2(cv0, cv1, F.factor); fin_at = i; }
+        if (!CWSLG_SPEC_LOADS_FIRST && fin_at != ~0u) {
+            if (CWSLG_FUSE_STORE_NT) __builtin_nontemporal_store(fin_word, reinterpret_cast<CWSLG_GLOBAL unsigned *>(F.out + fin_at));
+            else *reinterpret_cast<CWSLG_GLOBAL unsigned *>(F.out + fin_at) = fin_word;
+        }
+        const unsigned n = e1 + 2u * (unsigned)tid;
+        cv0 = 0.0f; cv1 = 0.0f;
+        if (n < e2) {
+            if (n + 2 <= F.nv) { const v2f p = *reinterpret_cast<const CWSLG_GLOBAL v2f *>(F.frame + n); cv0 = p.x; cv1 = p.y; }
+            else cv0 = n < F.nv ? F.frame[n] : 0.0f;
+        }
     }
     {   // the next step's window, in flight during this transform.  Unconditional (the workgroup's last step fetches its own window again: eight loads per
         // jper transforms): under `if (j + 1 < jend)` the registers were a merge of two paths, which hipcc kept as two sets and eight 64-bit moves per transform
@@ -767,6 +818,10 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         if (CWSLG_SPEC_TIGHT || j + 1 < jend)
 #pragma unroll
         for (int a = 0; a < AMAX; ++a) raw[a] = (128 * a + b < NPACK) ? d32[(STEP / 2) * jn + 128 * a] : 0u;
+    }
+    if (CWSLG_SPEC_LOADS_FIRST) {
+        store_prev_row();
+        if (fuse && fin_at != ~0u) *reinterpret_cast<CWSLG_GLOBAL unsigned *>(F.out + fin_at) = fin_word;
     }
 
     // stage 1 (wave-uniform split of the outputs between waves 0-1 and waves 2-3)

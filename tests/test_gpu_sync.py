@@ -271,3 +271,45 @@ def test_candidate_order_option_and_dense_lists(ctx, oracle):
     assert {c[:2] for c in s40} != {c[:2] for c in f40}                                 # cut: different entries
     g4s, g4f = lists[("sync", 600)][1], lists[("freq", 600)][1]
     assert sorted(key(g4s)) == sorted(key(g4f)) and [c[0] for c in g4f] == sorted(c[0] for c in g4f) and len(g4f) >= 4
+
+
+def test_fused_finalise_rewrites_the_tail_only_where_needed(ctx, oracle):
+    """Round 6: for FT8 channels with the sync stage on the slot's finalise (prepareAudio + int16, Instance.cpp:294-338, 238-241) runs inside
+    symbol_spectra_v2_kernel, which converts what its windows cover (samples 0 .. 179999) and rewrites the 20 s frame's tail beyond them only
+    as far as this slot or the previous one put samples there.  A late boundary (205 000 samples: tail in use), then a short slot (the old tail
+    must become zeros again), then an ordinary one, then one without the sync stage (the stand-alone finalise takes over) and with it again:
+    every int16 frame equals the oracle's whole, zero tail included, and the lists follow."""
+    f = 10000
+    lens = [1602 * BLK, 400 * BLK, 1405 * BLK, 1300 * BLK, 1406 * BLK]              # 205 056 / 51 200 / 179 840 / 166 400 / 179 968 outputs
+    rng = np.random.default_rng(9)
+    iq = oracle.synth_iq(91, sum(lens), FS).astype(np.complex64)
+    iq = (iq + ft8_iq(FS, len(iq), f, 1500.0, 0.7, 2500.0, rng) + ft8_iq(FS, len(iq), f, 900.0, 17.5 + 4.3 + 15.0, 2000.0, rng)).astype(np.complex64)
+    ctx.enable_sync(True, 1.5, 100, 200, 3000)
+    rx = ctx.receiver_open(FS, BLK, 0)
+    ch = ctx.channel_open(rx, f, "FT8")
+    oc = oracle.Channel("FT8", FS, BLK, f)
+    ctx.slot_boundary("FT8", 10); assert oc.boundary(10) is None
+    pos = 0
+    for k, n in enumerate(lens):
+        if k == 3:
+            ctx.enable_sync(False)
+        if k == 4:
+            ctx.enable_sync(True, 1.5, 100, 200, 3000)
+        for q in range(pos, pos + n, 128 * BLK):
+            ctx.push_iq(rx, iq[q:min(q + 128 * BLK, pos + n)])
+        oc.push_many(iq[pos:pos + n]); pos += n
+        ctx.slot_boundary("FT8", 25 + 15 * k)
+        ref = oc.boundary(25 + 15 * k, want_f32=True)
+        g = ctx.fetch_frame(ch)
+        assert g["n_valid"] == n // 16
+        if ctx.mode == "exact":
+            assert np.array_equal(g["i16"], ref["i16"]), k
+        else:
+            assert np.abs(g["i16"].astype(np.int32) - ref["i16"].astype(np.int32)).max() <= 1, k
+        assert not g["i16"][g["n_valid"]:].any(), k                                 # the reference's zero tail, whatever the buffer held before
+        if k != 3:
+            got = ctx.fetch_candidates(ch, 100)
+            want = oracle.ft8_sync(g["i16"], 200, 3000, 1.5, 100)
+            assert [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in got] == [(c[0], c[1], np.float32(c[2]).view(np.uint32)) for c in want], k
+    st = ctx.stats()
+    assert st["finalize_launches"] == 2            # the discarded first boundary and the slot without the sync stage; the other four rode in the spectra kernel
