@@ -642,10 +642,10 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     // ---- the slot's finalise, fused (see SpectraFin above): FT8 channels whose frame this boundary has not converted yet
     const bool fuse = !WINDOW && w->fin.frame != nullptr;                         // workgroup-uniform
     SpectraFin F{};
-    float cv0 = 0.0f, cv1 = 0.0f;                                                  // the pair of samples this lane converts at the top of the next transform
+    v2f cv = {0.0f, 0.0f};                                                          // the pair of samples this lane converts at the top of the next transform ...
+    unsigned fin_i = ~0u;                                                           // ... and its index in the frame (>= F.s_end: none)
+    unsigned fin_lim = 0u;                                                          // min(n_valid, s_end): pairs at and beyond it are zeros, not loaded
     constexpr int LOOK = 3;
-    // the int16 frame is final up to fin_end(j) once the conversion at the top of transform j has landed: the line-rounded end of window j + LOOK
-    auto fin_end = [&](int j) -> unsigned { return min(((unsigned)(STEP * (j + LOOK) + NIN) + 63u) & ~63u, F.s_end); };
     if (fuse) {
         const FinWork &f = w->fin;
         F.frame = as_global(f.frame); F.out = as_global_rw(f.out); F.nv = f.n_valid;
@@ -659,7 +659,11 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
             if (f.factor_out) *as_global_rw(f.factor_out) = factor;
         }
         F.s_end = min(((unsigned)(STEP * (jend - 1) + NIN) + 63u) & ~63u, flen);
-        spectra_finalize_range(F, (unsigned)(STEP * j0) & ~63u, fin_end(j0 - 1));    // windows j0 .. j0 + LOOK - 1
+        // The first LOOK windows now; then 512 samples (one pair per lane) at the top of every transform: after transform j's share the frame is final up
+        // to e0 + 512 (j - j0 + 1) >= the line-rounded end of window j + LOOK (a window advances by STEP = 480 <= 512 samples).  n_valid is even (pushes
+        // are whole multiples of four blocks), so a pair never straddles it.
+        const unsigned e0 = min(((unsigned)(STEP * (j0 + LOOK - 1) + NIN) + 63u) & ~63u, F.s_end);
+        spectra_finalize_range(F, (unsigned)(STEP * j0) & ~63u, e0);
         // the frame beyond the last window (FT8: samples 180000 .. 239999 of the 20 s frame): only as far as this slot or the previous one put
         // non-zero samples there (FinWork::tail_end; the int16 buffer keeps its zeros otherwise) -- an even share per workgroup of the channel
         const unsigned cover = min((unsigned)(STEP * (nsteps - 1) + NIN), flen), tail_end = min(max(f.tail_end, cover), flen);
@@ -669,11 +673,9 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): this wave's stores have reached the L2 ...
         __syncthreads();                                  // ... and so have every other wave's, before any window is read back
-        const unsigned i = fin_end(j0 - 1) + 2u * (unsigned)tid_;                    // the pair transform j0 converts
-        if (i < fin_end(j0)) {
-            if (i + 2 <= F.nv) { const v2f p = *reinterpret_cast<const CWSLG_GLOBAL v2f *>(F.frame + i); cv0 = p.x; cv1 = p.y; }
-            else cv0 = i < F.nv ? F.frame[i] : 0.0f;
-        }
+        fin_lim = min(F.nv & ~1u, F.s_end);
+        fin_i = e0 + 2u * (unsigned)tid_;
+        if (fin_i < fin_lim) cv = *reinterpret_cast<const CWSLG_GLOBAL v2f *>(F.frame + fin_i);
     }
     unsigned raw[AMAX];
 #pragma unroll
@@ -787,7 +789,11 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
 #define CWSLG_FUSE_STORE_NT 0
 #endif
     auto store_prev_row = [&]() {
+#ifdef CWSLG_SPEC_DIAG_NOSTORE                             // timing diagnostic only (no spectra leave the kernel): what do the plane's stores cost?
+        if (j > j0 && nbins < 0) {
+#else
         if (j > j0) {
+#endif
             CWSLG_GLOBAL v4f *out4 = reinterpret_cast<CWSLG_GLOBAL v4f *>(as_global_rw(CWSLG_SPEC_HOISTPTR ? plane : w->spectra) + (size_t)(j - 1) * nbins);
             // by waves 2-3 only when stage 1 is the prime-factor form: their half of it is 32 instructions shorter than waves 0-1's (stamps: they
             // waited ~430 cycles at the barrier behind stage 1)
@@ -796,21 +802,22 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         }
     };
     if (!CWSLG_SPEC_LOADS_FIRST) store_prev_row();
-    unsigned fin_word = 0u, fin_at = ~0u;
-    if (fuse) {       // this transform's share of the finalise: the pair fetched during the previous transform, then the fetch of the next one
-        const unsigned e0 = fin_end(j - 1), e1 = fin_end(j), e2 = fin_end(j + 1);
-        const unsigned i = e0 + 2u * (unsigned)tid;
-        if (i < e1) { fin_word = fin_pack2(cv0, cv1, F.factor); fin_at = i; }
-        if (!CWSLG_SPEC_LOADS_FIRST && fin_at != ~0u) {
-            if (CWSLG_FUSE_STORE_NT) __builtin_nontemporal_store(fin_word, reinterpret_cast<CWSLG_GLOBAL unsigned *>(F.out + fin_at));
-            else *reinterpret_cast<CWSLG_GLOBAL unsigned *>(F.out + fin_at) = fin_word;
+    if (fuse) {       // this transform's share of the finalise: the pair fetched during the previous transform leaves as two int16 samples, the next one is fetched.
+        // A wave of this kernel advances at the pace of its dependent chains, ~11 cycles per instruction of ANY kind (round 4's stamps), so what this block
+        // costs is its instruction count: the first in-loop form -- three evaluations of the range ends, scalar branches, two-sample scalar arithmetic,
+        // 46 instructions per wave and transform -- cost as much as converting everything in a prologue (+0.43 ms per 4096 slots, SQ counters in
+        // profiles/r6_sync_ab.txt); this one keeps the index in a register, advances it by a constant and does the arithmetic on the pair.
+        const v2f sc = cv * F.factor;                      // buf[k] *= factor            (v_pk_mul_f32: each half rounded on its own -- the same bits)
+        const v2f bi = sc + 0.5f;                          // + 0.5f
+        const int q0 = (int)bi.x, q1 = (int)bi.y;          // C truncation toward zero, then narrowed to int16
+        const unsigned word = __builtin_amdgcn_perm((unsigned)q1, (unsigned)q0, 0x05040100u);      // (q0 & 0xFFFF) | (q1 << 16)
+        if (fin_i < F.s_end) {
+            if (CWSLG_FUSE_STORE_NT) __builtin_nontemporal_store(word, reinterpret_cast<CWSLG_GLOBAL unsigned *>(F.out + fin_i));
+            else *reinterpret_cast<CWSLG_GLOBAL unsigned *>(F.out + fin_i) = word;
         }
-        const unsigned n = e1 + 2u * (unsigned)tid;
-        cv0 = 0.0f; cv1 = 0.0f;
-        if (n < e2) {
-            if (n + 2 <= F.nv) { const v2f p = *reinterpret_cast<const CWSLG_GLOBAL v2f *>(F.frame + n); cv0 = p.x; cv1 = p.y; }
-            else cv0 = n < F.nv ? F.frame[n] : 0.0f;
-        }
+        fin_i += 512u;
+        cv = v2f{0.0f, 0.0f};
+        if (fin_i < fin_lim) cv = *reinterpret_cast<const CWSLG_GLOBAL v2f *>(F.frame + fin_i);
     }
     {   // the next step's window, in flight during this transform.  Unconditional (the workgroup's last step fetches its own window again: eight loads per
         // jper transforms): under `if (j + 1 < jend)` the registers were a merge of two paths, which hipcc kept as two sets and eight 64-bit moves per transform
@@ -819,10 +826,7 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
 #pragma unroll
         for (int a = 0; a < AMAX; ++a) raw[a] = (128 * a + b < NPACK) ? d32[(STEP / 2) * jn + 128 * a] : 0u;
     }
-    if (CWSLG_SPEC_LOADS_FIRST) {
-        store_prev_row();
-        if (fuse && fin_at != ~0u) *reinterpret_cast<CWSLG_GLOBAL unsigned *>(F.out + fin_at) = fin_word;
-    }
+    if (CWSLG_SPEC_LOADS_FIRST) store_prev_row();
 
     // stage 1 (wave-uniform split of the outputs between waves 0-1 and waves 2-3)
     if (tid < 128) spectra_stage1_regs<0, NA, AMAX>(z, s_y, tw1, b);
