@@ -446,7 +446,10 @@ def main():
         return {"bound": "valu", "kernels": kernels, "nbins_stored": nbins, "bins_searched": nsearch, "per_kernel": per_kernel,
                 "avg_ms": ms, "transforms": 372 * S, "flop_per_transform": per_transform, "flop_per_slot": per_slot,
                 "achieved_tflops": tfl, "peak_tflops": VALU_PEAK_TFLOPS, "frac": tfl / VALU_PEAK_TFLOPS,
-                "algorithmic_bytes": S * (240000 * 2 + 200 * 20), "fabric_bytes": fabric, "fabric_source": src}
+                # round 6: the stage includes the slot's finalise (symbol_spectra_v2_kernel converts the float frame itself): it reads the float frame's
+                # valid part and writes the int16 frame's (4 + 2 bytes per 12 kHz sample) instead of reading a finished int16 frame; + the lists
+                "finalize_fused": st_["finalize_launches"] == 0,
+                "algorithmic_bytes": S * ((180000 * 6 if st_["finalize_launches"] == 0 else 240000 * 2) + 200 * 20), "fabric_bytes": fabric, "fabric_source": src}
 
     def record(exact, dt_, st_, kname, ver):
         """One arithmetic mode's record: whole-job rate + the roofline object of its demod kernel."""

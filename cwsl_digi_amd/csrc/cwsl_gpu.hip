@@ -362,7 +362,10 @@ WorkBuf *acquire_workbuf(cwslg_ctx *c, size_t bytes)
         // pool stops growing after its first revolution.
         if (w.h) hipHostFree(w.h);
         if (w.d) hipFree(w.d);
-        size_t nb = std::max<size_t>(std::max(bytes, c->wb_largest), 64 << 10);
+        // (round 6: ... and never less than one descriptor of the largest kind per channel the context has -- SyncWork grew to 112 bytes with the fused
+        // finalise and would otherwise arrive, at the first emitting boundary, as a new largest request: eight regrowths, each waiting for the device)
+        static_assert(sizeof(SyncWork) <= 128 && sizeof(ChanWork) <= 128 && sizeof(FinWork) <= 128, "per-channel descriptors");
+        size_t nb = std::max<size_t>(std::max(std::max(bytes, c->wb_largest), c->chans.size() * (size_t)128), 64 << 10);
         nb = (nb + 4095) & ~size_t(4095);
         c->wb_largest = nb;
         if (hipHostMalloc(&w.h, nb, hipHostMallocDefault) != hipSuccess) return nullptr;

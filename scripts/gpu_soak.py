@@ -62,58 +62,71 @@ def main():
                 st["many_channel_iterations"] = st.get("many_channel_iterations", 0) + 1
             oc = O.Channel(mode, fs, blk, f)
             ctx.slot_boundary(mode, 10); oc.boundary(10)
-            retune_at = int(rng.integers(1, max(2, n // blk))) * blk if rng.random() < 0.25 else -1
-            f2 = int(rng.integers(-half, half - 6000))
-            pos = 0
-            while pos < n:                          # ragged multi-block pushes; sometimes SSBD::Tune in mid-slot
-                m = min(n - pos, blk * int(rng.integers(1, 60)))
-                if 0 <= retune_at - pos < m and retune_at > pos:
-                    m = retune_at - pos
-                if pos == retune_at:                # SSBD::Tune with reset = true or false (SSBD.hpp:97), sometimes flipping the sideband
-                    keep, usb2 = bool(rng.random() < 0.5), bool(rng.random() < 0.8)
-                    try:
-                        oc.tune(f2, usb2, reset=not keep)
-                    except ValueError:              # out of band for this sideband: both sides refuse and keep the old tuning
-                        try:
-                            ctx.channel_tune(ch, f2, usb2, reset=not keep)
-                            st["failures"].append(dict(tag, what="retune accepted that the reference refuses"))
-                        except P.CwslGpuError:
-                            pass
-                    else:
-                        ctx.channel_tune(ch, f2, usb2, reset=not keep)
-                    st["retunes"] += 1; st["retunes_keep"] = st.get("retunes_keep", 0) + int(keep)
-                ctx.push_iq(rx, iq[pos:pos + m]); oc.push_many(iq[pos:pos + m]); pos += m
-            ctx.slot_boundary(mode, 25)
-            ref = oc.boundary(25, want_f32=True)
-            a, nv = ctx.fetch_audio_f32(ch)
-            g = ctx.fetch_frame(ch)
-            if exact:
-                if not (np.array_equal(a.view(np.uint32), ref["f32"].view(np.uint32)) and np.array_equal(g["i16"], ref["i16"])):
-                    st["failures"].append(dict(tag, what="exact frame differs"))
-                st["exact_frames"] += 1
-            else:
-                peak = float(np.abs(ref["f32"]).max()) or 1.0
-                rel = float(np.abs(a.astype(np.float64) - ref["f32"]).max()) / peak
-                st["worst_fast_rel"] = max(st["worst_fast_rel"], rel)
-                if rel > 1e-5 or int(np.abs(g["i16"].astype(np.int32) - ref["i16"]).max()) > 1:
-                    st["failures"].append(dict(tag, what="fast frame out of tolerance", rel=rel))
-                st["fast_frames"] += 1
-            # the sync stage works on the frame the GPU produced (g), whatever the mode's arithmetic
-            if mode == "FT8":
-                got = ctx.fetch_candidates(ch)
-                want = O.ft8_sync(g["i16"], 200, f_hi, 1.5, max_cand)
-                if [tuple(x) for x in got] != [tuple(x) for x in want]:
-                    st["failures"].append(dict(tag, what="ft8 candidate list differs", n_got=len(got), n_want=len(want)))
-                st["ft8_lists"] += 1; st["candidates"] += len(want)
-            elif mode == "FT4":
-                got = ctx.fetch_candidates(ch)
-                want = O.ft4_candidates(g["i16"], 200.0, float(f_hi), 1.2, max_cand)
-                if [tuple(x) for x in got] != [tuple(x) for x in want]:
-                    st["failures"].append(dict(tag, what="ft4 candidate list differs", n_got=len(got), n_want=len(want)))
-                got4, want4 = ctx.fetch_ft4_sync(ch), O.ft4_sync_all(g["i16"], want)
-                if got4 != want4:
-                    st["failures"].append(dict(tag, what="ft4 refined records differ", n_got=len(got4 or []), n_want=len(want4)))
-                st["ft4_lists"] += 1; st["candidates"] += len(want); st["ft4_records"] += len(want4)
+            order = str(rng.choice(["sync", "sync", "freq"]))   # round 6: cwslg_set_candidate_order
+            ctx.set_candidate_order(order)
+            # round 6: one to three slots per context, of different lengths -- a short one, a late boundary (the 20 s frame's tail in use), an ordinary one --
+            # so that the fused finalise's tail bookkeeping (what the int16 buffer held before) and the epoch carried by every result are exercised
+            n_full = n
+            for slot_k in range(int(rng.choice([1, 1, 2, 3]))):
+              epoch = 25 + 15 * slot_k
+              if slot_k:
+                  n = max(blk, int(n_full * float(rng.choice([0.3, 1.0, 1.12]))) // blk * blk)
+                  iq = np.concatenate([iq, iq])[:n] if n > len(iq) else iq[:n]
+              retune_at = int(rng.integers(1, max(2, n // blk))) * blk if (rng.random() < 0.25 and slot_k == 0) else -1
+              f2 = int(rng.integers(-half, half - 6000))
+              pos = 0
+              while pos < n:                          # ragged multi-block pushes; sometimes SSBD::Tune in mid-slot
+                  m = min(n - pos, blk * int(rng.integers(1, 60)))
+                  if 0 <= retune_at - pos < m and retune_at > pos:
+                      m = retune_at - pos
+                  if pos == retune_at:                # SSBD::Tune with reset = true or false (SSBD.hpp:97), sometimes flipping the sideband
+                      keep, usb2 = bool(rng.random() < 0.5), bool(rng.random() < 0.8)
+                      try:
+                          oc.tune(f2, usb2, reset=not keep)
+                      except ValueError:              # out of band for this sideband: both sides refuse and keep the old tuning
+                          try:
+                              ctx.channel_tune(ch, f2, usb2, reset=not keep)
+                              st["failures"].append(dict(tag, what="retune accepted that the reference refuses"))
+                          except P.CwslGpuError:
+                              pass
+                      else:
+                          ctx.channel_tune(ch, f2, usb2, reset=not keep)
+                      st["retunes"] += 1; st["retunes_keep"] = st.get("retunes_keep", 0) + int(keep)
+                  ctx.push_iq(rx, iq[pos:pos + m]); oc.push_many(iq[pos:pos + m]); pos += m
+              ctx.slot_boundary(mode, epoch)
+              ref = oc.boundary(epoch, want_f32=True)
+              a, nv = ctx.fetch_audio_f32(ch)
+              g = ctx.fetch_frame(ch)
+              if exact:
+                  if not (np.array_equal(a.view(np.uint32), ref["f32"].view(np.uint32)) and np.array_equal(g["i16"], ref["i16"])):
+                      st["failures"].append(dict(tag, what="exact frame differs"))
+                  st["exact_frames"] += 1
+              else:
+                  peak = float(np.abs(ref["f32"]).max()) or 1.0
+                  rel = float(np.abs(a.astype(np.float64) - ref["f32"]).max()) / peak
+                  st["worst_fast_rel"] = max(st["worst_fast_rel"], rel)
+                  if rel > 1e-5 or int(np.abs(g["i16"].astype(np.int32) - ref["i16"]).max()) > 1:
+                      st["failures"].append(dict(tag, what="fast frame out of tolerance", rel=rel))
+                  st["fast_frames"] += 1
+              # the sync stage works on the frame the GPU produced (g), whatever the mode's arithmetic
+              if mode == "FT8":
+                  got, t_list = ctx.fetch_candidates(ch, with_epoch=True)
+                  sl = ctx.fetch_slot(ch, max_list=max_cand)
+                  if t_list != g["t_start"] or sl["t_start"] != g["t_start"] or sl["list_kind"] != "FT8" or sl["list"] != got or not np.array_equal(sl["i16"], g["i16"]):
+                      st["failures"].append(dict(tag, what="fetch_slot / epoch inconsistent", slot=slot_k))
+                  want = O.ft8_sync(g["i16"], 200, f_hi, 1.5, max_cand, order=order)
+                  if [tuple(x) for x in got] != [tuple(x) for x in want]:
+                      st["failures"].append(dict(tag, what="ft8 candidate list differs", n_got=len(got), n_want=len(want)))
+                  st["ft8_lists"] += 1; st["candidates"] += len(want)
+              elif mode == "FT4":
+                  got = ctx.fetch_candidates(ch)
+                  want = O.ft4_candidates(g["i16"], 200.0, float(f_hi), 1.2, max_cand, order=order)
+                  if [tuple(x) for x in got] != [tuple(x) for x in want]:
+                      st["failures"].append(dict(tag, what="ft4 candidate list differs", n_got=len(got), n_want=len(want)))
+                  got4, want4 = ctx.fetch_ft4_sync(ch), O.ft4_sync_all(g["i16"], want)
+                  if got4 != want4:
+                      st["failures"].append(dict(tag, what="ft4 refined records differ", n_got=len(got4 or []), n_want=len(want4)))
+                  st["ft4_lists"] += 1; st["candidates"] += len(want); st["ft4_records"] += len(want4)
         finally:
             ctx.close()
         st["iterations"] += 1
