@@ -277,6 +277,10 @@ struct cwslg_ctx {
 #ifndef CWSLG_FUSE_FIN_DEFAULT
 #define CWSLG_FUSE_FIN_DEFAULT 1       // (-DCWSLG_FUSE_FIN_DEFAULT=0: a measurement build with round 5's separate finalise pass, scripts/gpu_r6_sync_ab.sh)
 #endif
+#ifndef CWSLG_FUSE_MODE_DEFAULT
+#define CWSLG_FUSE_MODE_DEFAULT 1      // 1: the windows are read back from the int16 frame through the cache (product); 2 (lab library only): from an LDS ring
+#endif
+    int fuse_mode = CWSLG_FUSE_MODE_DEFAULT;
     bool fuse_finalize = CWSLG_FUSE_FIN_DEFAULT != 0;         // FT8 + sync: the slot's finalise inside symbol_spectra_v2_kernel (lab build: CWSLG_FUSE_FIN=0 keeps the separate pass, for A/B)
     int process_min_outputs = 0;       // cwslg_set_process_threshold: 0 every cwslg_process() launches, < 0 the library's own threshold, > 0 that many outputs
     bool use_exact5 = true;            // exact mode: demod_exact5_kernel<D> (lab build: a non-zero CWSLG_DEMOD_VARIANT selects round 3/4's tile kernels instead)
@@ -1178,6 +1182,7 @@ int cwslg_create(cwslg_ctx **out, int device_ordinal)
     if (const char *v = std::getenv("CWSLG_LONG_VARIANT")) c->long_variant = std::atoi(v);
     if (const char *v = std::getenv("CWSLG_COPY_ON_MAIN")) c->copy_on_main = std::atoi(v) != 0;
     if (const char *v = std::getenv("CWSLG_FUSE_FIN")) c->fuse_finalize = std::atoi(v) != 0;
+    if (const char *v = std::getenv("CWSLG_FUSE_MODE")) c->fuse_mode = std::atoi(v) == 2 ? 2 : 1;
 #endif
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return CWSLG_ERR_HIP;
     for (int k = 0; k < kCopyStreams; ++k) {

@@ -611,9 +611,12 @@ __device__ __forceinline__ void spectra_finalize_range(const SpectraFin &F, unsi
     }
 }
 
-template <int NA, int NIN, int STEP, bool WINDOW>
+// FMODE: 0 = the int16 frame exists (FT4; FT8 behind a separate finalize_kernel: lab / A-B builds); 1 = fused finalise, windows read back from the int16
+// frame through the cache (this round's first product form); 2 = fused finalise, windows from an LDS ring (see below).
+template <int NA, int NIN, int STEP, bool WINDOW, int FMODE = 0>
 __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kernel(const SyncWork *__restrict__ works, SyncTables tb, int nbins, int nsteps, int jper)
 {
+    static_assert(FMODE == 0 || (!WINDOW && NIN == 4 * STEP && STEP == 480), "the fused forms are FT8's");
     constexpr int NZ = NA * 128;
     constexpr int NPACK = NIN / 2;
     constexpr int NGRP = NA * 16;
@@ -624,6 +627,14 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     __shared__ __attribute__((aligned(16))) float s_pw[NIN + 32];     // one power row: nbins <= NIN + 32 (FT8: the widest search stores 1952)
     __shared__ float2 s_y[NA][SY_PITCH];
     __shared__ float2 s_w128[64];
+    // FMODE 2 (measured alternative, lab library): the int16 window as an LDS ring of sample PAIRS (one dword = two int16 samples, the unit stage 1 reads):
+    // RING = a window (960 pairs) + one step (240 pairs), every pair stored twice, RING apart, so that a lane's eight reads base + 128 a need no wrap.  The
+    // workgroup converts 480 samples per transform (lanes 0..239, one pair each) into the ring AND into the int16 frame in HBM -- which the kernel then never
+    // reads.  The idea: the frame's stores cost 0.5 ms per 1.5 GB when the same CU reads them back two transforms later, the plane's write-only 6 GB cost
+    // 0.17 ms.  The result: 5.2 against 4.5 ms (profiles/r6_sync_ab.txt) -- eight LDS reads at the head of every transform's dependent chain, with nothing
+    // to hide them behind (prefetching them into registers needs the eight VGPRs the kernel does not have), cost more than the stores they make cheap.
+    constexpr int RING = NPACK + STEP / 2;                 // 1200 pairs
+    __shared__ unsigned s_ring[FMODE == 2 ? 2 * RING : 1];
     const SyncWork *w = works + blockIdx.y;
     const int j0 = blockIdx.x * jper;
     const int jend = min(j0 + jper, nsteps);
@@ -640,12 +651,13 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     const CWSLG_GLOBAL unsigned *d32 = as_global(reinterpret_cast<const unsigned *>(w->frame)) + b_;
     float *const plane = w->spectra;                      // (fetched here: behind the loop's barriers -- memory clobbers -- it was a scalar load and a wait per transform)
     // ---- the slot's finalise, fused (see SpectraFin above): FT8 channels whose frame this boundary has not converted yet
-    const bool fuse = !WINDOW && w->fin.frame != nullptr;                         // workgroup-uniform
+    const bool fuse = FMODE != 0;                                                   // (the host picks the instantiation: every channel of a launch is fused or none is)
     SpectraFin F{};
     v2f cv = {0.0f, 0.0f};                                                          // the pair of samples this lane converts at the top of the next transform ...
     unsigned fin_i = ~0u;                                                           // ... and its index in the frame (>= F.s_end: none)
     unsigned fin_lim = 0u;                                                          // min(n_valid, s_end): pairs at and beyond it are zeros, not loaded
     constexpr int LOOK = 3;
+    unsigned ring_rd = 0u, ring_wr = 0u;                                            // FMODE 2: this lane's read base / write position in the ring (pairs)
     if (fuse) {
         const FinWork &f = w->fin;
         F.frame = as_global(f.frame); F.out = as_global_rw(f.out); F.nv = f.n_valid;
@@ -658,12 +670,6 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
             if (f.peak_next) *as_global_rw(f.peak_next) = 0u;
             if (f.factor_out) *as_global_rw(f.factor_out) = factor;
         }
-        F.s_end = min(((unsigned)(STEP * (jend - 1) + NIN) + 63u) & ~63u, flen);
-        // The first LOOK windows now; then 512 samples (one pair per lane) at the top of every transform: after transform j's share the frame is final up
-        // to e0 + 512 (j - j0 + 1) >= the line-rounded end of window j + LOOK (a window advances by STEP = 480 <= 512 samples).  n_valid is even (pushes
-        // are whole multiples of four blocks), so a pair never straddles it.
-        const unsigned e0 = min(((unsigned)(STEP * (j0 + LOOK - 1) + NIN) + 63u) & ~63u, F.s_end);
-        spectra_finalize_range(F, (unsigned)(STEP * j0) & ~63u, e0);
         // the frame beyond the last window (FT8: samples 180000 .. 239999 of the 20 s frame): only as far as this slot or the previous one put
         // non-zero samples there (FinWork::tail_end; the int16 buffer keeps its zeros otherwise) -- an even share per workgroup of the channel
         const unsigned cover = min((unsigned)(STEP * (nsteps - 1) + NIN), flen), tail_end = min(max(f.tail_end, cover), flen);
@@ -671,15 +677,45 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
             const unsigned per = ((tail_end - cover + gridDim.x - 1) / gridDim.x + 7u) & ~7u;
             spectra_finalize_range(F, min(cover + per * blockIdx.x, tail_end), min(cover + per * (blockIdx.x + 1), tail_end));
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): this wave's stores have reached the L2 ...
-        __syncthreads();                                  // ... and so have every other wave's, before any window is read back
-        fin_lim = min(F.nv & ~1u, F.s_end);
-        fin_i = e0 + 2u * (unsigned)tid_;
+        if constexpr (FMODE == 1) {
+            F.s_end = min(((unsigned)(STEP * (jend - 1) + NIN) + 63u) & ~63u, flen);
+            // The first LOOK windows now; then 512 samples (one pair per lane) at the top of every transform: after transform j's share the frame is final up
+            // to e0 + 512 (j - j0 + 1) >= the line-rounded end of window j + LOOK (a window advances by STEP = 480 <= 512 samples).  n_valid is even (pushes
+            // are whole multiples of four blocks), so a pair never straddles it.
+            const unsigned e0 = min(((unsigned)(STEP * (j0 + LOOK - 1) + NIN) + 63u) & ~63u, F.s_end);
+            spectra_finalize_range(F, (unsigned)(STEP * j0) & ~63u, e0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): this wave's stores have reached the L2 ...
+            __syncthreads();                                  // ... and so have every other wave's, before any window is read back
+            fin_lim = min(F.nv & ~1u, F.s_end);
+            fin_i = e0 + 2u * (unsigned)tid_;
+        } else {
+            // FMODE 2: window j0 goes into the ring (and the frame) now, 960 pairs by 256 lanes; then lanes 0..239 add the 240 pairs of the next window's last
+            // step at the top of every transform
+            F.s_end = min((unsigned)(STEP * (jend - 1) + NIN), flen);
+            fin_lim = min(F.nv & ~1u, F.s_end);
+            const unsigned p0 = (unsigned)(STEP / 2) * (unsigned)j0;               // first pair of window j0
+            for (unsigned k = (unsigned)tid_; k < (unsigned)NPACK; k += 256u) {
+                const unsigned i = 2u * (p0 + k);
+                v2f p = {0.0f, 0.0f};
+                if (i < fin_lim) p = *reinterpret_cast<const CWSLG_GLOBAL v2f *>(F.frame + i);
+                const v2f bi = p * F.factor + 0.5f;
+                const unsigned word = __builtin_amdgcn_perm((unsigned)(int)bi.y, (unsigned)(int)bi.x, 0x05040100u);
+                if (i < F.s_end) *reinterpret_cast<CWSLG_GLOBAL unsigned *>(F.out + i) = word;
+                const unsigned pos = (p0 + k) % (unsigned)RING;
+                s_ring[pos] = word; s_ring[pos + RING] = word;
+            }
+            __syncthreads();
+            fin_i = tid_ < STEP / 2 ? (unsigned)(STEP * j0 + NIN) + 2u * (unsigned)tid_ : 0x40000000u;      // the pair transform j0 converts (lanes 240..255: none, ever)
+            ring_rd = (p0 + (unsigned)b_) % (unsigned)RING;
+            ring_wr = (p0 + (unsigned)NPACK + (unsigned)tid_) % (unsigned)RING;
+        }
         if (fin_i < fin_lim) cv = *reinterpret_cast<const CWSLG_GLOBAL v2f *>(F.frame + fin_i);
     }
     unsigned raw[AMAX];
+    if constexpr (FMODE != 2) {
 #pragma unroll
-    for (int a = 0; a < AMAX; ++a) raw[a] = (128 * a + b_ < NPACK) ? d32[(STEP / 2) * j0 + 128 * a] : 0u;
+        for (int a = 0; a < AMAX; ++a) raw[a] = (128 * a + b_ < NPACK) ? d32[(STEP / 2) * j0 + 128 * a] : 0u;
+    }
     float2 wn[WINDOW ? AMAX : 1];
     if (WINDOW) {
 #pragma unroll
@@ -767,6 +803,11 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     const char *const w128_bytes = reinterpret_cast<const char *>(&s_w128[0]);
     char *const pw_bytes = reinterpret_cast<char *>(&s_pw[0]);
     PSTAMP(0);
+    if constexpr (FMODE == 2) {      // window j from the ring: pairs ring_rd + 128 a (the second copy makes the run contiguous)
+        const unsigned *const rp = s_ring + ring_rd;
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) raw[a] = rp[128 * a];
+    }
     float2 z[AMAX];
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) {
@@ -814,17 +855,26 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         if (fin_i < F.s_end) {
             if (CWSLG_FUSE_STORE_NT) __builtin_nontemporal_store(word, reinterpret_cast<CWSLG_GLOBAL unsigned *>(F.out + fin_i));
             else *reinterpret_cast<CWSLG_GLOBAL unsigned *>(F.out + fin_i) = word;
+            if constexpr (FMODE == 2) { s_ring[ring_wr] = word; s_ring[ring_wr + RING] = word; }       // the last step of window j + 1 (read at the top of j + 1, behind this transform's barriers)
         }
-        fin_i += 512u;
+        if constexpr (FMODE == 2) {
+            fin_i += (unsigned)STEP;
+            ring_wr += (unsigned)(STEP / 2); if (ring_wr >= (unsigned)RING) ring_wr -= (unsigned)RING;
+            ring_rd += (unsigned)(STEP / 2); if (ring_rd >= (unsigned)RING) ring_rd -= (unsigned)RING;
+        } else {
+            fin_i += 512u;
+        }
         cv = v2f{0.0f, 0.0f};
         if (fin_i < fin_lim) cv = *reinterpret_cast<const CWSLG_GLOBAL v2f *>(F.frame + fin_i);
     }
     {   // the next step's window, in flight during this transform.  Unconditional (the workgroup's last step fetches its own window again: eight loads per
         // jper transforms): under `if (j + 1 < jend)` the registers were a merge of two paths, which hipcc kept as two sets and eight 64-bit moves per transform
         const int jn = CWSLG_SPEC_TIGHT ? min(j + 1, jend - 1) : j + 1;
+        if constexpr (FMODE != 2) {
         if (CWSLG_SPEC_TIGHT || j + 1 < jend)
 #pragma unroll
         for (int a = 0; a < AMAX; ++a) raw[a] = (128 * a + b < NPACK) ? d32[(STEP / 2) * jn + 128 * a] : 0u;
+        }
     }
     if (CWSLG_SPEC_LOADS_FIRST) store_prev_row();
 
