@@ -67,6 +67,10 @@ int main(int argc, char **argv)
         if (sink.collect() != 1 || sink.collect() != 0) return 11;     // delivered once
         if (delivered != 1 || sink_t0 != t0 || sink_crc != crc32(audio.data(), audio.size() * 2) || sink_tr != 15.0f || sink_id != 3 ||
             sink_f != 28074000 || sink_mode != "FT8" || sink_cwd != "/tmp/cwd3") return 12;
+        {   // ABI 5: the slot's results under one ticket -- the same frame and epoch; no list (the sync stage is off on this context)
+            std::vector<std::int16_t> audio3; std::vector<cwslg_candidate> cands3; std::uint64_t t3 = 0;
+            if (!chan.fetchSlot(audio3, t3, cands3) || t3 != t0 || audio3 != audio || !cands3.empty()) return 14;
+        }
         std::vector<cwslg_candidate> cands; std::vector<cwslg_ft4_sync> recs;
         bool cand_threw = false;                       // sync stage not enabled on this context: the C ABI reports it, the shim throws
         try { chan.candidates(cands); } catch (const std::exception &) { cand_threw = true; }

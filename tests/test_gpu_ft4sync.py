@@ -61,6 +61,10 @@ def test_candidate_baseband_and_records_bit_identical(ctx, oracle):
     assert len(got) == len(want) and len(want) >= 3
     for g, w in zip(got, want):
         assert g == w, (g, w)
+    # ABI 5: the same slot in one call -- frame, list and refinements of one epoch under one ticket
+    sl = ctx.fetch_slot(ch, max_list=100)
+    assert sl["t_start"] == 10 and sl["list_kind"] == "FT4" and np.array_equal(sl["i16"], fr)
+    assert [tuple(c) for c in sl["list"]] == [tuple(c) for c in cands] and sl["ft4_sync"] == got
     # and the refinement means something: each burst is found at its start time and frequency
     for audio_hz, t0, _ in bursts:
         near = [h for h in got if abs(h["f1_hz"] - audio_hz) <= 2.0 and abs(h["ibest"] / 666.67 - t0) <= 0.006]

@@ -42,7 +42,9 @@ def long_frames(oracle):
             wspr_frame=ctx.fetch_frame(cw)["i16"].copy(), fst_frame=ctx.fetch_frame(cf)["i16"].copy(),
             wspr_cands=ctx.fetch_wspr_candidates(cw), fst_cands=ctx.fetch_fst4w_candidates(cf),
             iq=ctx.long_sync_debug(cw, "iq"), ps=ctx.long_sync_debug(cw, "ps"), smspec=ctx.long_sync_debug(cw, "smspec"),
-            s2=ctx.long_sync_debug(cf, "s2"), band=ctx.long_sync_debug(cf, "band"))
+            s2=ctx.long_sync_debug(cf, "s2"), band=ctx.long_sync_debug(cf, "band"),
+            wspr_slot=ctx.fetch_slot(cw), fst_slot=ctx.fetch_slot(cf),
+            wspr_epoch=ctx.fetch_wspr_candidates(cw, with_epoch=True)[1], fst_epoch=ctx.fetch_fst4w_candidates(cf, with_epoch=True)[1])
         with pytest.raises(P.CwslGpuError):
             ctx.fetch_fst4w_candidates(cw)                               # a WSPR channel has no FST4W list
     return out
@@ -80,6 +82,19 @@ def test_fst4w_stages_and_candidates_bit_exact(oracle, long_frames):
     baud = 12000.0 / 8200.0
     assert abs(got[0][0] - (1500.0 + 1.5 * baud)) <= baud
     assert any(abs(c[0] - (1451.0 + 1.5 * baud)) <= baud for c in got[:5])
+
+
+def test_fetch_slot_carries_the_long_modes_lists(long_frames):
+    """ABI 5: cwslg_fetch_slot on WSPR / FST4W-120 channels -- the frame, its start epoch and the list in the channel's own record type, under one
+    ticket; the list fetches name the same epoch."""
+    g = long_frames
+    for slot, frame, cands, kind, epoch in ((g["wspr_slot"], g["wspr_frame"], g["wspr_cands"], "WSPR", g["wspr_epoch"]),
+                                            (g["fst_slot"], g["fst_frame"], g["fst_cands"], "FST4W", g["fst_epoch"])):
+        assert slot["t_start"] == 120 == epoch and slot["list_kind"] == kind and slot["n_valid"] == N // 16
+        assert np.array_equal(slot["i16"], frame)
+        assert [tuple(np.float32(x).view(np.uint32) if isinstance(x, float) else x for x in c) for c in slot["list"]] == \
+               [tuple(np.float32(x).view(np.uint32) if isinstance(x, float) else x for x in c) for c in cands]
+        assert len(cands) >= 2 and slot["ft4_sync"] == []
 
 
 def test_short_slot_zero_tail(oracle):
