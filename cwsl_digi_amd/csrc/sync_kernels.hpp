@@ -742,11 +742,16 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     // opaque copy below keeps everything else out of registers, but these are worth theirs -- recomputed per transform they were
     // ~90 of a wave's ~610 VALU instructions (swizzle, row pitch products, shifts).
     float2 w3[IPT][2];
-    unsigned au1[IPT], au2[IPT], aw1[IPT], aw2[IPT], ap1[IPT], ap2[IPT];   // ap1 of item 0 carries the kind in bits 16-17 (sparse mode)
-    bool iskip[IPT], izero[IPT];
+    // CWSLG_SPEC_UNHOIST=1 (measured alternative, round 6): the addresses are recomputed in every transform from the opaque thread index instead of being held
+    // in 20 registers across the loop -- the route to a fifth wave per SIMD that needs no hand-written transform (with -DCWSLG_SPEC_WAVES=5)
+#ifndef CWSLG_SPEC_UNHOIST
+#define CWSLG_SPEC_UNHOIST 0
+#endif
+    struct ItemAddr { unsigned au1[IPT], au2[IPT], aw1[IPT], aw2[IPT], ap1[IPT], ap2[IPT], aB[8]; bool iskip[IPT], izero[IPT]; };
+    auto item_addr = [&](int tidx, ItemAddr &A, int (&K1o)[IPT], int (&K2o)[IPT]) {
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
-        const int it = tid_ + 256 * i;
+        const int it = tidx + 256 * i;
         int r = it >> 6, q = it & 63, kind = 0;
         bool skip = it >= NITEM || (r == 0 && q > 32);
         int Kup = 0;
@@ -759,31 +764,40 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         }
         const int r2 = (r == 0) ? 0 : NA - r;
         const int k2 = (r == 0) ? ((64 - q) & 63) : 63 - q;
-        izero[i] = r == 0 && q == 0 && kind == 0;
-        if (sparse && izero[i]) kind = 1;
-        iskip[i] = skip;
+        A.izero[i] = r == 0 && q == 0 && kind == 0;
+        if (sparse && A.izero[i]) kind = 1;
+        A.iskip[i] = skip;
         const int rr = skip ? 0 : r, rr2 = skip ? 0 : r2;
         // the partner column k + 64 is not kept: sy_col(k + 64) = 64 + (sy_col(k) ^ 8) for k < 64, and a row starts at a multiple of 128 bytes,
         // so its byte address is (address of column k ^ 64) + 512 -- one XOR at the point of use, the 512 rides in the instruction's offset field
         static_assert((SY_PITCH * 8) % 128 == 0, "row pitch");
-        au1[i] = 8u * (unsigned)(rr * SY_PITCH + sy_col(q));
-        au2[i] = 8u * (unsigned)(rr2 * SY_PITCH + sy_col(k2));
-        aw1[i] = 8u * (unsigned)q; aw2[i] = 8u * (unsigned)k2;
+        A.au1[i] = 8u * (unsigned)(rr * SY_PITCH + sy_col(q));
+        A.au2[i] = 8u * (unsigned)(rr2 * SY_PITCH + sy_col(k2));
+        A.aw1[i] = 8u * (unsigned)q; A.aw2[i] = 8u * (unsigned)k2;
         int K1 = NA * q + r, K2 = NA * k2 + r2;            // the bins of a plain item
         unsigned p1 = 4u * (unsigned)K1, p2 = 4u * (unsigned)K2;
         if (kind == 1) { K2 = NA * 64; p2 = (K2 < nbins) ? 4u * (unsigned)K2 : PW_DUMMY; }        // bins 0 and NA * 64, each paired with itself
         if (kind >= 2) { K1 = Kup; p1 = 4u * (unsigned)Kup; K2 = nbins; p2 = PW_DUMMY; }          // one bin; the second unpack lands in the dummy
-        ap1[i] = p1 | ((unsigned)kind << 16); ap2[i] = p2;
-        w3[i][0] = (!skip && K1 < nbins) ? tb.w3840[K1] : make_float2(0.f, 0.f);
-        w3[i][1] = (!skip && K2 < nbins) ? tb.w3840[K2] : make_float2(0.f, 0.f);
+        A.ap1[i] = p1 | ((unsigned)kind << 16); A.ap2[i] = p2;
+        K1o[i] = (!skip && K1 < nbins) ? K1 : -1; K2o[i] = (!skip && K2 < nbins) ? K2 : -1;
+    }
+    {
+        const int c = tidx >> 4, g = tidx & 15, blk = g >> 3, r = g & 7;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) A.aB[q] = 8u * (unsigned)((tidx < NGRP ? c : 0) * SY_PITCH + sy_col(64 * blk + r + 8 * q));
+    }
+    };
+    ItemAddr IA0;
+    {
+        int K1o[IPT], K2o[IPT];
+        item_addr(tid_, IA0, K1o, K2o);
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            w3[i][0] = K1o[i] >= 0 ? tb.w3840[K1o[i]] : make_float2(0.f, 0.f);
+            w3[i][1] = K2o[i] >= 0 ? tb.w3840[K2o[i]] : make_float2(0.f, 0.f);
+        }
     }
     const bool wave0_ = __builtin_amdgcn_readfirstlane(tid_ >> 6) == 0;
-    unsigned aB[8];
-    {
-        const int c = tid_ >> 4, g = tid_ & 15, blk = g >> 3, r = g & 7;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) aB[q] = 8u * (unsigned)((tid_ < NGRP ? c : 0) * SY_PITCH + sy_col(64 * blk + r + 8 * q));
-    }
     // (the twiddles of the two self-paired bins 0 and NA * 64 are per-lane registers like every other item's -- w3[0][] of lane 0: fetched inside
     // the loop, as in round 3, they were a global load on wave 0's path in EVERY transform whose vmcnt wait also drained the prefetched window:
     // ~550 cycles that the other three waves then spent at the barrier; s_memtime stamps, scripts/gpu_stamps_spectra.py)
@@ -799,6 +813,10 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     int t = tid_;
     asm volatile("" : "+v"(t));
     const int tid = t, b = t & 127;
+    ItemAddr IAj;
+    int k1j[IPT], k2j[IPT];
+    if (CWSLG_SPEC_UNHOIST) item_addr(tid, IAj, k1j, k2j);
+    const ItemAddr &IA = CWSLG_SPEC_UNHOIST ? IAj : IA0;
     char *const sy_bytes = reinterpret_cast<char *>(&s_y[0][0]);
     const char *const w128_bytes = reinterpret_cast<const char *>(&s_w128[0]);
     char *const pw_bytes = reinterpret_cast<char *>(&s_pw[0]);
@@ -927,7 +945,7 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         const int r = tid & 7;
         float2 e[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) e[q] = *reinterpret_cast<const float2 *>(sy_bytes + aB[q]);
+        for (int q = 0; q < 8; ++q) e[q] = *reinterpret_cast<const float2 *>(sy_bytes + IA.aB[q]);
         {
             const float2 w0 = s_w128[r * 8];
             bfly(e[0], e[1], w0); bfly(e[2], e[3], w0); bfly(e[4], e[5], w0); bfly(e[6], e[7], w0);
@@ -941,23 +959,32 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
             bfly(e[2], e[6], s_w128[(r + 16) * 2]); bfly(e[3], e[7], s_w128[(r + 24) * 2]);
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) *reinterpret_cast<float2 *>(sy_bytes + aB[q]) = e[q];
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<float2 *>(sy_bytes + IA.aB[q]) = e[q];
     }
     PSTAMP(4);
     lds_barrier();
     PSTAMP(5);
 
     // last stage (len = 128) fused with the unpack: see the header of this kernel
+    float2 w3j[IPT][2];
+    if (CWSLG_SPEC_UNHOIST) {        // the unpack twiddles fetched per transform (L1 / L2 hits; the window prefetch issued at the top of the transform has long landed)
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            w3j[i][0] = k1j[i] >= 0 ? tb.w3840[k1j[i]] : make_float2(0.f, 0.f);
+            w3j[i][1] = k2j[i] >= 0 ? tb.w3840[k2j[i]] : make_float2(0.f, 0.f);
+        }
+    }
+    const float2 (&w3u)[IPT][2] = CWSLG_SPEC_UNHOIST ? w3j : w3;
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
-        if (iskip[i]) continue;
-        float2 u1 = *reinterpret_cast<const float2 *>(sy_bytes + au1[i]), v1 = *reinterpret_cast<const float2 *>(sy_bytes + (au1[i] ^ 64u) + 512);
-        float2 u2 = *reinterpret_cast<const float2 *>(sy_bytes + au2[i]), v2 = *reinterpret_cast<const float2 *>(sy_bytes + (au2[i] ^ 64u) + 512);
-        bfly(u1, v1, *reinterpret_cast<const float2 *>(w128_bytes + aw1[i]));
-        bfly(u2, v2, *reinterpret_cast<const float2 *>(w128_bytes + aw2[i]));
+        if (IA.iskip[i]) continue;
+        float2 u1 = *reinterpret_cast<const float2 *>(sy_bytes + IA.au1[i]), v1 = *reinterpret_cast<const float2 *>(sy_bytes + (IA.au1[i] ^ 64u) + 512);
+        float2 u2 = *reinterpret_cast<const float2 *>(sy_bytes + IA.au2[i]), v2 = *reinterpret_cast<const float2 *>(sy_bytes + (IA.au2[i] ^ 64u) + 512);
+        bfly(u1, v1, *reinterpret_cast<const float2 *>(w128_bytes + IA.aw1[i]));
+        bfly(u2, v2, *reinterpret_cast<const float2 *>(w128_bytes + IA.aw2[i]));
         if (sparse) {
             float2 A1 = u1, B1 = v2, A2 = u2;
-            unsigned p1 = ap1[i];
+            unsigned p1 = IA.ap1[i];
             if (i == 0 && wave0_) {                        // wave-uniform: row 0's lanes -- plain items, the self-paired pair, the bins above NA * 64
                 const unsigned kind = p1 >> 16;
                 p1 &= 0xFFFFu;
@@ -965,20 +992,20 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
                 B1 = (kind == 0) ? v2 : (kind == 2) ? u2 : u1;
                 A2 = (kind == 1) ? v1 : u2;
             }
-            *reinterpret_cast<float *>(pw_bytes + p1) = unpack_power(A1, B1, w3[i][0]);
-            *reinterpret_cast<float *>(pw_bytes + ap2[i]) = unpack_power(A2, v1, w3[i][1]);
+            *reinterpret_cast<float *>(pw_bytes + p1) = unpack_power(A1, B1, w3u[i][0]);
+            *reinterpret_cast<float *>(pw_bytes + IA.ap2[i]) = unpack_power(A2, v1, w3u[i][1]);
             continue;
         }
-        if (izero[i]) {                                     // Z[0] and Z[NZ/2] pair with themselves
-            s_pw[0] = unpack_power(u1, u1, w3[i][0]);
+        if (IA.izero[i]) {                                     // Z[0] and Z[NZ/2] pair with themselves
+            s_pw[0] = unpack_power(u1, u1, w3u[i][0]);
             if (NA * 64 < nbins) s_pw[NA * 64] = unpack_power(v1, v1, tb.w3840[NA * 64]);
             if (NZ < nbins) s_pw[NZ] = unpack_power(u1, u1, tb.w3840[NZ]);
             continue;
         }
-        const int K1 = (int)(ap1[i] >> 2), K2 = (int)(ap2[i] >> 2);
+        const int K1 = (int)(IA.ap1[i] >> 2), K2 = (int)(IA.ap2[i] >> 2);
         const int K3 = K1 + NA * 64, K4 = K2 + NA * 64;
-        if (K1 < nbins) s_pw[K1] = unpack_power(u1, v2, w3[i][0]);
-        if (K2 < nbins) s_pw[K2] = unpack_power(u2, v1, w3[i][1]);
+        if (K1 < nbins) s_pw[K1] = unpack_power(u1, v2, w3u[i][0]);
+        if (K2 < nbins) s_pw[K2] = unpack_power(u2, v1, w3u[i][1]);
         if (K3 < nbins) s_pw[K3] = unpack_power(v1, u2, tb.w3840[K3]);
         if (K4 < nbins) s_pw[K4] = unpack_power(v2, u1, tb.w3840[K4]);
     }
