@@ -856,11 +856,8 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
             CWSLG_GLOBAL v4f *out4 = reinterpret_cast<CWSLG_GLOBAL v4f *>(as_global_rw(CWSLG_SPEC_HOISTPTR ? plane : w->spectra) + (size_t)(j - 1) * nbins);
             // by waves 2-3 only when stage 1 is the prime-factor form: their half of it is 32 instructions shorter than waves 0-1's (stamps: they
             // waited ~430 cycles at the barrier behind stage 1)
-#ifndef CWSLG_SPEC_ROWSPLIT
-#define CWSLG_SPEC_ROWSPLIT 0          // 1 (measured alternative, round 6): the row's second 128 float4 leave from waves 0-1 instead of a second pass of waves 2-3
-#endif
-            if (NA == 15 && CWSLG_SPEC_ROWSPLIT) { const int k4 = tid >= 128 ? tid - 128 : tid + 128; if (4 * k4 < nbins) plane_store(out4 + k4, *reinterpret_cast<const v4f *>(s_pw + 4 * k4)); }
-            else if (NA == 15) { if (tid >= 128) for (int k4 = tid - 128; 4 * k4 < nbins; k4 += 128) plane_store(out4 + k4, *reinterpret_cast<const v4f *>(s_pw + 4 * k4)); }
+            // (round 6: the row's second 120 float4 from waves 0-1 instead of a second pass of waves 2-3 -- 4.50-4.53 against 4.48-4.51 ms: no gain)
+            if (NA == 15) { if (tid >= 128) for (int k4 = tid - 128; 4 * k4 < nbins; k4 += 128) plane_store(out4 + k4, *reinterpret_cast<const v4f *>(s_pw + 4 * k4)); }
             else for (int k4 = tid; 4 * k4 < nbins; k4 += 256) plane_store(out4 + k4, *reinterpret_cast<const v4f *>(s_pw + 4 * k4));
         }
     };
