@@ -864,9 +864,11 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     if (!CWSLG_SPEC_LOADS_FIRST) store_prev_row();
     if (fuse) {       // this transform's share of the finalise: the pair fetched during the previous transform leaves as two int16 samples, the next one is fetched.
         // A wave of this kernel advances at the pace of its dependent chains, ~11 cycles per instruction of ANY kind (round 4's stamps), so what this block
-        // costs is its instruction count: the first in-loop form -- three evaluations of the range ends, scalar branches, two-sample scalar arithmetic,
-        // 46 instructions per wave and transform -- cost as much as converting everything in a prologue (+0.43 ms per 4096 slots, SQ counters in
-        // profiles/r6_sync_ab.txt); this one keeps the index in a register, advances it by a constant and does the arithmetic on the pair.
+        // costs is partly its instruction count: the first in-loop form -- three evaluations of the range ends, scalar branches, two-sample scalar arithmetic,
+        // 46 instructions per wave and transform -- cost as much as converting everything in a prologue; this one keeps the index in a register, advances it by
+        // a constant and does the arithmetic on the pair.  What remains (+0.3-0.45 ms per 4096 slots) is that the words stored here are READ BACK by the window
+        // loads two transforms later: the same store aimed at memory the kernel never reads costs nothing (4.06 against 4.50 ms), reading the lines by a
+        // scalar load before they are written does not help, non-temporal stores do not, windows from an LDS ring cost more (profiles/r6_sync_ab.txt).
         const v2f sc = cv * F.factor;                      // buf[k] *= factor            (v_pk_mul_f32: each half rounded on its own -- the same bits)
         const v2f bi = sc + 0.5f;                          // + 0.5f
         const int q0 = (int)bi.x, q1 = (int)bi.y;          // C truncation toward zero, then narrowed to int16
