@@ -868,15 +868,12 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         // 46 instructions per wave and transform -- cost as much as converting everything in a prologue; this one keeps the index in a register, advances it by
         // a constant and does the arithmetic on the pair.  What remains (+0.3-0.45 ms per 4096 slots) is that the words stored here are READ BACK by the window
         // loads two transforms later: the same store aimed at memory the kernel never reads costs nothing (4.06 against 4.50 ms), reading the lines by a
-        // scalar load before they are written does not help, non-temporal stores do not, windows from an LDS ring cost more (profiles/r6_sync_ab.txt).
+        // scalar load before they are written does not help, non-temporal stores do not, windows from an LDS ring cost more; and windows read from OTHER memory
+        // this workgroup wrote one to four transforms earlier are just as slow (4.9 ms): reading back what the CU has just written is what is slow (profiles/r6_sync_ab.txt).
         const v2f sc = cv * F.factor;                      // buf[k] *= factor            (v_pk_mul_f32: each half rounded on its own -- the same bits)
         const v2f bi = sc + 0.5f;                          // + 0.5f
         const int q0 = (int)bi.x, q1 = (int)bi.y;          // C truncation toward zero, then narrowed to int16
         const unsigned word = __builtin_amdgcn_perm((unsigned)q1, (unsigned)q0, 0x05040100u);      // (q0 & 0xFFFF) | (q1 << 16)
-#ifdef CWSLG_FUSE_DIAG_ELSEWHERE                           // timing diagnostics only (wrong frames): 1 = the pair goes to a place the kernel never reads (its own plane,
-        // five rows ahead); 2 = ... and the WINDOW is read from those scribbled rows (written one to four transforms ago by this workgroup) instead of the frame
-        if (fin_i < F.s_end && j + 5 < jend) { *(reinterpret_cast<CWSLG_GLOBAL unsigned *>(as_global_rw(plane)) + (size_t)(j + 5) * nbins + tid) = word; } else if (false)
-#endif
         if (fin_i < F.s_end) {
             if (CWSLG_FUSE_STORE_NT) __builtin_nontemporal_store(word, reinterpret_cast<CWSLG_GLOBAL unsigned *>(F.out + fin_i));
             else *reinterpret_cast<CWSLG_GLOBAL unsigned *>(F.out + fin_i) = word;
@@ -896,13 +893,6 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         // jper transforms): under `if (j + 1 < jend)` the registers were a merge of two paths, which hipcc kept as two sets and eight 64-bit moves per transform
         const int jn = CWSLG_SPEC_TIGHT ? min(j + 1, jend - 1) : j + 1;
         if constexpr (FMODE != 2) {
-#if defined(CWSLG_FUSE_DIAG_ELSEWHERE) && CWSLG_FUSE_DIAG_ELSEWHERE == 2
-        if (FMODE == 1 && j + 5 < jend && j > j0 + 4) {
-#pragma unroll
-            for (int a = 0; a < AMAX; ++a)
-                raw[a] = *(reinterpret_cast<const CWSLG_GLOBAL unsigned *>(as_global(plane)) + (size_t)(j + 1 + (a >> 1)) * nbins + b + 128 * (a & 1));
-        } else
-#endif
         if (CWSLG_SPEC_TIGHT || j + 1 < jend)
 #pragma unroll
         for (int a = 0; a < AMAX; ++a) raw[a] = (128 * a + b < NPACK) ? d32[(STEP / 2) * jn + 128 * a] : 0u;
