@@ -125,7 +125,7 @@ ABI_SYMBOLS = [
     "cwslg_abi_version", "cwslg_create", "cwslg_destroy", "cwslg_strerror", "cwslg_last_error",
     "cwslg_set_scale_factors", "cwslg_set_exact", "cwslg_receiver_open", "cwslg_receiver_close", "cwslg_push_iq", "cwslg_push_iq_many",
     "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_parse_decoder_line", "cwslg_channel_open_line", "cwslg_channel_open", "cwslg_channel_close", "cwslg_channel_tune", "cwslg_channel_tune_ex",
-    "cwslg_channel_info", "cwslg_process", "cwslg_set_process_threshold", "cwslg_slot_boundary", "cwslg_slot_boundary_begin", "cwslg_slot_boundary_end", "cwslg_slot_boundary_channel",
+    "cwslg_channel_info", "cwslg_process", "cwslg_set_process_threshold", "cwslg_flush", "cwslg_slot_boundary", "cwslg_slot_boundary_begin", "cwslg_slot_boundary_end", "cwslg_slot_boundary_channel",
     "cwslg_set_boundary_rendezvous", "cwslg_set_rendezvous_flag", "cwslg_rccl_unique_id", "cwslg_rccl_init",
     "cwslg_enable_long_sync", "cwslg_fetch_wspr_candidates", "cwslg_fetch_fst4w_candidates", "cwslg_long_sync_debug_fetch",
     "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_fetch_slot", "cwslg_write_wav", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
@@ -198,6 +198,7 @@ def load_library(build_if_missing=True):
     L.cwslg_channel_info.argtypes = [vp, i32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), C.POINTER(C.c_size_t)]
     L.cwslg_process.argtypes = [vp]
     L.cwslg_set_process_threshold.argtypes = [vp, i32]
+    L.cwslg_flush.argtypes = [vp]
     L.cwslg_slot_boundary.argtypes = [vp, i32, u64]
     L.cwslg_slot_boundary_begin.argtypes = [vp, i32, u64]
     L.cwslg_slot_boundary_end.argtypes = [vp]
@@ -413,6 +414,10 @@ class Context:
 
     def process(self):
         self._chk(self.L.cwslg_process(self.h))
+
+    def flush(self):
+        """cwslg_flush: demodulate everything pending now, whatever the process threshold."""
+        self._chk(self.L.cwslg_flush(self.h))
 
     def set_process_threshold(self, min_outputs=-1):
         """cwslg_set_process_threshold: 0 every process() launches; > 0 only once a channel has that many outputs pending; < 0 the library's own."""

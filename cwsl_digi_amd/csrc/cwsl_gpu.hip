@@ -1973,6 +1973,14 @@ int cwslg_process(cwslg_ctx *c)
     return process_locked(c, false);
 }
 
+int cwslg_flush(cwslg_ctx *c)
+{
+    if (!c) return CWSLG_ERR_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    hipSetDevice(c->device);
+    return process_locked(c, false);
+}
+
 int cwslg_set_process_threshold(cwslg_ctx *c, int min_outputs)
 {
     if (!c) return CWSLG_ERR_ARG;

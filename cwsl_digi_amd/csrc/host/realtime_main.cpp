@@ -51,6 +51,8 @@ struct Options {
     std::string mode = "threads";  // threads | batch
     int exact = 1, sync = 1;
     double process_ms = 0;         // stream time between explicit cwslg_process calls (0: the library demodulates when a ring fills or at the boundary)
+    int flush_before = 0;          // cwslg_flush this many blocks ahead of every slot boundary (a host with a slot clock knows when it is due): the boundary then
+                                   // finds only these blocks pending
     int process_threshold = 0;     // cwslg_set_process_threshold: 0 every cwslg_process() launches, -1 the library's own threshold, > 0 outputs
     std::string iq_path, out_dir;
     int iq_stride = 7;
@@ -108,6 +110,7 @@ int main(int argc, char **argv)
         else if (a == "--sync") o.sync = std::atoi(val());
         else if (a == "--process-ms") o.process_ms = std::atof(val());
         else if (a == "--process-threshold") o.process_threshold = std::atoi(val());
+        else if (a == "--flush-before") o.flush_before = std::atoi(val());
         else if (a == "--iq") o.iq_path = val();
         else if (a == "--iq-stride") o.iq_stride = std::atoi(val());
         else if (a == "--out") o.out_dir = val();
@@ -239,6 +242,7 @@ int main(int argc, char **argv)
                     CHK(cwslg_push_iq(ctx, rx_ids[r], block_ptr(r, k), o.block));
                     worst_push[r] = std::max(worst_push[r], ms_since(tp));
                     if (r == 0 && proc_every && (k + 1) % proc_every == 0 && !is_boundary_after(k)) CHK(cwslg_process(ctx));
+                    if (r == 0 && o.flush_before > 0 && is_boundary_after(k + o.flush_before) == 2 && !is_boundary_after(k)) CHK(cwslg_flush(ctx));
                     if (const int b = is_boundary_after(k)) meet.arrive([&] { boundary(k, b == 2); });
                 }
             });
@@ -254,6 +258,7 @@ int main(int argc, char **argv)
             CHK(cwslg_push_iq_many(ctx, R, rx_ids.data(), ptrs.data(), o.block));
             worst_push[0] = std::max(worst_push[0], ms_since(tp));
             if (proc_every && (k + 1) % proc_every == 0 && !is_boundary_after(k)) CHK(cwslg_process(ctx));
+            if (o.flush_before > 0 && is_boundary_after(k + o.flush_before) == 2 && !is_boundary_after(k)) CHK(cwslg_flush(ctx));
             if (const int b = is_boundary_after(k)) boundary(k, b == 2);
         }
     }
@@ -304,13 +309,13 @@ int main(int argc, char **argv)
                 "\"h2d_gbytes_per_s\": %.4f, \"push_calls\": %llu, \"push_batches\": %llu, \"push_host_ms_total\": %.1f, \"push_call_ms_worst\": %.3f, "
                 "\"push_late_ms_worst\": %.3f, \"push_late_ms_mean\": %.4f, \"host_cpu_seconds_per_second\": %.4f, "
                 "\"gpu_busy_fraction\": %.5f, \"demod_launches\": %llu, \"demod_ms\": %.2f, \"finalize_ms\": %.2f, \"sync_ms\": %.2f, "
-                "\"process_every_ms\": %.1f, \"process_threshold\": %d, \"process_deferred\": %llu, \"demod_redundancy\": %.4f, \"boundaries\": [",
+                "\"process_every_ms\": %.1f, \"process_threshold\": %d, \"flush_before_blocks\": %d, \"process_deferred\": %llu, \"demod_redundancy\": %.4f, \"boundaries\": [",
                 o.mode.c_str(), o.exact, o.sync, R, C, NCH, o.fs, o.block, o.speed, o.pre_blocks, o.slot_blocks, o.slots, stream_s, wall_ms / 1e3,
                 push_wall_ms / 1e3, setup_ms / 1e3, (double)R * total_blocks, (unsigned long long)st.blocks_dropped,
                 (unsigned long long)st.frames_emitted, (unsigned long long)st.frames_discarded, frames_fetched.load(),
                 (double)st.h2d_bytes / 1e9 / (push_wall_ms / 1e3), (unsigned long long)st.push_calls, (unsigned long long)st.push_batches, st.push_host_ms, wp,
                 wl, sl / std::max(1.0, n_push), cpu_s / (wall_ms / 1e3), (st.demod_ms + st.finalize_ms + st.sync_ms) / wall_ms,
-                (unsigned long long)st.demod_launches, st.demod_ms, st.finalize_ms, st.sync_ms, o.process_ms, o.process_threshold,
+                (unsigned long long)st.demod_launches, st.demod_ms, st.finalize_ms, st.sync_ms, o.process_ms, o.process_threshold, o.flush_before,
                 (unsigned long long)st.process_deferred, st.demod_samples ? (double)st.demod_blocks_read * (o.fs / 12000.0) / (double)st.demod_samples : 0.0);
     for (size_t k = 0; k < recs.size(); ++k)
         std::printf("%s{\"after_block\": %ld, \"boundary_call_ms\": %.3f, \"frames_ready_ms\": %.3f, \"all_frames_fetched_ms\": %.3f}", k ? ", " : "",

@@ -8,6 +8,8 @@ timeout 200 $RT --receivers 32 --channels-per-rx 128 --speed 1 --slots 2 --mode 
 timeout 200 $RT --receivers 32 --channels-per-rx 128 --speed 8 --slots 3 --mode threads > $O/rt_32x128_x8.json 2> $O/rt_32x128_x8.err
 timeout 200 $RT --receivers 4096 --channels-per-rx 1 --speed 1 --slots 2 --mode batch --process-ms 10.6 --process-threshold -1 > $O/rt_4096x1_batch_x1_wake.json 2> $O/rt_4096x1_batch_x1_wake.err
 timeout 200 $RT --receivers 4096 --channels-per-rx 1 --speed 1 --slots 2 --mode batch --process-ms 100 > $O/rt_4096x1_batch_x1_p100.json 2> $O/rt_4096x1_batch_x1_p100.err
+timeout 200 $RT --receivers 4096 --channels-per-rx 1 --speed 1 --slots 2 --mode batch --flush-before 8 > $O/rt_4096x1_batch_x1_flush8.json 2> $O/rt_4096x1_batch_x1_flush8.err
+timeout 200 $RT --receivers 32 --channels-per-rx 128 --speed 1 --slots 2 --mode threads --flush-before 8 > $O/rt_32x128_x1_flush8.json 2> $O/rt_32x128_x1_flush8.err
 python3 - <<'PY'
 import json, os
 O = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "r6rec")
@@ -16,8 +18,8 @@ out = {"note": "cwsl_gpu_realtime (csrc/host/realtime_main.cpp) on the round-6 l
                "boundaries[k]: ms from the cwslg_slot_boundary call to (its return / every frame and candidate list final on the device / all 4096 int16 frames in host memory).  "
                "gpu_busy_fraction = sum of the kernels' HIP-event spans / wall.  demod_redundancy = blocks put through the arithmetic (warm-up included) / blocks delivered.  "
                "_wake: cwslg_process() after EVERY block period with the library's launch threshold (cwslg_set_process_threshold(ctx, -1)); _p100: every 100 ms, no threshold "
-               "(round 5's behaviour)."}
-for name in ("rt_4096x1_batch_x1", "rt_32x128_x1", "rt_32x128_x8", "rt_4096x1_batch_x1_wake", "rt_4096x1_batch_x1_p100"):
+               "(round 5's behaviour); _flush8: cwslg_flush eight blocks (85 ms) ahead of every boundary -- a host with a slot clock knows when one is due."}
+for name in ("rt_4096x1_batch_x1", "rt_32x128_x1", "rt_32x128_x8", "rt_4096x1_batch_x1_wake", "rt_4096x1_batch_x1_p100", "rt_4096x1_batch_x1_flush8", "rt_32x128_x1_flush8"):
     try:
         out[name] = json.loads(open(os.path.join(O, name + ".json")).read().strip().splitlines()[-1])
     except Exception as e:

@@ -313,3 +313,33 @@ def test_candidate_lists_are_atomic_against_the_next_boundary(ctx, oracle):
         t.join()
     assert not errors, errors[:3]
     assert {e for _, e in seen} >= {n_epochs} and len({e for _, e in seen}) >= 3
+
+
+def test_process_threshold_defers_and_flush_overrides(ctx, oracle):
+    """cwslg_set_process_threshold / cwslg_flush (ABI 5): below the threshold a cwslg_process() over a few pending blocks returns without a
+    launch; cwslg_flush demodulates them at once; the boundary takes whatever is left.  The frame is the oracle's whichever way the launches fell."""
+    f, n_blk = 12000, 96
+    iq = oracle.synth_iq(77, n_blk * BLK, FS, tones_hz=[f + 1100.0, f + 1900.5], amp=1.2e4)
+    rx = ctx.receiver_open(FS, BLK, 0)
+    ch = ctx.channel_open(rx, f, "FT8")
+    oc = oracle.Channel("FT8", FS, BLK, f)
+    ctx.slot_boundary("FT8", 15); assert oc.boundary(15) is None
+    ctx.set_process_threshold(20480 if ctx.mode == "exact" else 100000)      # (exact mode: the value the library itself picks with -1)
+    base = ctx.stats()
+    for k in range(0, 40):
+        ctx.push_iq(rx, iq[k * BLK:(k + 1) * BLK]); ctx.process()
+    st = ctx.stats()
+    assert st["process_deferred"] - base["process_deferred"] == 40 and st["demod_launches"] == base["demod_launches"]
+    ctx.flush()
+    assert ctx.stats()["demod_launches"] == base["demod_launches"] + 1
+    for k in range(40, n_blk):
+        ctx.push_iq(rx, iq[k * BLK:(k + 1) * BLK]); ctx.process()
+    ctx.slot_boundary("FT8", 30)
+    st = ctx.stats()
+    assert st["demod_launches"] == base["demod_launches"] + 2 and st["demod_samples"] - base["demod_samples"] == n_blk * BLK
+    assert 1.0 < (st["demod_blocks_read"] - base["demod_blocks_read"]) * 16 / (n_blk * BLK) < 12.0
+    oc.push_many(iq); ref = oc.boundary(30, want_f32=True)
+    a, nv = ctx.fetch_audio_f32(ch)
+    assert nv == n_blk * BLK // 16
+    assert_frames_match(a[:nv], ref["f32"][:nv])
+    ctx.set_process_threshold(0)
