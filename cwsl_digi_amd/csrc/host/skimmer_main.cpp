@@ -76,7 +76,7 @@ int usage()
     std::fprintf(stderr,
         "usage: cwsl_gpu_skimmer --config config.ini --rx file=PATH|-[,header=1][,fs=N,block=N,lo=HZ] [--rx udp=PORT,fs=..]...\n"
         "         --out DIR [--start-ms UTC_MS] [--pace samples|wall] [--fast] [--sync 0|1] [--wav route|always|never]\n"
-        "         [--max-seconds S] [--device N] [--dry-run]\n"
+        "         [--max-seconds S] [--flush-ahead-ms MS (default 100; 0 = never)] [--device N] [--dry-run]\n"
         "         [--world N --rank R --rccl-id FILE]   one process per GPU: decoders shard by receiver (receiver k -> rank k mod N),\n"
         "                                               RCCL rendezvous at every slot boundary; rank 0 writes FILE, the others read it\n");
     return 2;
@@ -100,6 +100,7 @@ int main(int argc, char **argv)
     int sync = 1, device = -1, world = 1, rank = 0;
     std::string rccl_id_path;
     double max_seconds = 0;
+    long flush_ahead_ms = 100;     // cwslg_flush this long before the next slot edge (0: never): the boundary then finds a few blocks pending, not seconds
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto need = [&](const char *) -> const char * { return (i + 1 < argc) ? argv[++i] : nullptr; };
@@ -113,6 +114,7 @@ int main(int argc, char **argv)
         else if (a == "--sync" && (v = need("sync"))) sync = std::atoi(v);
         else if (a == "--device" && (v = need("device"))) device = std::atoi(v);
         else if (a == "--max-seconds" && (v = need("max"))) max_seconds = std::atof(v);
+        else if (a == "--flush-ahead-ms" && (v = need("flush"))) flush_ahead_ms = std::atol(v);
         else if (a == "--world" && (v = need("world"))) world = std::atoi(v);
         else if (a == "--rank" && (v = need("rank"))) rank = std::atoi(v);
         else if (a == "--rccl-id" && (v = need("id"))) rccl_id_path = v;
@@ -357,6 +359,7 @@ int main(int argc, char **argv)
     // main loop: always advance the receiver that is furthest behind in (virtual) time
     std::vector<std::complex<float>> blk;
     const bool wall = pace == "wall";
+    uint64_t flushed_edge = 0;
     for (;;) {
         int pick = -1; double tmin = 0;
         for (size_t k = 0; k < rxs.size(); ++k) {
@@ -379,6 +382,16 @@ int main(int argc, char **argv)
             for (const Rx &q : rxs) { if (q.eof) continue; const double tq = (double)q.samples / q.spec.fs; if (t < 0 || tq < t) t = tq; }
             if (t < 0) t = (double)r.samples / r.spec.fs;
             now_ms = start_ms + (uint64_t)(t * 1000.0);
+        }
+        // a slot clock knows when the next edge is due: demodulate what is pending a little ahead of it (cwslg_flush), so that the boundary itself
+        // finds only the last few blocks and the frames are final one sync stage after it (profiles/r6_realtime.json: 10 instead of 13.6 ms at 4096 channels)
+        if (flush_ahead_ms > 0 && !next_edge.empty()) {
+            uint64_t first = ~0ull;
+            for (const auto &ge : next_edge) first = std::min(first, ge.second);
+            if (first != flushed_edge && first > now_ms && first - now_ms <= (uint64_t)flush_ahead_ms) {
+                if ((rc = cwslg_flush(ctx)) != CWSLG_OK) die("flush", rc);
+                flushed_edge = first;
+            }
         }
         fire_due(now_ms);
     }
