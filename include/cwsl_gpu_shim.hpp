@@ -200,7 +200,13 @@ class FrameSink {
 public:
     using Callback = std::function<void(std::vector<std::int16_t> &&audio, const std::string &mode, std::uint64_t epochTime,
                                         std::int64_t baseFreq, int instanceId, const std::string &cwd, float trperiod)>;
+    // ABI 5: the same hand-off with the candidate list of the SAME epoch beside the audio (cwslg_fetch_slot: one call, one ticket) -- for a decoder
+    // pool whose ItemToDecode (DecoderPool.hpp:174-210) is extended by a candidate vector; FT8 / FT4 channels with the sync stage on, empty otherwise
+    using SlotCallback = std::function<void(std::vector<std::int16_t> &&audio, const std::string &mode, std::uint64_t epochTime,
+                                            std::int64_t baseFreq, int instanceId, const std::string &cwd, float trperiod,
+                                            std::vector<cwslg_candidate> &&candidates)>;
     explicit FrameSink(Callback cb) : cb_(std::move(cb)) {}
+    explicit FrameSink(SlotCallback cb, int maxCandidates = 600) : scb_(std::move(cb)), max_cand_(maxCandidates) {}
     // ssbFreq, instanceId, cwd: Instance's members of the same names (Instance.cpp:121-176)
     void add(SsbChannel &ch, std::int64_t ssbFreq, int instanceId, const std::string &cwd)
     {
@@ -212,12 +218,14 @@ public:
         int n = 0;
         for (Entry &e : entries_) {
             std::vector<std::int16_t> audio;
+            std::vector<cwslg_candidate> cands;
             std::uint64_t t0 = 0;
-            if (!e.ch->fetch(audio, t0)) continue;
+            if (!(scb_ ? e.ch->fetchSlot(audio, t0, cands, max_cand_) : e.ch->fetch(audio, t0))) continue;
             if (e.seen && t0 == e.last) continue;            // that frame went out at an earlier boundary
             e.seen = true;
             e.last = t0;
-            cb_(std::move(audio), e.ch->mode(), t0, e.ssbFreq, e.instanceId, e.cwd, e.ch->trPeriod());
+            if (scb_) scb_(std::move(audio), e.ch->mode(), t0, e.ssbFreq, e.instanceId, e.cwd, e.ch->trPeriod(), std::move(cands));
+            else cb_(std::move(audio), e.ch->mode(), t0, e.ssbFreq, e.instanceId, e.cwd, e.ch->trPeriod());
             ++n;
         }
         return n;
@@ -225,6 +233,8 @@ public:
 private:
     struct Entry { SsbChannel *ch; std::int64_t ssbFreq; int instanceId; std::string cwd; std::uint64_t last; bool seen; };
     Callback cb_;
+    SlotCallback scb_;
+    int max_cand_ = 600;
     std::vector<Entry> entries_;
 };
 

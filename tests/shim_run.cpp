@@ -67,6 +67,13 @@ int main(int argc, char **argv)
         if (sink.collect() != 1 || sink.collect() != 0) return 11;     // delivered once
         if (delivered != 1 || sink_t0 != t0 || sink_crc != crc32(audio.data(), audio.size() * 2) || sink_tr != 15.0f || sink_id != 3 ||
             sink_f != 28074000 || sink_mode != "FT8" || sink_cwd != "/tmp/cwd3") return 12;
+        {   // ABI 5: FrameSink with the candidate list beside the audio: the same frame once more, the list empty (sync stage off)
+            int n2 = 0; std::uint64_t e2 = 0; std::uint32_t c2 = 0; std::size_t nc2 = 99;
+            cwslgpu::FrameSink sink2([&](std::vector<std::int16_t> &&a, const std::string &, std::uint64_t epoch, std::int64_t, int, const std::string &, float,
+                                         std::vector<cwslg_candidate> &&cands) { ++n2; e2 = epoch; c2 = crc32(a.data(), a.size() * 2); nc2 = cands.size(); });
+            sink2.add(chan, 28074000, 3, "/tmp/cwd3");
+            if (sink2.collect() != 1 || sink2.collect() != 0 || n2 != 1 || e2 != t0 || c2 != crc32(audio.data(), audio.size() * 2) || nc2 != 0) return 15;
+        }
         {   // ABI 5: the slot's results under one ticket -- the same frame and epoch; no list (the sync stage is off on this context)
             std::vector<std::int16_t> audio3; std::vector<cwslg_candidate> cands3; std::uint64_t t3 = 0;
             if (!chan.fetchSlot(audio3, t3, cands3) || t3 != t0 || audio3 != audio || !cands3.empty()) return 14;
