@@ -125,7 +125,7 @@ ABI_SYMBOLS = [
     "cwslg_abi_version", "cwslg_create", "cwslg_destroy", "cwslg_strerror", "cwslg_last_error",
     "cwslg_set_scale_factors", "cwslg_set_exact", "cwslg_receiver_open", "cwslg_receiver_close", "cwslg_push_iq", "cwslg_push_iq_many",
     "cwslg_push_iq_device", "cwslg_push_synth", "cwslg_ring_commit", "cwslg_ring_commit_all", "cwslg_ring_info", "cwslg_parse_decoder_line", "cwslg_channel_open_line", "cwslg_channel_open", "cwslg_channel_close", "cwslg_channel_tune", "cwslg_channel_tune_ex",
-    "cwslg_channel_info", "cwslg_process", "cwslg_set_process_threshold", "cwslg_flush", "cwslg_slot_boundary", "cwslg_slot_boundary_begin", "cwslg_slot_boundary_end", "cwslg_slot_boundary_channel",
+    "cwslg_channel_info", "cwslg_process", "cwslg_set_process_threshold", "cwslg_flush", "cwslg_exact_stream_length", "cwslg_slot_boundary", "cwslg_slot_boundary_begin", "cwslg_slot_boundary_end", "cwslg_slot_boundary_channel",
     "cwslg_set_boundary_rendezvous", "cwslg_set_rendezvous_flag", "cwslg_rccl_unique_id", "cwslg_rccl_init",
     "cwslg_enable_long_sync", "cwslg_fetch_wspr_candidates", "cwslg_fetch_fst4w_candidates", "cwslg_long_sync_debug_fetch",
     "cwslg_synchronize", "cwslg_fetch_frame", "cwslg_fetch_slot", "cwslg_write_wav", "cwslg_fetch_audio_f32", "cwslg_frame_device_ptrs",
@@ -199,6 +199,7 @@ def load_library(build_if_missing=True):
     L.cwslg_process.argtypes = [vp]
     L.cwslg_set_process_threshold.argtypes = [vp, i32]
     L.cwslg_flush.argtypes = [vp]
+    L.cwslg_exact_stream_length.argtypes = [u64, u32, u32, i32]; L.cwslg_exact_stream_length.restype = u32
     L.cwslg_slot_boundary.argtypes = [vp, i32, u64]
     L.cwslg_slot_boundary_begin.argtypes = [vp, i32, u64]
     L.cwslg_slot_boundary_end.argtypes = [vp]
@@ -263,6 +264,11 @@ def pool_sizing(counts, decoderburden=1.0, n_decoders=None):
     if rc != 0:
         raise CwslGpuError(rc, "pool_sizing")
     return nj.value, nw.value
+
+
+def exact_stream_length(total_blocks, max_blocks, cu_count=256, latency=True):
+    """cwslg_exact_stream_length: outputs per stream of the bit-identical kernel for a launch of that size (pure; no GPU needed)."""
+    return int(load_library().cwslg_exact_stream_length(int(total_blocks), int(max_blocks), int(cu_count), 1 if latency else 0))
 
 
 def find_band(bands, f_hz):

@@ -606,16 +606,23 @@ int restore_open_tuning(cwslg_ctx *c, Channel &ch, const Receiver &rx)
 // long as the channel with the most pending blocks allows with all 32 lanes of its wave busy (max_blocks / 32), i.e. one wave per channel and
 // warm-up share 32 / seg, unless the latency policy's streams are longer still (bench scale).  stats.demod_blocks_read counts the blocks a
 // launch actually fetches and puts through the arithmetic, warm-up included: demod_blocks_read x D / demod_samples is the redundancy.
+// (pure: exported as cwslg_exact_stream_length so that the CPU suite can hold the policy to the figures the notebook quotes)
+unsigned exact5_stream_length(uint64_t total_blocks, unsigned max_blocks, unsigned cu_count, unsigned seg_cap, bool latency)
+{
+    const uint64_t waves_min = (uint64_t)cu_count * 8 * 2;
+    unsigned seg = (unsigned)std::min<uint64_t>(seg_cap, (total_blocks + 32 * waves_min - 1) / (32 * waves_min));
+    seg = std::max(4u, (seg + 3) / 4 * 4);
+    if (!latency) seg = std::max(seg, std::min(seg_cap, max_blocks / 32 / 4 * 4));
+    return seg;
+}
+
 template <int D>
 int launch_exact5(cwslg_ctx *c, const std::vector<ChanWork> &works, unsigned max_blocks, uint32_t fs, bool chunk_major, bool latency)
 {
     if (works.empty()) return CWSLG_OK;
     uint64_t total_blocks = 0;
     for (const ChanWork &w : works) total_blocks += w.n_blocks;
-    const uint64_t waves_min = (uint64_t)c->cu_count * 8 * 2;
-    unsigned seg = (unsigned)std::min<uint64_t>(c->exact5_seg_cap, (total_blocks + 32 * waves_min - 1) / (32 * waves_min));
-    seg = std::max(4u, (seg + 3) / 4 * 4);
-    if (!latency) seg = std::max(seg, std::min(c->exact5_seg_cap, max_blocks / 32 / 4 * 4));
+    unsigned seg = exact5_stream_length(total_blocks, max_blocks, (unsigned)c->cu_count, c->exact5_seg_cap, latency);
     if (c->exact5_seg_force) seg = c->exact5_seg_force;
     const int chunks = (int)((max_blocks + 32 * seg - 1) / (32 * seg));
     for (const ChanWork &w : works) {                   // streams of seg outputs (the last one shorter), each 32 blocks of warm-up
@@ -1971,6 +1978,11 @@ int cwslg_process(cwslg_ctx *c)
         if (!due) { c->stats.process_deferred++; return CWSLG_OK; }
     }
     return process_locked(c, false);
+}
+
+unsigned cwslg_exact_stream_length(uint64_t total_blocks, unsigned max_blocks, unsigned cu_count, int latency)
+{
+    return exact5_stream_length(total_blocks, max_blocks, cu_count ? cu_count : 256u, kExact5SegCap, latency != 0);
 }
 
 int cwslg_flush(cwslg_ctx *c)

@@ -196,6 +196,12 @@ int cwslg_set_process_threshold(cwslg_ctx *ctx, int min_outputs);
  * sync stage after the boundary call instead of one demod launch + one sync stage (cwsl_gpu_realtime --flush-before: 4096 channels,
  * 9.9-10.2 instead of 13.6 ms, profiles/r6_realtime.json). */
 int cwslg_flush(cwslg_ctx *ctx);
+/* The launch policy of the bit-identical kernel as a pure function (no context needed; for tests and capacity planning): outputs per stream for a
+ * launch over total_blocks pending blocks (one block = one 12 kHz output), max_blocks of them on the busiest channel, on a chip of cu_count CUs
+ * (0 = 256).  Every stream pays a 32-block warm-up, so a launch fetches and multiplies (1 + 32 / length) x what it delivers.  latency != 0: a
+ * boundary's rule (the shortest launch: total / 65536, at least 4); 0: the rule of cwslg_process / cwslg_flush / ring pressure (at least one
+ * full wave per channel: max_blocks / 32).  At most 1408. */
+unsigned cwslg_exact_stream_length(uint64_t total_blocks, unsigned max_blocks, unsigned cu_count, int latency);
 /* Replaces SyncPredicate::store(true) for every predicate of one group (CWSL_DIGI.cpp:247-251) and the
  * per-Instance reaction to it (Instance.cpp:203-253): swap frames, stamp the new frame with epoch_s,
  * finalise (peak-normalise + int16) the finished one unless its start time is 0, restart the demodulator. */

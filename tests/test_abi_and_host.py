@@ -131,3 +131,22 @@ def test_product_library_has_one_kernel_per_job_and_no_lab_switches():
     # FT8: Costas search + candidate selection in one launch per boundary, or (few channels) one workgroup per band + the selection
     assert any("ft8_sync_chan_kernel" in k for k in kp) and any("ft8_sync2d_v3_kernel" in k for k in kp)
     assert len(kp) <= 37, sorted(kp)                   # round 4: + scatter_blocks_kernel (cwslg_push_iq_many); round 5: exact5<16 / 8 / 4> for exact4 + exact3<8 / 4>
+
+
+def test_exact_kernel_launch_policy_is_what_the_notebook_says():
+    """cwslg_exact_stream_length (pure): outputs per stream of demod_exact5_kernel by launch size.  Every stream pays a 32-block warm-up, so the
+    redundancy of a launch is 1 + 32 / length (docs/lab-notebook.md, "Round 6: launch policy").  No GPU needed."""
+    import cwsl_digi_amd as P
+    L = P.exact_stream_length
+    red = lambda n: 1.0 + 32.0 / n
+    assert L(4096 * 180000, 180000, 256, latency=True) == 1408 == L(4096 * 180000, 180000, 256, latency=False)      # the bench: capped, 1.023
+    assert L(4096 * 128, 128, 256, latency=True) == 4 and red(4) == 9.0                                             # a launch per block: nine-fold
+    assert L(4096 * 128, 128, 256, latency=False) == 4                                                               # (nothing to gain: 128 / 32 = 4)
+    assert L(1024 * 20480, 20480, 256, latency=False) == 640 and abs(red(640) - 1.05) < 1e-9                        # the library's own threshold: 5 %
+    assert L(1024 * 20480, 20480, 256, latency=True) == 160                                                          # the same launch, were somebody waiting
+    assert L(4096 * 28800, 28800, 256, latency=False) == 900 == L(4096 * 28800, 28800, 256, latency=True)           # ring pressure at 4096 channels (2.4 s pending)
+    assert L(10 * 28800, 28800, 256, latency=True) == 4 and L(10 * 28800, 28800, 256, latency=False) == 900         # ten decoders: short launch at the boundary, one wave each otherwise
+    for n in (1, 4, 100, 10 ** 6, 10 ** 10):
+        for lat in (True, False):
+            v = L(n, min(n, 10 ** 6), 256, lat)
+            assert 4 <= v <= 1408 and v % 4 == 0
