@@ -631,8 +631,8 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     // RING = a window (960 pairs) + one step (240 pairs), every pair stored twice, RING apart, so that a lane's eight reads base + 128 a need no wrap.  The
     // workgroup converts 480 samples per transform (lanes 0..239, one pair each) into the ring AND into the int16 frame in HBM -- which the kernel then never
     // reads.  The idea: the frame's stores cost 0.5 ms per 1.5 GB when the same CU reads them back two transforms later, the plane's write-only 6 GB cost
-    // 0.17 ms.  The result: 5.2 against 4.5 ms (profiles/r6_sync_ab.txt) -- eight LDS reads at the head of every transform's dependent chain, with nothing
-    // to hide them behind (prefetching them into registers needs the eight VGPRs the kernel does not have), cost more than the stores they make cheap.
+    // 0.17 ms.  The result: 5.1-5.2 against 4.5 ms (profiles/r6_sync_ab.txt), with the ring's reads at the head of the transform or prefetched into registers behind the
+    // previous transform's first barrier alike: ten more LDS operations per lane and transform cost this kernel more than the read-back they avoid.
     constexpr int RING = NPACK + STEP / 2;                 // 1200 pairs
     __shared__ unsigned s_ring[FMODE == 2 ? 2 * RING : 1];
     const SyncWork *w = works + blockIdx.y;
@@ -715,6 +715,10 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     if constexpr (FMODE != 2) {
 #pragma unroll
         for (int a = 0; a < AMAX; ++a) raw[a] = (128 * a + b_ < NPACK) ? d32[(STEP / 2) * j0 + 128 * a] : 0u;
+    } else {                         // window j0 from the ring; from here on ring_rd is the base of the NEXT window, read behind each transform's first barrier
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) raw[a] = s_ring[ring_rd + 128 * a];
+        ring_rd += (unsigned)(STEP / 2); if (ring_rd >= (unsigned)RING) ring_rd -= (unsigned)RING;
     }
     float2 wn[WINDOW ? AMAX : 1];
     if (WINDOW) {
@@ -821,11 +825,6 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     const char *const w128_bytes = reinterpret_cast<const char *>(&s_w128[0]);
     char *const pw_bytes = reinterpret_cast<char *>(&s_pw[0]);
     PSTAMP(0);
-    if constexpr (FMODE == 2) {      // window j from the ring: pairs ring_rd + 128 a (the second copy makes the run contiguous)
-        const unsigned *const rp = s_ring + ring_rd;
-#pragma unroll
-        for (int a = 0; a < AMAX; ++a) raw[a] = rp[128 * a];
-    }
     float2 z[AMAX];
 #pragma unroll
     for (int a = 0; a < AMAX; ++a) {
@@ -882,7 +881,6 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         if constexpr (FMODE == 2) {
             fin_i += (unsigned)STEP;
             ring_wr += (unsigned)(STEP / 2); if (ring_wr >= (unsigned)RING) ring_wr -= (unsigned)RING;
-            ring_rd += (unsigned)(STEP / 2); if (ring_rd >= (unsigned)RING) ring_rd -= (unsigned)RING;
         } else {
             fin_i += 512u;
         }
@@ -906,13 +904,23 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     PSTAMP(1);
     lds_barrier();
     PSTAMP(2);
+    if constexpr (FMODE == 2) {      // the next window from the ring (its last quarter was written at the top of this transform, ahead of the barrier): in registers by the next top
+#pragma unroll
+        for (int a = 0; a < AMAX; ++a) raw[a] = s_ring[ring_rd + 128 * a];
+        ring_rd += (unsigned)(STEP / 2); if (ring_rd >= (unsigned)RING) ring_rd -= (unsigned)RING;
+    }
 
     // stage 2, pass A: DIT stages len = 2,4,8 (see the first version)
+#ifndef CWSLG_SPEC_MERGE_AB
+#define CWSLG_SPEC_MERGE_AB 1          // round 6: passes A and B under ONE exec-mask region instead of three (115 instead of 128 VGPRs, -0.02 ms; 0 = the A/B partner)
+#endif
+    const bool inAB = tid < NGRP;
+    if (CWSLG_SPEC_MERGE_AB ? inAB : true) {
     {
         const int c = tid >> 4, g = tid & 15;
         const int gb = (int)(__brev((unsigned)g) >> 28);
         float2 e[8];
-        if (tid < NGRP) {
+        if (CWSLG_SPEC_MERGE_AB || inAB) {
             // (one address, the eight columns 16 k3 + gb as instruction offsets: indexed as s_y[c][16 * k3 + gb] hipcc built every address from scratch)
             const char *const pa = sy_bytes + 8u * (unsigned)(c * SY_PITCH + gb);
 #pragma unroll
@@ -927,7 +935,7 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (tid < NGRP) {
+        if (CWSLG_SPEC_MERGE_AB || inAB) {
             bfly_one(e[0], e[1]); bfly_one(e[2], e[3]); bfly_one(e[4], e[5]); bfly_one(e[6], e[7]);
             bfly_one(e[0], e[2]); bfly_mj(e[1], e[3]); bfly_one(e[4], e[6]); bfly_mj(e[5], e[7]);
             bfly_one(e[0], e[4]); bfly(e[1], e[5], s_w128[16]); bfly_mj(e[2], e[6]); bfly(e[3], e[7], s_w128[48]);
@@ -945,7 +953,7 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     PSTAMP(3);
     // pass B: stages len = 16,32,64
-    if (tid < NGRP) {
+    if (CWSLG_SPEC_MERGE_AB || inAB) {
         const int r = tid & 7;
         float2 e[8];
 #pragma unroll
@@ -964,6 +972,7 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) *reinterpret_cast<float2 *>(sy_bytes + IA.aB[q]) = e[q];
+    }
     }
     PSTAMP(4);
     lds_barrier();
