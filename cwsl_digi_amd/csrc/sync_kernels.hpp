@@ -860,33 +860,6 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
             else for (int k4 = tid; 4 * k4 < nbins; k4 += 256) plane_store(out4 + k4, *reinterpret_cast<const v4f *>(s_pw + 4 * k4));
         }
     };
-#ifndef CWSLG_SPEC_UNCOND
-#define CWSLG_SPEC_UNCOND 0
-#endif
-    // CWSLG_SPEC_UNCOND=1 (round 6 experiment, FT8 fused form): every vector-memory operation of the transform UNCONDITIONAL and in the order loads, then
-    // stores -- inactive lanes are steered to harmless addresses instead of being masked off -- so that hipcc can count them and the top of the next transform
-    // waits for the window with vmcnt(N), N = the stores behind it, instead of vmcnt(0).
-    constexpr bool UNCOND = CWSLG_SPEC_UNCOND && FMODE == 1 && NA == 15;
-    if constexpr (UNCOND) {
-        const unsigned flen_ = w->fin.frame_len;
-        const v2f bi = cv * F.factor + 0.5f;
-        const unsigned word = __builtin_amdgcn_perm((unsigned)(int)bi.y, (unsigned)(int)bi.x, 0x05040100u);
-        const unsigned st_i = fin_i < F.s_end ? fin_i : flen_ - 2u;                 // inactive lanes: the frame's last pair -- always zeros (a frame never fills), and cv is 0 there
-        fin_i += 512u;
-        const unsigned ld_i = fin_i < fin_lim ? fin_i : 0u;
-        const v2f nx = *reinterpret_cast<const CWSLG_GLOBAL v2f *>(F.frame + ld_i);
-        const int jn = min(j + 1, jend - 1);
-#pragma unroll
-        for (int a = 0; a < AMAX; ++a) raw[a] = d32[(STEP / 2) * jn + 128 * a];       // (lanes past the window read on into the frame: in bounds, never used)
-        cv = fin_i < fin_lim ? nx : v2f{0.0f, 0.0f};
-        {
-            CWSLG_GLOBAL v4f *out4 = reinterpret_cast<CWSLG_GLOBAL v4f *>(as_global_rw(plane) + (size_t)max(j - 1, j0) * nbins);
-            const int n4 = nbins >> 2;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) { const int k4 = min(tid + 256 * q, n4 - 1); plane_store(out4 + k4, *reinterpret_cast<const v4f *>(s_pw + 4 * k4)); }
-        }
-        *reinterpret_cast<CWSLG_GLOBAL unsigned *>(F.out + st_i) = (fin_i - 512u) < F.s_end ? word : 0u;
-    } else {
     if (!CWSLG_SPEC_LOADS_FIRST) store_prev_row();
     if (fuse) {       // this transform's share of the finalise: the pair fetched during the previous transform leaves as two int16 samples, the next one is fetched.
         // A wave of this kernel advances at the pace of its dependent chains, ~11 cycles per instruction of ANY kind (round 4's stamps), so what this block
@@ -924,7 +897,6 @@ __global__ __launch_bounds__(256, CWSLG_SPEC_WAVES) void symbol_spectra_v2_kerne
         }
     }
     if (CWSLG_SPEC_LOADS_FIRST) store_prev_row();
-    }   // !UNCOND
 
     // stage 1 (wave-uniform split of the outputs between waves 0-1 and waves 2-3)
     if (tid < 128) spectra_stage1_regs<0, NA, AMAX>(z, s_y, tw1, b);
