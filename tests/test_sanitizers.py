@@ -2,7 +2,7 @@
 cwsl_gpu.hip is rebuilt with -fsanitize=address,undefined on its HOST code only (-fno-gpu-sanitize: GPU sanitizers are not available on this pool)
 and the tests of its pure-function half -- decoder= grammar, slot clock, pool sizing, spot parsing, the decoder hand-off block and commands, WAV
 header -- run against that build in a child process with the sanitizer runtime preloaded.  Any report fails the test.
-The threaded host programs get a ThreadSanitizer build on the GPU box: scripts/gpu_r5_tsan.sh (profiles/r5_tsan.txt)."""
+The threaded host programs get a ThreadSanitizer build on the GPU box: scripts/gpu_r6_tsan.sh (profiles/r6_tsan.txt; round 5: gpu_r5_tsan.sh, r5_tsan.txt)."""
 import glob
 import os
 import subprocess
